@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Run in the build container only (needs /root/reference and oracle/_ref/dw, built by
+oracle/build_ref.sh).  What it commits is DATA, never reference source:
+
+  tests/golden/<fixture>/graph.{meta,variables,weights,factors,domains}
+      the reference's own TSV test fixtures (/root/reference/test/<fixture>/*.tsv)
+      converted with the reference's `dw text2bin` exactly as
+      /root/reference/test/run_end_to_end.sh:6-15 does (per-kind files are
+      concatenated in glob order, as its `cat graph.factors*` does).
+  tests/golden/<fixture>/dw-args
+      the fixture's sampler flags (test/<fixture>/dw-args).
+  tests/golden/<fixture>/ref_{short,full}.{weights.text,text}
+      outputs of the reference `dw gibbs -t 1 -c 1` (single worker => bit
+      reproducible) with the fixture's flags ("full") and with
+      the epoch counts cut to <=100 ("short").
+  tests/golden/synth_*/...
+      small synthetic graphs (written by sampler_amd.binary_format from
+      sampler_amd.synthetic) plus the reference's multi-threaded marginals on them.
+"""
+import glob
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("DW_REFERENCE_DIR", "/root/reference")
+DW = os.path.join(ROOT, "oracle", "_ref", "dw")
+
+FIXTURES = [
+    "biased_coin",
+    "biased_coin_continuous",
+    "biased_coin_with_multinomial",
+    "biased_coin_truthiness",
+    "partial_observation",
+    "sparse_domains",
+    "sparse_multinomial2",
+]
+
+
+def short_args(args):
+    """Cut -l/-i epoch counts to at most 100."""
+    out = list(args)
+    for i, a in enumerate(out):
+        if a in ("-l", "-i"):
+            out[i + 1] = str(min(int(out[i + 1]), 100))
+    return out
+
+
+def run_ref(gdir, args, outdir):
+    cmd = [DW, "gibbs", "-m", os.path.join(gdir, "graph.meta"),
+           "-w", os.path.join(gdir, "graph.weights"),
+           "-v", os.path.join(gdir, "graph.variables"),
+           "-f", os.path.join(gdir, "graph.factors"),
+           "-o", outdir, "--quiet"]
+    if os.path.exists(os.path.join(gdir, "graph.domains")):
+        cmd += ["--domains", os.path.join(gdir, "graph.domains")]
+    cmd += args
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+
+
+def convert_fixture(name):
+    src = os.path.join(REF, "test", name)
+    dst = os.path.join(HERE, name)
+    os.makedirs(dst, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        for what in ("variable", "domain", "factor", "weight"):
+            parts = []
+            for tsv in sorted(glob.glob(os.path.join(src, what + "s*.tsv"))):
+                base = os.path.basename(tsv)[:-4]
+                out = os.path.join(tmp, "graph." + base)
+                extra = []
+                argf = os.path.join(src, base + ".text2bin-args")
+                if os.path.exists(argf):
+                    extra = open(argf).read().split()
+                subprocess.run([DW, "text2bin", what, tsv, out, "/dev/null"] + extra,
+                               check=True)
+                parts.append(out)
+            if parts:
+                # run_end_to_end.sh feeds `cat graph.<kind>s*` (glob order)
+                parts.sort()
+                with open(os.path.join(dst, "graph." + what + "s"), "wb") as f:
+                    for p in parts:
+                        f.write(open(p, "rb").read())
+    shutil.copy(os.path.join(src, "graph.meta"), os.path.join(dst, "graph.meta"))
+    shutil.copy(os.path.join(src, "dw-args"), os.path.join(dst, "dw-args"))
+    os.chmod(os.path.join(dst, "graph.meta"), 0o644)
+    os.chmod(os.path.join(dst, "dw-args"), 0o644)
+    args = open(os.path.join(src, "dw-args")).read().split()
+    # strip any -c/-t the fixture sets; goldens are single worker, single copy
+    clean = []
+    skip = False
+    for a in args:
+        if skip:
+            skip = False
+            continue
+        if a in ("-c", "-t", "--n_datacopy", "--n_threads"):
+            skip = True
+            continue
+        clean.append(a)
+    for tag, a in (("full", clean), ("short", short_args(clean))):
+        with tempfile.TemporaryDirectory() as out:
+            run_ref(dst, a + ["-t", "1", "-c", "1"], out)
+            shutil.copy(os.path.join(out, "inference_result.out.weights.text"),
+                        os.path.join(dst, "ref_%s.weights.text" % tag))
+            res = os.path.join(out, "inference_result.out.text")
+            if os.path.exists(res):
+                shutil.copy(res, os.path.join(dst, "ref_%s.text" % tag))
+        with open(os.path.join(dst, "ref_%s.args" % tag), "w") as f:
+            f.write(" ".join(a + ["-t", "1", "-c", "1"]) + "\n")
+
+
+def synth_goldens():
+    """Reference marginals / weights on small synthetic graphs (1/500 scale of
+    BASELINE.json configs 2-4).  The reference runs multi-threaded here, so these
+    are statistical (KS / tolerance) pins, not bit-exact ones."""
+    sys.path.insert(0, ROOT)
+    from sampler_amd import synthetic, binary_format
+    cases = {
+        "synth_cfg2": (synthetic.cfg2(2000, n_weights=200, seed=1234),
+                       ["-l", "0", "-i", "400"]),
+        "synth_cfg3": (synthetic.cfg3(2000, n_weights=200, seed=1234),
+                       ["-l", "60", "-i", "400", "--alpha", "0.01",
+                        "--diminish", "0.95", "--reg_param", "0.01"]),
+        "synth_cfg3b": (synthetic.cfg3b(2000, n_weights=200, seed=1234),
+                        ["-l", "60", "-i", "400", "--alpha", "0.01",
+                         "--diminish", "0.95", "--reg_param", "0.01"]),
+        "synth_cfg4": (synthetic.cfg4(1000, card=8, seed=1234, learn=False),
+                       ["-l", "0", "-i", "400"]),
+    }
+    for name, (g, args) in cases.items():
+        dst = os.path.join(HERE, name)
+        os.makedirs(dst, exist_ok=True)
+        binary_format.write_graph(g, dst)
+        with open(os.path.join(dst, "dw-args"), "w") as f:
+            f.write(" ".join(args) + "\n")
+        with tempfile.TemporaryDirectory() as out:
+            run_ref(dst, args, out)
+            shutil.copy(os.path.join(out, "inference_result.out.weights.text"),
+                        os.path.join(dst, "ref.weights.text"))
+            shutil.copy(os.path.join(out, "inference_result.out.text"),
+                        os.path.join(dst, "ref.text"))
+
+
+if __name__ == "__main__":
+    if not os.path.exists(DW):
+        sys.exit("oracle/_ref/dw missing: run oracle/build_ref.sh first")
+    which = sys.argv[1:] or ["fixtures", "synth"]
+    if "fixtures" in which:
+        for fx in FIXTURES:
+            convert_fixture(fx)
+            print("golden:", fx)
+    if "synth" in which:
+        synth_goldens()
+        print("golden: synthetic")
