@@ -1,0 +1,139 @@
+"""Synthetic factor graphs of BASELINE.json's configs.  All seeds
+fixed; generators are numpy-vectorised so the 10M-variable graph builds in seconds.
+
+`var_offset`/`total_variables` generate one contiguous variable block of a larger
+graph (the variable-block shard one GPU owns, config 5): ids are local to the block,
+weights are global.
+"""
+import numpy as np
+
+from .rawgraph import (RawGraph, FUNC_ISTRUE, FUNC_EQUAL, FUNC_AND_CATEGORICAL,
+                       DTYPE_BOOLEAN, DTYPE_CATEGORICAL)
+
+
+def _rng(seed, shard=0):
+    return np.random.Generator(np.random.PCG64([seed, shard]))
+
+
+def _unary_block(V, k, W, rng):
+    """k unary factors per variable, emitted variable-major."""
+    F = V * k
+    edge_vid = np.repeat(np.arange(V, dtype=np.uint64), k)
+    wid = rng.integers(0, W, size=F, dtype=np.uint64)
+    return edge_vid, wid
+
+
+def cfg2(V=1_000_000, k=10, n_weights=None, seed=1234, shard=0):
+    """Config 2: V boolean query variables x k unary ISTRUE factors, W fixed weights
+    ~ N(0, 0.5^2); closed form P(x=1) = sigmoid(2 * sum_j w_j)."""
+    W = n_weights or max(1, V // 10)
+    rng = _rng(seed, shard)
+    w = _rng(seed, 10_000).normal(0.0, 0.5, W)
+    edge_vid, wid = _unary_block(V, k, W, rng)
+    F = V * k
+    return RawGraph(
+        var_role=np.zeros(V, np.uint8), var_init_value=np.zeros(V, np.uint64),
+        var_dtype=np.full(V, DTYPE_BOOLEAN, np.uint16), var_cardinality=np.full(V, 2, np.uint64),
+        fac_func=np.full(F, FUNC_ISTRUE, np.uint16),
+        fac_edge_offset=np.arange(F + 1, dtype=np.uint64),
+        fac_weight_id=wid, fac_feature_value=np.ones(F),
+        edge_vid=edge_vid, edge_equal_to=np.ones(F, np.uint64),
+        w_initial_value=w, w_is_fixed=np.ones(W, np.uint8))
+
+
+def cfg2_closed_form(g: RawGraph):
+    """Exact marginals of a unary ISTRUE/AND graph: sigmoid(2 * sum w*f)."""
+    V = g.num_variables
+    contrib = g.w_initial_value[g.fac_weight_id.astype(np.int64)] * g.fac_feature_value
+    s = np.zeros(V)
+    np.add.at(s, g.edge_vid.astype(np.int64), contrib)
+    return 1.0 / (1.0 + np.exp(-2.0 * s))
+
+
+def cfg3(V=10_000_000, k=10, n_weights=None, seed=1234, shard=0):
+    """Config 3: as cfg2 but learnable weights (init 0), 50 % evidence variables with
+    value ~ Bernoulli(0.7)."""
+    W = n_weights or max(1, V // 10)
+    rng = _rng(seed, shard)
+    edge_vid, wid = _unary_block(V, k, W, rng)
+    is_evid = rng.random(V) < 0.5
+    val = (rng.random(V) < 0.7) & is_evid
+    F = V * k
+    return RawGraph(
+        var_role=is_evid.astype(np.uint8), var_init_value=val.astype(np.uint64),
+        var_dtype=np.full(V, DTYPE_BOOLEAN, np.uint16), var_cardinality=np.full(V, 2, np.uint64),
+        fac_func=np.full(F, FUNC_ISTRUE, np.uint16),
+        fac_edge_offset=np.arange(F + 1, dtype=np.uint64),
+        fac_weight_id=wid, fac_feature_value=np.ones(F),
+        edge_vid=edge_vid, edge_equal_to=np.ones(F, np.uint64),
+        w_initial_value=np.zeros(W), w_is_fixed=np.zeros(W, np.uint8))
+
+
+def cfg3b(V=10_000_000, n_weights=None, seed=1234, offsets=None):
+    """Config 3b: per variable 6 unary ISTRUE + 4 binary EQUAL(v, (v+o) mod V),
+    o in {1, 7, 101, V/8+3}: F = 10 V, E = 14 V.  Exercises the colouring."""
+    W = n_weights or max(1, V // 10)
+    rng = _rng(seed, 0)
+    offsets = offsets or [1, 7, 101, V // 8 + 3]
+    nu, nb = 6, len(offsets)
+    k = nu + nb
+    F = V * k
+    arity = np.tile(np.array([1] * nu + [2] * nb, np.uint64), V)
+    off = np.zeros(F + 1, np.uint64)
+    np.cumsum(arity, out=off[1:])
+    E = int(off[-1])
+    func = np.tile(np.array([FUNC_ISTRUE] * nu + [FUNC_EQUAL] * nb, np.uint16), V)
+    edge_vid = np.empty(E, np.uint64)
+    v = np.arange(V, dtype=np.uint64)
+    per = nu + 2 * nb
+    ev = edge_vid.reshape(V, per)
+    for j in range(nu):
+        ev[:, j] = v
+    for j, o in enumerate(offsets):
+        ev[:, nu + 2 * j] = v
+        ev[:, nu + 2 * j + 1] = (v + np.uint64(o)) % np.uint64(V)
+    is_evid = rng.random(V) < 0.5
+    val = (rng.random(V) < 0.7) & is_evid
+    return RawGraph(
+        var_role=is_evid.astype(np.uint8), var_init_value=val.astype(np.uint64),
+        var_dtype=np.full(V, DTYPE_BOOLEAN, np.uint16), var_cardinality=np.full(V, 2, np.uint64),
+        fac_func=func, fac_edge_offset=off,
+        fac_weight_id=rng.integers(0, W, size=F, dtype=np.uint64),
+        fac_feature_value=np.ones(F), edge_vid=edge_vid, edge_equal_to=np.ones(E, np.uint64),
+        w_initial_value=np.zeros(W), w_is_fixed=np.zeros(W, np.uint8))
+
+
+def cfg4(V=5_000_000, card=8, seed=1234, learn=False, shard=0):
+    """Config 4: V categorical variables of cardinality `card` (implicit dense domain),
+    one unary AND_CATEGORICAL factor per (v, d) with weight id d (the
+    biased_coin_with_multinomial shape).  Infer-only: weights fixed ~ N(0,1), all
+    query.  Learn: weights init 0, first half evidence ~ Categorical(softmax(w*))."""
+    rng = _rng(seed, shard)
+    wstar = _rng(seed, 10_000).normal(0.0, 1.0, card)
+    F = V * card
+    role = np.zeros(V, np.uint8)
+    init = np.zeros(V, np.uint64)
+    if learn:
+        p = np.exp(wstar - wstar.max()); p /= p.sum()
+        h = V // 2
+        role[:h] = 1
+        init[:h] = rng.choice(card, size=h, p=p).astype(np.uint64)
+        w0, fixed = np.zeros(card), np.zeros(card, np.uint8)
+    else:
+        w0, fixed = wstar, np.ones(card, np.uint8)
+    d = np.tile(np.arange(card, dtype=np.uint64), V)
+    return RawGraph(
+        var_role=role, var_init_value=init,
+        var_dtype=np.full(V, DTYPE_CATEGORICAL, np.uint16),
+        var_cardinality=np.full(V, card, np.uint64),
+        fac_func=np.full(F, FUNC_AND_CATEGORICAL, np.uint16),
+        fac_edge_offset=np.arange(F + 1, dtype=np.uint64),
+        fac_weight_id=d.copy(), fac_feature_value=np.ones(F),
+        edge_vid=np.repeat(np.arange(V, dtype=np.uint64), card), edge_equal_to=d,
+        w_initial_value=w0, w_is_fixed=fixed)
+
+
+def cfg4_closed_form(g: RawGraph, card):
+    w = g.w_initial_value[:card]
+    p = np.exp(w - w.max())
+    return p / p.sum()
