@@ -1,0 +1,193 @@
+/*
+ * dwx.h -- C ABI of the MI355X-native DimmWitted Gibbs sweep ("dwx").
+ *
+ * This is the drop-in boundary for the reference's ONE hot path: the seam between
+ * the epoch driver (DimmWitted::learn / inference, /root/reference/src/dimmwitted.cc:
+ * 121-207) and the per-replica sampler (class GibbsSampler,
+ * /root/reference/src/gibbs_sampler.h:18-57).  The reference has no FFI of its own;
+ * every entry point below names the internal C++ interface it replaces.  Plain
+ * pointers and sizes only -- no C++ or torch types cross this boundary.
+ *
+ * Conventions: every function returns 0 on success and a negative DWX_E_* code on
+ * error (dwx_last_error() gives the text; the reference assert()s/abort()s in the
+ * same situations).  Handles are opaque.  Host arrays passed in are copied during
+ * the call; the library owns all device memory until *_destroy.  One host thread
+ * drives one sampler handle; *_async calls enqueue on the handle's HIP stream and
+ * dwx_wait() is the barrier, exactly like GibbsSampler::sample()/wait().
+ *
+ * There is NO CPU fallback: dwx_sampler_create fails with DWX_E_DEVICE when no HIP
+ * device is usable.  dwx_graph_* functions are host-only (graph compilation) and
+ * work without a GPU.
+ */
+#ifndef DWX_H_
+#define DWX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DWX_VERSION 1
+
+enum {
+  DWX_OK = 0,
+  DWX_E_INVALID = -1,  /* malformed graph / argument (reference: assert/abort)   */
+  DWX_E_LIMIT = -2,    /* graph exceeds the compact 32-bit layout               */
+  DWX_E_DEVICE = -3,   /* HIP error or no device                                */
+  DWX_E_NOMEM = -4
+};
+
+/* Columnar image of the reference's binary input files
+ * (/root/reference/doc/binary_format.md; loaders src/binary_format.cc:48-226).
+ * Ids must be dense (0..N-1), as FactorGraph::safety_check demands
+ * (src/factor_graph.cc:201-219). */
+typedef struct dwx_graph_desc {
+  uint64_t num_variables, num_factors, num_edges, num_weights;
+  const uint8_t *var_role;         /* isEvidence byte; evidence iff >= 1          */
+  const uint64_t *var_init_value;  /* initialValue as in the file                 */
+  const uint16_t *var_dtype;       /* 0 boolean, 1 categorical                    */
+  const uint64_t *var_cardinality;
+  uint64_t num_domains;            /* categorical domain blocks (may be 0)        */
+  const uint64_t *dom_vid;         /* [num_domains]                               */
+  const uint64_t *dom_offset;      /* [num_domains+1] into dom_value/truthiness   */
+  const uint64_t *dom_value;
+  const double *dom_truthiness;
+  const uint16_t *fac_func;        /* FACTOR_FUNCTION_TYPE (src/common.h:35-48)   */
+  const uint64_t *fac_edge_offset; /* [num_factors+1]                             */
+  const uint64_t *fac_weight_id;
+  const double *fac_feature_value;
+  const uint64_t *edge_vid;
+  const uint64_t *edge_equal_to;   /* equalPredicate as in the file               */
+  const double *w_initial_value;   /* indexed by weight id                        */
+  const uint8_t *w_is_fixed;
+} dwx_graph_desc;
+
+/* Graph-compilation knobs; zero-initialise for defaults. */
+typedef struct dwx_compile_opts {
+  uint32_t tile_vars;          /* variables per workgroup tile (default 256, max 256)  */
+  uint32_t tile_edges;         /* edge records staged in LDS per tile (default 3072)   */
+  uint32_t tile_rows;          /* value rows per tile (default 256 bool / 2048 categ.) */
+  uint32_t conflict_arity_cap; /* factors wider than this do not constrain the
+                                  colouring (Hogwild reads, as in the reference);
+                                  default 256                                          */
+  uint32_t n_threads;          /* host threads for the build (0 = all cores)           */
+  uint32_t reserved;
+} dwx_compile_opts;
+
+typedef struct dwx_graph_info {
+  uint64_t num_variables, num_factors, num_edges, num_weights;
+  uint64_t num_values;         /* value rows: 1 per boolean, cardinality per categorical
+                                  (== FactorGraph size.num_values)                     */
+  uint64_t num_index_entries;  /* |factor_index| after dedup (src/factor_graph.cc:177) */
+  uint64_t num_vif_entries;    /* factor->variable entries kept for arity >= 2         */
+  uint64_t num_colors, num_launches, num_tiles, num_giant_tiles;
+  uint64_t max_cardinality;
+  uint64_t device_bytes;       /* bytes the sampler will hold in HBM                   */
+  uint32_t has_categorical, order_is_identity;
+} dwx_graph_info;
+
+/* Runtime options of one sampler (the CmdParser fields the hot path reads:
+ * src/gibbs_sampler.cc:46-48, src/inference_result.h:66-85). */
+typedef struct dwx_options {
+  int32_t device;              /* HIP device ordinal                                   */
+  int32_t sample_evidence;     /* --sample_evidence                                    */
+  int32_t learn_non_evidence;  /* --learn_non_evidence                                 */
+  int32_t noise_aware;         /* --noise_aware                                        */
+  int32_t regularization;      /* 0 = l1, 1 = l2 (reference enum order)                */
+  int32_t reserved;
+  double reg_param;            /* -b / --reg_param                                     */
+  double step_cap;             /* cap on stepsize x (updates of one weight per sweep);
+                                  <= 0 disables; default via dwx_default_options: 1.0  */
+  uint64_t seed;               /* Philox key                                           */
+} dwx_options;
+
+typedef struct dwx_graph dwx_graph;
+typedef struct dwx_sampler dwx_sampler;
+
+const char *dwx_last_error(void);
+int dwx_version(void);
+void dwx_default_options(dwx_options *o);
+
+/* ---- graph compilation (host only) --------------------------------------------
+ * Replaces FactorGraph::load_* conversions + construct_index
+ * (src/binary_format.cc:128-226, src/factor_graph.cc:90-199) and adds what the
+ * device needs: chromatic partition, colour-major variable order, LDS tiles. */
+int dwx_graph_create(const dwx_graph_desc *desc, const dwx_compile_opts *opts, dwx_graph **out);
+void dwx_graph_destroy(dwx_graph *g);
+int dwx_graph_get_info(const dwx_graph *g, dwx_graph_info *out);
+/* Execution schedule: order[V] = original variable ids in device order;
+ * launch_off[num_launches+1] = offsets into order; every launch is an independent
+ * set of the variable conflict graph. */
+int dwx_graph_get_schedule(const dwx_graph *g, uint64_t *order, uint64_t *launch_off);
+/* Value table for result dumps (src/inference_result.cc:211-243):
+ * var_val_base[V] (reference numbering) and value_sparse[num_values]. */
+int dwx_graph_get_values(const dwx_graph *g, uint64_t *var_val_base, uint64_t *value_sparse);
+/* Reference-order CSR, for parity checks against construct_index:
+ * index_base/index_len[num_values], factor_index[num_index_entries]. */
+int dwx_graph_get_index(const dwx_graph *g, uint64_t *index_base, uint64_t *index_len,
+                        uint64_t *factor_index);
+
+/* ---- sampler (device) -----------------------------------------------------------
+ * Replaces GibbsSampler(pfg, weights, numa_nodes, nthread, nodeid, opts)
+ * (src/gibbs_sampler.cc:5-18) incl. the InferenceResult it owns
+ * (src/inference_result.cc:24-42). */
+int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler **out);
+void dwx_sampler_destroy(dwx_sampler *s);
+
+/* GibbsSampler::sample(i_epoch) (src/gibbs_sampler.cc:20-25): one inference sweep. */
+int dwx_sample_async(dwx_sampler *s);
+/* GibbsSampler::sample_sgd(stepsize) (src/gibbs_sampler.cc:27-33): one learning
+ * sweep = dwx_sgd_accumulate_async + dwx_sgd_apply_async. */
+int dwx_sample_sgd_async(dwx_sampler *s, double stepsize);
+/* GibbsSampler::wait() (src/gibbs_sampler.cc:35-38). */
+int dwx_wait(dwx_sampler *s);
+
+/* The two halves of a learning sweep, split so that a multi-GPU driver can
+ * all-reduce the gradient buffer in between (replaces the dormant
+ * InferenceResult::merge_gradients_from, src/inference_result.cc:57-62). */
+int dwx_sgd_accumulate_async(dwx_sampler *s);
+int dwx_sgd_apply_async(dwx_sampler *s, double stepsize);
+
+/* infrs.weight_values access (src/dimmwitted.cc:209-216 merge/average, :245-258 dump) */
+int dwx_get_weights(dwx_sampler *s, double *out);
+int dwx_set_weights(dwx_sampler *s, const double *in);
+/* InferenceResult::clear_variabletally / sample_tallies + agg_nsamples
+ * (src/inference_result.cc:107-127); arrays are in the REFERENCE numbering. */
+int dwx_clear_tallies(dwx_sampler *s);
+int dwx_get_tallies(dwx_sampler *s, uint64_t *tallies, uint64_t *nsamples);
+/* assignments_free (chain 0) / assignments_evid (chain 1), original variable order */
+int dwx_get_assignments(dwx_sampler *s, int chain, uint64_t *out);
+int dwx_set_assignments(dwx_sampler *s, int chain, const uint64_t *in);
+/* sweep counter (the Philox counter word); starts at 0, +1 per sweep */
+int dwx_get_sweep(dwx_sampler *s, uint64_t *out);
+int dwx_set_sweep(dwx_sampler *s, uint64_t sweep);
+
+/* Raw device buffers, so the caller's collective library (RCCL via
+ * torch.distributed or rccl.h) can reduce / exchange in place. */
+enum {
+  DWX_BUF_WEIGHTS = 0,      /* double[W]                                            */
+  DWX_BUF_GRAD = 1,         /* int64[2W]: fixed-point (2^-30) gradient sums G[W],
+                               then update counts T[W]                             */
+  DWX_BUF_ASSIGN_FREE = 2,  /* uint32[V] in device order                           */
+  DWX_BUF_ASSIGN_EVID = 3,  /* uint32[V] in device order                           */
+  DWX_BUF_TALLIES = 4       /* uint32[num_values] in device order                  */
+};
+int dwx_device_buffer(dwx_sampler *s, int which, void **dev_ptr, uint64_t *nbytes);
+/* The HIP stream (hipStream_t) the sampler enqueues on. */
+int dwx_stream(dwx_sampler *s, void **stream);
+
+/* Device time of the sweep kernels only, measured with HIP events on the sampler's
+ * stream around every launch since the last reset: total milliseconds, number of
+ * kernel launches and number of sweeps.  kind: 0 = inference, 1 = learning. */
+int dwx_kernel_time(dwx_sampler *s, int kind, double *ms, uint64_t *launches, uint64_t *sweeps);
+int dwx_kernel_time_reset(dwx_sampler *s, int enable);
+
+/* Test hook: evaluate one factor function on the device.  sat[i] = whether the
+ * predicate of position i holds; mirrors test/factor_test.cc's truth tables. */
+int dwx_test_factor_sign(int device, int func, uint64_t arity, const uint8_t *sat, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DWX_H_ */

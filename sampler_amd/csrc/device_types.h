@@ -1,0 +1,93 @@
+// device_types.h -- records and launch parameters shared by the host graph compiler
+// and the HIP kernels.  Plain C++ (no HIP types) so the host-only parts compile
+// with g++.
+#ifndef DWX_DEVICE_TYPES_H_
+#define DWX_DEVICE_TYPES_H_
+
+#include <stdint.h>
+
+namespace dwx {
+
+// FACTOR_FUNCTION_TYPE, /root/reference/src/common.h:35-48
+enum : uint32_t {
+  FUNC_IMPLY_NATURAL = 0, FUNC_OR = 1, FUNC_AND = 2, FUNC_EQUAL = 3, FUNC_ISTRUE = 4,
+  FUNC_LINEAR = 7, FUNC_RATIO = 8, FUNC_LOGICAL = 9, FUNC_AND_CATEGORICAL = 12,
+  FUNC_IMPLY_MLN = 13,
+};
+
+// One entry of a variable's (value) row: replaces factor_index[] + Factor (48 B) +
+// the weight_id indirection of the reference (src/factor_graph.h:127-145) by ONE
+// 16-byte record stored variable-major, so a workgroup tile's records are a single
+// contiguous, 16-B-aligned HBM range.
+struct alignas(16) EdgeRec {
+  uint32_t wid;     // weight id
+  uint32_t aux;     // arity == 1: dense equal_to of the (only) predicate;
+                    // arity >= 2: base index into vifs[]
+  uint32_t packed;  // bits 0-3 func id, bit 4: feature value needs the f64 side
+                    // array, bits 8-31 arity
+  float fval;       // feature value (exact when bit 4 is clear)
+};
+static_assert(sizeof(EdgeRec) == 16, "EdgeRec must be 16 bytes");
+
+constexpr uint32_t EDGE_FUNC_MASK = 0xF;
+constexpr uint32_t EDGE_F64_FLAG = 1u << 4;
+constexpr uint32_t EDGE_ARITY_SHIFT = 8;
+constexpr uint32_t MAX_ARITY = (1u << 24) - 1;
+
+// factor -> variable entry (src/variable.h:154-167), 8 bytes, device variable ids
+struct alignas(8) VifRec {
+  uint32_t vid;       // DEVICE position of the variable
+  uint32_t equal_to;  // dense predicate value
+};
+
+// v_meta bits
+constexpr uint32_t VM_CATEGORICAL = 1u << 0;
+constexpr uint32_t VM_EVIDENCE = 1u << 1;
+constexpr uint32_t VM_TRUTHINESS = 1u << 2;  // total_truthiness not ~0
+constexpr uint32_t VM_CARD_SHIFT = 8;
+constexpr uint32_t MAX_CARD = (1u << 24) - 1;
+
+// option flag bits (KernelParams::flags)
+constexpr uint32_t OPT_SAMPLE_EVIDENCE = 1u << 0;
+constexpr uint32_t OPT_LEARN_NON_EVIDENCE = 1u << 1;
+constexpr uint32_t OPT_NOISE_AWARE = 1u << 2;
+constexpr uint32_t OPT_HAS_F64_FVAL = 1u << 3;
+constexpr uint32_t OPT_HAS_TRUTHINESS = 1u << 4;
+
+constexpr double FIX_SCALE = 1073741824.0;  // 2^30: gradient fixed-point scale
+constexpr double LINEAR_ZERO_THRESHOLD = 0.000001;  // src/common.h:15
+
+constexpr uint32_t BLOCK_THREADS = 256;
+
+// Everything one sweep launch needs; passed by value.
+struct KernelParams {
+  // graph (read only)
+  const uint32_t *v_meta;     // [V]
+  const uint32_t *v_orig;     // [V] original variable id (Philox counter)
+  const uint32_t *v_row;      // [V+1] first value row of each variable
+  const uint32_t *v_init;     // [V] dense evidence value (assignment_dense)
+  const uint32_t *row_ptr;    // [R+1] edge-record offsets
+  const double *row_truth;    // [R] truthiness per value row, or null
+  const EdgeRec *edges;       // [NIdx]
+  const double *edge_fval64;  // [NIdx] or null
+  const VifRec *vifs;         // [NVif]
+  const uint32_t *tile_v;     // [n_tiles+1] variable positions
+  // state
+  uint32_t *assign_free;      // [V]
+  uint32_t *assign_evid;      // [V]
+  uint32_t *tally;            // [R]
+  const double *weights;      // [W]
+  const uint8_t *w_fixed;     // [W]
+  long long *grad;            // [2W]: G then T (fixed point)
+  // launch
+  uint64_t seed, sweep;
+  uint32_t tile_begin;        // first tile of this launch
+  uint32_t num_weights;
+  uint32_t flags;
+  uint32_t ecap, rcap;        // LDS capacities (edge records / value rows per tile)
+  uint32_t lds_pot_off;       // byte offset of the potentials scratch in dynamic LDS
+  uint32_t lds_edge_off;      // byte offset of the staged edge records
+};
+
+}  // namespace dwx
+#endif

@@ -1,0 +1,478 @@
+// dwx_api.cc -- implementation of the C ABI in include/dwx.h.
+//
+// Compiled as HIP for gfx950 into libdwx.so (Makefile).  The runtime layer is
+// rt_hip.h; when DWX_EMU is defined (tests/hipemu only) the same file is compiled by
+// g++ against a host emulation of that layer so the kernels run under sanitizers.
+#include "../../include/dwx.h"
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "graph_compile.h"
+
+#ifdef DWX_EMU
+#include "rt_emu.h"
+#else
+#include "rt_hip.h"
+#endif
+
+#include "sweep_kernels.h"
+
+using namespace dwx;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+template <class Fn>
+int guarded(Fn &&fn) {
+  try {
+    fn();
+    return DWX_OK;
+  } catch (const std::bad_alloc &) {
+    return fail(DWX_E_NOMEM, "out of host memory");
+  } catch (const std::invalid_argument &e) {
+    return fail(DWX_E_INVALID, e.what());
+  } catch (const std::exception &e) {
+    return fail(DWX_E_DEVICE, e.what());
+  }
+}
+
+template <class T>
+T *upload(const std::vector<T> &v, rt::stream_t s) {
+  T *d = (T *)rt::dmalloc(v.size() * sizeof(T));
+  rt::h2d(d, v.data(), v.size() * sizeof(T), s);
+  return d;
+}
+
+struct TimedSpan {
+  rt::event_t a, b;
+  int kind;
+  uint32_t launches;
+};
+}  // namespace
+
+struct dwx_graph {
+  std::shared_ptr<CompiledGraph> cg;
+};
+
+struct dwx_sampler {
+  std::shared_ptr<CompiledGraph> cg;
+  dwx_options opts;
+  int device = 0;
+  rt::stream_t stream = nullptr;
+  // device buffers
+  uint32_t *d_v_meta = nullptr, *d_v_orig = nullptr, *d_v_row = nullptr, *d_v_init = nullptr;
+  uint32_t *d_row_ptr = nullptr, *d_tile_v = nullptr;
+  double *d_row_truth = nullptr, *d_edge_fval64 = nullptr;
+  EdgeRec *d_edges = nullptr;
+  VifRec *d_vifs = nullptr;
+  uint32_t *d_assign_free = nullptr, *d_assign_evid = nullptr, *d_tally = nullptr;
+  double *d_weights = nullptr;
+  uint8_t *d_w_fixed = nullptr;
+  long long *d_grad = nullptr;
+  KernelParams base{};
+  size_t lds_bytes = 0;
+  uint64_t sweep = 0;
+  uint64_t infer_sweeps = 0;  // inference sweeps since the last clear_tallies
+  // kernel timing
+  bool timing = false;
+  std::vector<TimedSpan> spans;
+  double t_ms[2] = {0, 0};
+  uint64_t t_launches[2] = {0, 0}, t_sweeps[2] = {0, 0};
+
+  ~dwx_sampler() {
+    for (auto &sp : spans) { rt::event_destroy(sp.a); rt::event_destroy(sp.b); }
+    rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
+    rt::dfree(d_row_ptr); rt::dfree(d_tile_v); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
+    rt::dfree(d_edges); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
+    rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w_fixed); rt::dfree(d_grad);
+    if (stream) rt::stream_destroy(stream);
+  }
+};
+
+namespace {
+template <bool LEARN>
+void enqueue_sweep(dwx_sampler *s) {
+  const CompiledGraph &c = *s->cg;
+  rt::set_device(s->device);
+  KernelParams P = s->base;
+  P.sweep = s->sweep;
+  TimedSpan sp{};
+  if (s->timing) {
+    sp.a = rt::event_create(); sp.b = rt::event_create(); sp.kind = LEARN ? 1 : 0;
+    rt::event_record(sp.a, s->stream);
+  }
+  const size_t nl = c.launch_off.size() - 1;
+  uint32_t launches = 0;
+  for (size_t l = 0; l < nl; ++l) {
+    const uint32_t t0 = c.launch_tile[l], t1 = c.launch_tile[l + 1];
+    if (t1 == t0) continue;
+    P.tile_begin = t0;
+    rt::launch(sweep_kernel<LEARN>, t1 - t0, BLOCK_THREADS, s->lds_bytes, s->stream, P);
+    ++launches;
+  }
+  if (s->timing) {
+    rt::event_record(sp.b, s->stream);
+    sp.launches = launches;
+    s->spans.push_back(sp);
+  }
+  ++s->sweep;
+}
+
+void drain_spans(dwx_sampler *s) {
+  if (s->spans.empty()) return;
+  rt::stream_sync(s->stream);
+  for (auto &sp : s->spans) {
+    s->t_ms[sp.kind] += rt::event_elapsed_ms(sp.a, sp.b);
+    s->t_launches[sp.kind] += sp.launches;
+    s->t_sweeps[sp.kind] += 1;
+    rt::event_destroy(sp.a); rt::event_destroy(sp.b);
+  }
+  s->spans.clear();
+}
+}  // namespace
+
+extern "C" {
+
+const char *dwx_last_error(void) { return g_err.c_str(); }
+int dwx_version(void) { return DWX_VERSION; }
+
+void dwx_default_options(dwx_options *o) {
+  std::memset(o, 0, sizeof *o);
+  o->regularization = 1;  // l2 (src/cmd_parser.cc:163-166)
+  o->reg_param = 0.01;    // src/cmd_parser.cc:162
+  o->step_cap = 1.0;
+  o->seed = 0x5eed5eedULL;
+}
+
+// ------------------------------------------------------------------ graph
+int dwx_graph_create(const dwx_graph_desc *desc, const dwx_compile_opts *opts, dwx_graph **out) {
+  if (!desc || !out) return fail(DWX_E_INVALID, "null argument");
+  dwx_compile_opts o{};
+  if (opts) o = *opts;
+  bool limit = false;
+  try {
+    auto cg = std::make_shared<CompiledGraph>();
+    compile_graph(*desc, o, *cg, &limit);
+    *out = new dwx_graph{cg};
+    return DWX_OK;
+  } catch (const std::bad_alloc &) {
+    return fail(DWX_E_NOMEM, "out of host memory while compiling the graph");
+  } catch (const std::exception &e) {
+    return fail(limit ? DWX_E_LIMIT : DWX_E_INVALID, e.what());
+  }
+}
+
+void dwx_graph_destroy(dwx_graph *g) { delete g; }
+
+int dwx_graph_get_info(const dwx_graph *g, dwx_graph_info *out) {
+  if (!g || !out) return fail(DWX_E_INVALID, "null argument");
+  const CompiledGraph &c = *g->cg;
+  std::memset(out, 0, sizeof *out);
+  out->num_variables = c.V; out->num_factors = c.F; out->num_edges = c.E; out->num_weights = c.W;
+  out->num_values = c.R; out->num_index_entries = c.NIdx; out->num_vif_entries = c.NVif;
+  out->num_colors = c.n_colors; out->num_launches = c.launch_off.size() - 1;
+  out->num_tiles = c.tile_v.size() - 1; out->num_giant_tiles = c.n_giant_tiles;
+  out->max_cardinality = c.max_card; out->device_bytes = c.device_bytes();
+  out->has_categorical = c.has_categorical; out->order_is_identity = c.order_is_identity;
+  return DWX_OK;
+}
+
+int dwx_graph_get_schedule(const dwx_graph *g, uint64_t *order, uint64_t *launch_off) {
+  if (!g || !order || !launch_off) return fail(DWX_E_INVALID, "null argument");
+  const CompiledGraph &c = *g->cg;
+  for (uint64_t p = 0; p < c.V; ++p) order[p] = c.perm[p];
+  std::copy(c.launch_off.begin(), c.launch_off.end(), launch_off);
+  return DWX_OK;
+}
+
+int dwx_graph_get_values(const dwx_graph *g, uint64_t *var_val_base, uint64_t *value_sparse) {
+  if (!g) return fail(DWX_E_INVALID, "null argument");
+  const CompiledGraph &c = *g->cg;
+  if (var_val_base) std::copy(c.ref_var_val_base.begin(), c.ref_var_val_base.end(), var_val_base);
+  if (value_sparse) std::copy(c.value_sparse.begin(), c.value_sparse.end(), value_sparse);
+  return DWX_OK;
+}
+
+int dwx_graph_get_index(const dwx_graph *g, uint64_t *index_base, uint64_t *index_len,
+                        uint64_t *factor_index) {
+  if (!g) return fail(DWX_E_INVALID, "null argument");
+  const CompiledGraph &c = *g->cg;
+  for (uint64_t r = 0; r < c.R; ++r) {
+    if (index_base) index_base[r] = c.ref_row_ptr[r];
+    if (index_len) index_len[r] = c.ref_row_ptr[r + 1] - c.ref_row_ptr[r];
+  }
+  if (factor_index) for (uint64_t i = 0; i < c.NIdx; ++i) factor_index[i] = c.ref_fidx[i];
+  return DWX_OK;
+}
+
+// ------------------------------------------------------------------ sampler
+int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler **out) {
+  if (!g || !opts || !out) return fail(DWX_E_INVALID, "null argument");
+  std::unique_ptr<dwx_sampler> s(new dwx_sampler());
+  int rc = guarded([&]() {
+    rt::init_device(opts->device);
+    s->cg = g->cg;
+    s->opts = *opts;
+    s->device = opts->device;
+    const CompiledGraph &c = *s->cg;
+    s->stream = rt::stream_create();
+    rt::stream_t st = s->stream;
+    s->d_v_meta = upload(c.v_meta, st);
+    s->d_v_orig = upload(c.perm, st);
+    s->d_v_row = upload(c.v_row, st);
+    s->d_v_init = upload(c.v_init, st);
+    s->d_row_ptr = upload(c.row_ptr, st);
+    s->d_tile_v = upload(c.tile_v, st);
+    if (!c.row_truth.empty()) s->d_row_truth = upload(c.row_truth, st);
+    if (!c.edge_fval64.empty()) s->d_edge_fval64 = upload(c.edge_fval64, st);
+    s->d_edges = upload(c.edges, st);
+    s->d_vifs = upload(c.vifs, st);
+    // InferenceResult init (src/inference_result.cc:24-42): both chains start at the
+    // evidence value or 0, tallies zero, weights at their initial values
+    std::vector<uint32_t> a0(c.V);
+    for (uint64_t p = 0; p < c.V; ++p) a0[p] = (c.v_meta[p] & VM_EVIDENCE) ? c.v_init[p] : 0u;
+    s->d_assign_free = upload(a0, st);
+    s->d_assign_evid = upload(a0, st);
+    s->d_tally = (uint32_t *)rt::dmalloc(c.R * 4);
+    rt::dmemset(s->d_tally, 0, c.R * 4, st);
+    s->d_weights = upload(c.w_init, st);
+    s->d_w_fixed = upload(c.w_fixed, st);
+    s->d_grad = (long long *)rt::dmalloc(c.W * 16);
+    rt::dmemset(s->d_grad, 0, c.W * 16, st);
+
+    KernelParams &P = s->base;
+    P.v_meta = s->d_v_meta; P.v_orig = s->d_v_orig; P.v_row = s->d_v_row; P.v_init = s->d_v_init;
+    P.row_ptr = s->d_row_ptr; P.row_truth = s->d_row_truth; P.edges = s->d_edges;
+    P.edge_fval64 = s->d_edge_fval64; P.vifs = s->d_vifs; P.tile_v = s->d_tile_v;
+    P.assign_free = s->d_assign_free; P.assign_evid = s->d_assign_evid; P.tally = s->d_tally;
+    P.weights = s->d_weights; P.w_fixed = s->d_w_fixed; P.grad = s->d_grad;
+    P.seed = opts->seed; P.sweep = 0; P.tile_begin = 0; P.num_weights = (uint32_t)c.W;
+    P.flags = (opts->sample_evidence ? OPT_SAMPLE_EVIDENCE : 0) |
+              (opts->learn_non_evidence ? OPT_LEARN_NON_EVIDENCE : 0) |
+              (opts->noise_aware ? OPT_NOISE_AWARE : 0) |
+              (c.has_f64_fval ? OPT_HAS_F64_FVAL : 0) | (c.has_truthiness ? OPT_HAS_TRUTHINESS : 0);
+    P.ecap = c.ecap; P.rcap = c.rcap;
+    // dynamic LDS layout: [row pointers | potentials scratch (categorical) | edge records]
+    size_t off = ((size_t)(c.rcap + 1) * 4 + 15) & ~(size_t)15;
+    P.lds_pot_off = c.has_categorical ? (uint32_t)off : 0u;
+    if (c.has_categorical) off += (size_t)c.rcap * 8;
+    off = (off + 15) & ~(size_t)15;
+    P.lds_edge_off = (uint32_t)off;
+    s->lds_bytes = off + (size_t)c.ecap * sizeof(EdgeRec);
+    if (s->lds_bytes > 160 * 1024) throw std::invalid_argument("tile does not fit the 160 KiB LDS");
+    rt::allow_dynamic_lds(sweep_kernel<false>, s->lds_bytes);
+    rt::allow_dynamic_lds(sweep_kernel<true>, s->lds_bytes);
+    rt::stream_sync(st);
+  });
+  if (rc != DWX_OK) return rc;
+  *out = s.release();
+  return DWX_OK;
+}
+
+void dwx_sampler_destroy(dwx_sampler *s) {
+  if (!s) return;
+  try {
+    rt::set_device(s->device);
+    rt::stream_sync(s->stream);
+  } catch (...) {
+  }
+  delete s;
+}
+
+
+int dwx_sample_async(dwx_sampler *s) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  return guarded([&]() {
+    enqueue_sweep<false>(s);
+    ++s->infer_sweeps;
+  });
+}
+
+int dwx_sgd_accumulate_async(dwx_sampler *s) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  return guarded([&]() { enqueue_sweep<true>(s); });
+}
+
+int dwx_sgd_apply_async(dwx_sampler *s, double stepsize) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  return guarded([&]() {
+    rt::set_device(s->device);
+    const uint32_t W = (uint32_t)s->cg->W;
+    if (!W) return;
+    const unsigned grid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 2048u);
+    rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights,
+               (const uint8_t *)s->d_w_fixed, s->d_grad, W, stepsize, s->opts.step_cap,
+               s->opts.reg_param, (int)(s->opts.regularization == 1));
+  });
+}
+
+int dwx_sample_sgd_async(dwx_sampler *s, double stepsize) {
+  int rc = dwx_sgd_accumulate_async(s);
+  if (rc != DWX_OK) return rc;
+  return dwx_sgd_apply_async(s, stepsize);
+}
+
+int dwx_wait(dwx_sampler *s) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  return guarded([&]() {
+    rt::set_device(s->device);
+    rt::stream_sync(s->stream);
+  });
+}
+
+int dwx_get_weights(dwx_sampler *s, double *out) {
+  if (!s || !out) return fail(DWX_E_INVALID, "null argument");
+  return guarded([&]() {
+    rt::set_device(s->device);
+    rt::d2h(out, s->d_weights, s->cg->W * 8, s->stream);
+    rt::stream_sync(s->stream);
+  });
+}
+
+int dwx_set_weights(dwx_sampler *s, const double *in) {
+  if (!s || !in) return fail(DWX_E_INVALID, "null argument");
+  return guarded([&]() {
+    rt::set_device(s->device);
+    rt::h2d(s->d_weights, in, s->cg->W * 8, s->stream);
+    rt::stream_sync(s->stream);
+  });
+}
+
+int dwx_clear_tallies(dwx_sampler *s) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  return guarded([&]() {
+    rt::set_device(s->device);
+    rt::dmemset(s->d_tally, 0, s->cg->R * 4, s->stream);
+    s->infer_sweeps = 0;
+  });
+}
+
+int dwx_get_tallies(dwx_sampler *s, uint64_t *tallies, uint64_t *nsamples) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  return guarded([&]() {
+    const CompiledGraph &c = *s->cg;
+    rt::set_device(s->device);
+    if (tallies) {
+      std::vector<uint32_t> t(c.R);
+      rt::d2h(t.data(), s->d_tally, c.R * 4, s->stream);
+      rt::stream_sync(s->stream);
+      for (uint64_t p = 0; p < c.V; ++p) {
+        const uint64_t rb = c.ref_var_val_base[c.perm[p]];
+        for (uint32_t r = c.v_row[p]; r < c.v_row[p + 1]; ++r) tallies[rb + (r - c.v_row[p])] = t[r];
+      }
+    }
+    if (nsamples)  // agg_nsamples: +1 per inference sweep for every sampled variable
+      for (uint64_t v = 0; v < c.V; ++v)
+        nsamples[v] = (!c.var_is_evid[v] || s->opts.sample_evidence) ? s->infer_sweeps : 0;
+  });
+}
+
+int dwx_get_assignments(dwx_sampler *s, int chain, uint64_t *out) {
+  if (!s || !out) return fail(DWX_E_INVALID, "null argument");
+  return guarded([&]() {
+    const CompiledGraph &c = *s->cg;
+    rt::set_device(s->device);
+    std::vector<uint32_t> a(c.V);
+    rt::d2h(a.data(), chain == 0 ? s->d_assign_free : s->d_assign_evid, c.V * 4, s->stream);
+    rt::stream_sync(s->stream);
+    for (uint64_t p = 0; p < c.V; ++p) out[c.perm[p]] = a[p];
+  });
+}
+
+int dwx_set_assignments(dwx_sampler *s, int chain, const uint64_t *in) {
+  if (!s || !in) return fail(DWX_E_INVALID, "null argument");
+  return guarded([&]() {
+    const CompiledGraph &c = *s->cg;
+    rt::set_device(s->device);
+    std::vector<uint32_t> a(c.V);
+    for (uint64_t p = 0; p < c.V; ++p) a[p] = (uint32_t)in[c.perm[p]];
+    rt::h2d(chain == 0 ? s->d_assign_free : s->d_assign_evid, a.data(), c.V * 4, s->stream);
+    rt::stream_sync(s->stream);
+  });
+}
+
+int dwx_get_sweep(dwx_sampler *s, uint64_t *out) {
+  if (!s || !out) return fail(DWX_E_INVALID, "null argument");
+  *out = s->sweep;
+  return DWX_OK;
+}
+
+int dwx_set_sweep(dwx_sampler *s, uint64_t sweep) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  s->sweep = sweep;
+  return DWX_OK;
+}
+
+int dwx_device_buffer(dwx_sampler *s, int which, void **dev_ptr, uint64_t *nbytes) {
+  if (!s || !dev_ptr || !nbytes) return fail(DWX_E_INVALID, "null argument");
+  const CompiledGraph &c = *s->cg;
+  switch (which) {
+    case DWX_BUF_WEIGHTS: *dev_ptr = s->d_weights; *nbytes = c.W * 8; break;
+    case DWX_BUF_GRAD: *dev_ptr = s->d_grad; *nbytes = c.W * 16; break;
+    case DWX_BUF_ASSIGN_FREE: *dev_ptr = s->d_assign_free; *nbytes = c.V * 4; break;
+    case DWX_BUF_ASSIGN_EVID: *dev_ptr = s->d_assign_evid; *nbytes = c.V * 4; break;
+    case DWX_BUF_TALLIES: *dev_ptr = s->d_tally; *nbytes = c.R * 4; break;
+    default: return fail(DWX_E_INVALID, "unknown buffer id");
+  }
+  return DWX_OK;
+}
+
+int dwx_stream(dwx_sampler *s, void **stream) {
+  if (!s || !stream) return fail(DWX_E_INVALID, "null argument");
+  *stream = (void *)s->stream;
+  return DWX_OK;
+}
+
+int dwx_kernel_time_reset(dwx_sampler *s, int enable) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  return guarded([&]() {
+    rt::set_device(s->device);
+    drain_spans(s);
+    for (int k = 0; k < 2; ++k) { s->t_ms[k] = 0; s->t_launches[k] = 0; s->t_sweeps[k] = 0; }
+    s->timing = enable != 0;
+  });
+}
+
+int dwx_kernel_time(dwx_sampler *s, int kind, double *ms, uint64_t *launches, uint64_t *sweeps) {
+  if (!s || kind < 0 || kind > 1) return fail(DWX_E_INVALID, "bad argument");
+  return guarded([&]() {
+    rt::set_device(s->device);
+    drain_spans(s);
+    if (ms) *ms = s->t_ms[kind];
+    if (launches) *launches = s->t_launches[kind];
+    if (sweeps) *sweeps = s->t_sweeps[kind];
+  });
+}
+
+int dwx_test_factor_sign(int device, int func, uint64_t arity, const uint8_t *sat, double *out) {
+  if (!sat || !out || arity == 0 || arity > 4096) return fail(DWX_E_INVALID, "bad argument");
+  return guarded([&]() {
+    rt::init_device(device);
+    rt::stream_t st = rt::stream_create();
+    std::vector<VifRec> vifs(arity);
+    std::vector<uint32_t> assign(arity);
+    for (uint64_t i = 0; i < arity; ++i) { vifs[i] = VifRec{(uint32_t)i, 1u}; assign[i] = sat[i]; }
+    VifRec *dv = upload(vifs, st);
+    uint32_t *da = upload(assign, st);
+    double *dout = (double *)rt::dmalloc(8);
+    rt::launch(test_sign_kernel, 1, 64, 0, st, (uint32_t)func, (uint32_t)arity,
+               (const VifRec *)dv, (const uint32_t *)da, dout);
+    rt::d2h(out, dout, 8, st);
+    rt::stream_sync(st);
+    rt::dfree(dv); rt::dfree(da); rt::dfree(dout);
+    rt::stream_destroy(st);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,431 @@
+// graph_compile.cc -- see graph_compile.h.  Host-only C++17, no HIP.
+#include "graph_compile.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <numeric>
+#include <stdexcept>
+#include <thread>
+
+namespace dwx {
+namespace {
+
+struct LimitError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+constexpr uint32_t kUnset = 0xFFFFFFFFu;
+constexpr uint64_t kInvalid64 = ~0ull;
+
+inline bool is_linear_zero(double x) {  // src/common.h:114-116
+  return x <= LINEAR_ZERO_THRESHOLD && x >= -LINEAR_ZERO_THRESHOLD;
+}
+
+inline bool known_func(uint32_t f) {
+  switch (f) {
+    case FUNC_IMPLY_NATURAL: case FUNC_OR: case FUNC_AND: case FUNC_EQUAL: case FUNC_ISTRUE:
+    case FUNC_LINEAR: case FUNC_RATIO: case FUNC_LOGICAL: case FUNC_AND_CATEGORICAL:
+    case FUNC_IMPLY_MLN:
+      return true;
+  }
+  return false;
+}
+
+// run fn(begin, end) over [0, n) split across threads
+void parallel_ranges(uint64_t n, uint32_t n_threads, const std::function<void(uint64_t, uint64_t)> &fn) {
+  if (n_threads <= 1 || n < 65536) {
+    fn(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  std::atomic<bool> failed{false};
+  std::exception_ptr eptr = nullptr;
+  std::atomic_flag lock = ATOMIC_FLAG_INIT;
+  uint64_t per = (n + n_threads - 1) / n_threads;
+  for (uint32_t t = 0; t < n_threads; ++t) {
+    uint64_t b = std::min<uint64_t>(n, per * t), e = std::min<uint64_t>(n, per * (t + 1));
+    if (b >= e) break;
+    th.emplace_back([&, b, e]() {
+      try {
+        fn(b, e);
+      } catch (...) {
+        if (!lock.test_and_set()) eptr = std::current_exception();
+        failed = true;
+      }
+    });
+  }
+  for (auto &t : th) t.join();
+  if (failed && eptr) std::rethrow_exception(eptr);
+}
+
+}  // namespace
+
+uint64_t CompiledGraph::device_bytes() const {
+  uint64_t b = 0;
+  b += 4 * (V * 4 + 1);                       // v_meta, v_orig, v_init, v_row
+  b += 4 * (R + 1) + (row_truth.empty() ? 0 : 8 * R);
+  b += 16 * NIdx + (edge_fval64.empty() ? 0 : 8 * NIdx) + 8 * NVif;
+  b += 4 * tile_v.size();
+  b += 4 * V * 2 + 4 * R;                     // assignments x2, tallies
+  b += W * (8 + 1 + 16);                      // weights, fixed, grad G/T
+  return b;
+}
+
+void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledGraph &g,
+                   bool *limit) {
+  *limit = false;
+  try {
+    const uint64_t V = d.num_variables, F = d.num_factors, E = d.num_edges, W = d.num_weights;
+    g.V = V; g.F = F; g.E = E; g.W = W;
+    if (V >= kUnset || F >= kUnset || W >= kUnset || E >= kUnset)
+      throw LimitError("graph exceeds the 32-bit compact layout (V, F, W, E must be < 2^32-1)");
+    uint32_t nth = o.n_threads ? o.n_threads : std::max(1u, std::thread::hardware_concurrency());
+    nth = std::min(nth, 64u);
+    g.tile_vars = o.tile_vars ? std::min(o.tile_vars, BLOCK_THREADS) : BLOCK_THREADS;
+    const uint32_t arity_cap = o.conflict_arity_cap ? o.conflict_arity_cap : 256;
+    if (F && d.fac_edge_offset[F] != E) throw std::runtime_error("fac_edge_offset[F] != num_edges");
+
+    // ---- variables (src/binary_format.cc:64-126) ----
+    std::vector<uint8_t> is_cat(V);
+    std::vector<uint32_t> card(V), assign_dense(V);
+    g.var_is_evid.resize(V);
+    for (uint64_t v = 0; v < V; ++v) {
+      if (d.var_dtype[v] > 1)
+        throw std::runtime_error("Only Boolean and Categorical variables are supported");
+      is_cat[v] = d.var_dtype[v] == 1;
+      if (d.var_cardinality[v] > MAX_CARD) throw LimitError("cardinality exceeds 2^24-1");
+      card[v] = (uint32_t)d.var_cardinality[v];
+      if (is_cat[v] && card[v] == 0) throw std::runtime_error("categorical variable with cardinality 0");
+      g.var_is_evid[v] = d.var_role[v] >= 1;
+      uint64_t init = g.var_is_evid[v] ? d.var_init_value[v] : 0;
+      if (init >= kUnset && d.num_domains == 0) throw LimitError("initial value exceeds 32 bits");
+      assign_dense[v] = (uint32_t)init;
+      if (is_cat[v]) { g.has_categorical = true; g.max_card = std::max(g.max_card, card[v]); }
+    }
+
+    // ---- domains (src/binary_format.cc:192-226): value -> index in file order ----
+    // per block: (value, index) sorted by value, last index wins for duplicates
+    std::vector<int64_t> dom_of(d.num_domains ? V : 0, -1);
+    std::vector<uint64_t> ds_val;   // sorted values per block (same offsets as dom_offset)
+    std::vector<uint32_t> ds_idx;
+    std::vector<double> total_truth(V, 0.0);
+    if (d.num_domains) {
+      ds_val.resize(d.dom_offset[d.num_domains]);
+      ds_idx.resize(ds_val.size());
+      for (uint64_t b = 0; b < d.num_domains; ++b) {
+        uint64_t vid = d.dom_vid[b];
+        if (vid >= V) throw std::runtime_error("domain block for unknown variable");
+        uint64_t lo = d.dom_offset[b], hi = d.dom_offset[b + 1];
+        if (!is_cat[vid]) throw std::runtime_error("domain block for a boolean variable");
+        if (hi - lo != card[vid]) throw std::runtime_error("domain size != cardinality");
+        std::vector<uint32_t> ord(hi - lo);
+        std::iota(ord.begin(), ord.end(), 0u);
+        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) {
+          return d.dom_value[lo + a] < d.dom_value[lo + c];
+        });
+        double tt = 0;
+        for (uint64_t i = 0; i < ord.size(); ++i) {
+          ds_val[lo + i] = d.dom_value[lo + ord[i]];
+          ds_idx[lo + i] = ord[i];
+          double tr = d.dom_truthiness[lo + ord[i]];
+          if (!(tr >= 0 && tr <= 1)) throw std::runtime_error("truthiness outside [0,1]");
+          bool last_of_run = (i + 1 == ord.size()) || d.dom_value[lo + ord[i + 1]] != ds_val[lo + i];
+          if (last_of_run) tt += tr;   // unordered_map keeps one entry per value (the last)
+        }
+        total_truth[vid] = tt;
+        dom_of[vid] = (int64_t)b;
+      }
+    }
+    auto domain_index = [&](uint64_t vid, uint64_t val) -> uint64_t {  // src/variable.h:124-126
+      if (dom_of.empty() || dom_of[vid] < 0) return val;
+      uint64_t b = dom_of[vid], lo = d.dom_offset[b], hi = d.dom_offset[b + 1];
+      // last element equal to val
+      auto it = std::upper_bound(ds_val.begin() + lo, ds_val.begin() + hi, val);
+      if (it == ds_val.begin() + lo || *(it - 1) != val)
+        throw std::runtime_error("value " + std::to_string(val) + " not in the domain of variable " +
+                                 std::to_string(vid));
+      return ds_idx[(it - 1) - ds_val.begin()];
+    };
+    if (d.num_domains)
+      for (uint64_t v = 0; v < V; ++v)
+        if (dom_of[v] >= 0 && assign_dense[v]) {
+          uint64_t init = g.var_is_evid[v] ? d.var_init_value[v] : 0;
+          assign_dense[v] = (uint32_t)domain_index(v, init);
+        }
+
+    // ---- reference value numbering (src/factor_graph.cc:139-175) ----
+    g.ref_var_val_base.resize(V);
+    uint64_t R = 0;
+    for (uint64_t v = 0; v < V; ++v) { g.ref_var_val_base[v] = R; R += is_cat[v] ? card[v] : 1; }
+    if (R >= kUnset) throw LimitError("number of value rows exceeds 2^32-1");
+    g.R = R;
+    g.value_sparse.assign(R, 0);
+    std::vector<double> ref_truth;
+    for (uint64_t v = 0; v < V; ++v) {
+      if (!is_cat[v]) continue;
+      uint64_t base = g.ref_var_val_base[v];
+      if (!dom_of.empty() && dom_of[v] >= 0) {
+        uint64_t b = dom_of[v], lo = d.dom_offset[b];
+        if (ref_truth.empty()) ref_truth.assign(R, 0.0);
+        for (uint32_t j = 0; j < card[v]; ++j) g.value_sparse[base + j] = kInvalid64;
+        for (uint32_t i = 0; i < card[v]; ++i) {
+          bool last_of_run = (i + 1 == card[v]) || ds_val[lo + i + 1] != ds_val[lo + i];
+          if (!last_of_run) continue;
+          uint32_t idx = ds_idx[lo + i];
+          g.value_sparse[base + idx] = ds_val[lo + i];
+          ref_truth[base + idx] = d.dom_truthiness[lo + idx];
+        }
+      } else {
+        for (uint32_t j = 0; j < card[v]; ++j) g.value_sparse[base + j] = j;
+      }
+    }
+    for (uint64_t v = 0; v < V; ++v)
+      if (is_cat[v] && g.var_is_evid[v] && assign_dense[v] >= card[v])
+        throw std::runtime_error("evidence value of variable " + std::to_string(v) +
+                                 " is outside its domain");
+    for (double t : ref_truth) if (t != 0.0) { g.has_truthiness = true; break; }
+
+    // ---- factors: dense predicates + per-variable back-refs
+    //      (src/binary_format.cc:128-190) ----
+    std::vector<uint32_t> edge_dense(E);
+    std::vector<uint32_t> cnt(V + 1, 0);
+    for (uint64_t f = 0; f < F; ++f) {
+      uint64_t lo = d.fac_edge_offset[f], hi = d.fac_edge_offset[f + 1];
+      if (hi < lo || hi > E) throw std::runtime_error("fac_edge_offset not monotone");
+      if (hi - lo > MAX_ARITY) throw LimitError("factor arity exceeds 2^24-1");
+      if (!known_func(d.fac_func[f]))
+        throw std::runtime_error("Unsupported FACTOR_FUNCTION_TYPE = " + std::to_string(d.fac_func[f]));
+      if (d.fac_weight_id[f] >= W) throw std::runtime_error("factor references unknown weight");
+    }
+    for (uint64_t e = 0; e < E; ++e) {
+      uint64_t vid = d.edge_vid[e];
+      if (vid >= V) throw std::runtime_error("factor references unknown variable");
+      ++cnt[vid + 1];
+    }
+    std::vector<uint64_t> start(V + 1, 0);
+    for (uint64_t v = 0; v < V; ++v) start[v + 1] = start[v] + cnt[v + 1];
+    std::vector<uint32_t> pv(E), pf(E);
+    {
+      std::vector<uint64_t> cur(start.begin(), start.end() - 1);
+      for (uint64_t f = 0; f < F; ++f)
+        for (uint64_t e = d.fac_edge_offset[f]; e < d.fac_edge_offset[f + 1]; ++e) {
+          uint64_t vid = d.edge_vid[e];
+          uint64_t dense = domain_index(vid, d.edge_equal_to[e]);
+          if (dense >= kUnset) throw LimitError("predicate value exceeds 32 bits");
+          edge_dense[e] = (uint32_t)dense;
+          uint64_t slot = cur[vid]++;
+          pv[slot] = is_cat[vid] ? (uint32_t)dense : 0u;   // booleans index under value 0
+          pf[slot] = (uint32_t)f;
+        }
+    }
+
+    // ---- construct_index: sort by (value, fid), dedup (src/factor_graph.cc:177-197) ----
+    std::vector<uint32_t> row_len(R, 0);
+    std::vector<uint32_t> ucnt(V, 0);
+    parallel_ranges(V, nth, [&](uint64_t vb, uint64_t ve) {
+      std::vector<std::pair<uint32_t, uint32_t>> tmp;
+      for (uint64_t v = vb; v < ve; ++v) {
+        uint64_t lo = start[v], hi = start[v + 1];
+        if (lo == hi) continue;
+        bool sorted = true;
+        for (uint64_t i = lo + 1; i < hi && sorted; ++i)
+          sorted = pv[i - 1] < pv[i] || (pv[i - 1] == pv[i] && pf[i - 1] <= pf[i]);
+        if (!sorted) {
+          tmp.resize(hi - lo);
+          for (uint64_t i = lo; i < hi; ++i) tmp[i - lo] = {pv[i], pf[i]};
+          std::sort(tmp.begin(), tmp.end());
+          for (uint64_t i = lo; i < hi; ++i) { pv[i] = tmp[i - lo].first; pf[i] = tmp[i - lo].second; }
+        }
+        uint64_t w = lo;
+        for (uint64_t i = lo; i < hi; ++i) {
+          if (i > lo && pv[i] == pv[w - 1] && pf[i] == pf[w - 1]) continue;
+          uint32_t lim = is_cat[v] ? card[v] : 1;
+          if (pv[i] >= lim)
+            throw std::runtime_error("predicate value outside the domain of variable " + std::to_string(v));
+          pv[w] = pv[i]; pf[w] = pf[i]; ++w;
+          ++row_len[g.ref_var_val_base[v] + pv[i]];
+        }
+        ucnt[v] = (uint32_t)(w - lo);
+      }
+    });
+    g.ref_row_ptr.assign(R + 1, 0);
+    for (uint64_t r = 0; r < R; ++r) g.ref_row_ptr[r + 1] = g.ref_row_ptr[r] + row_len[r];
+    g.NIdx = g.ref_row_ptr[R];
+    if (g.NIdx >= kUnset) throw LimitError("index entries exceed 2^32-1");
+    g.ref_fidx.resize(g.NIdx);
+    parallel_ranges(V, nth, [&](uint64_t vb, uint64_t ve) {
+      for (uint64_t v = vb; v < ve; ++v) {
+        uint64_t src = start[v], dst = g.ref_row_ptr[g.ref_var_val_base[v]];
+        // the variable's unique (value, fid) pairs are sorted by value, so they are
+        // exactly its rows back to back
+        for (uint32_t i = 0; i < ucnt[v]; ++i) g.ref_fidx[dst + i] = pf[src + i];
+      }
+    });
+    std::vector<uint32_t>().swap(pv);
+    std::vector<uint32_t>().swap(pf);
+
+    // ---- chromatic partition: greedy colouring of the variable conflict graph
+    //      (two variables conflict iff they share a factor of arity 2..cap) ----
+    std::vector<uint32_t> color(V, kUnset);
+    {
+      std::vector<uint64_t> stamp;
+      uint32_t ncol = 0;
+      for (uint64_t v = 0; v < V; ++v) {
+        uint64_t r0 = g.ref_var_val_base[v], r1 = r0 + (is_cat[v] ? card[v] : 1);
+        for (uint64_t i = g.ref_row_ptr[r0]; i < g.ref_row_ptr[r1]; ++i) {
+          uint32_t f = g.ref_fidx[i];
+          uint64_t lo = d.fac_edge_offset[f], hi = d.fac_edge_offset[f + 1];
+          if (hi - lo < 2 || hi - lo > arity_cap) continue;
+          for (uint64_t e = lo; e < hi; ++e) {
+            uint64_t u = d.edge_vid[e];
+            if (u == v || color[u] == kUnset) continue;
+            if (color[u] >= stamp.size()) stamp.resize(color[u] + 1, 0);
+            stamp[color[u]] = v + 1;
+          }
+        }
+        uint32_t c = 0;
+        while (c < stamp.size() && stamp[c] == v + 1) ++c;
+        color[v] = c;
+        ncol = std::max(ncol, c + 1);
+      }
+      g.n_colors = V ? ncol : 0;
+    }
+
+    // ---- device order: colour-major, booleans before categoricals, then id ----
+    const uint32_t nkeys = std::max(1u, g.n_colors) * 2;
+    std::vector<uint64_t> key_start(nkeys + 1, 0);
+    for (uint64_t v = 0; v < V; ++v) ++key_start[color[v] * 2 + is_cat[v] + 1];
+    for (uint32_t k = 0; k < nkeys; ++k) key_start[k + 1] += key_start[k];
+    g.perm.resize(V); g.pos.resize(V);
+    {
+      std::vector<uint64_t> cur(key_start.begin(), key_start.end() - 1);
+      for (uint64_t v = 0; v < V; ++v) {
+        uint64_t p = cur[color[v] * 2 + is_cat[v]]++;
+        g.perm[p] = (uint32_t)v; g.pos[v] = (uint32_t)p;
+        if (p != v) g.order_is_identity = false;
+      }
+    }
+    g.launch_off.clear();
+    for (uint32_t c = 0; c < g.n_colors; ++c) g.launch_off.push_back(key_start[2 * c]);
+    g.launch_off.push_back(V);
+    if (g.n_colors == 0) g.launch_off.assign(1, 0);
+
+    // ---- device rows ----
+    g.v_meta.resize(V); g.v_init.resize(V); g.v_row.resize(V + 1);
+    g.v_row[0] = 0;
+    for (uint64_t p = 0; p < V; ++p) {
+      uint64_t v = g.perm[p];
+      uint32_t m = (is_cat[v] ? VM_CATEGORICAL : 0) | (g.var_is_evid[v] ? VM_EVIDENCE : 0) |
+                   (!is_linear_zero(total_truth[v]) ? VM_TRUTHINESS : 0) |
+                   ((is_cat[v] ? card[v] : 2u) << VM_CARD_SHIFT);
+      g.v_meta[p] = m;
+      g.v_init[p] = assign_dense[v];
+      g.v_row[p + 1] = g.v_row[p] + (is_cat[v] ? card[v] : 1);
+    }
+    g.row_ptr.assign(R + 1, 0);
+    if (g.has_truthiness) g.row_truth.assign(R, 0.0);
+    for (uint64_t p = 0; p < V; ++p) {
+      uint64_t v = g.perm[p], rb = g.ref_var_val_base[v];
+      uint32_t nr = g.v_row[p + 1] - g.v_row[p];
+      for (uint32_t j = 0; j < nr; ++j) {
+        g.row_ptr[g.v_row[p] + j + 1] = row_len[rb + j];
+        if (g.has_truthiness) g.row_truth[g.v_row[p] + j] = ref_truth[rb + j];
+      }
+    }
+    for (uint64_t r = 0; r < R; ++r) g.row_ptr[r + 1] += g.row_ptr[r];
+
+    // ---- vifs of factors with arity >= 2 ----
+    std::vector<uint32_t> vif_base(F, 0);
+    uint64_t nvif = 0;
+    for (uint64_t f = 0; f < F; ++f) {
+      uint64_t a = d.fac_edge_offset[f + 1] - d.fac_edge_offset[f];
+      if (a >= 2) { vif_base[f] = (uint32_t)nvif; nvif += a; }
+      if (nvif >= kUnset) throw LimitError("vif entries exceed 2^32-1");
+    }
+    g.NVif = nvif;
+    g.vifs.resize(nvif);
+    parallel_ranges(F, nth, [&](uint64_t fb, uint64_t fe) {
+      for (uint64_t f = fb; f < fe; ++f) {
+        uint64_t lo = d.fac_edge_offset[f], hi = d.fac_edge_offset[f + 1];
+        if (hi - lo < 2) continue;
+        for (uint64_t e = lo; e < hi; ++e)
+          g.vifs[vif_base[f] + (e - lo)] = VifRec{g.pos[d.edge_vid[e]], edge_dense[e]};
+      }
+    });
+
+    // ---- edge records, variable-major in device order ----
+    g.edges.resize(g.NIdx);
+    std::atomic<bool> need64{false};
+    parallel_ranges(V, nth, [&](uint64_t pb, uint64_t pe) {
+      for (uint64_t p = pb; p < pe; ++p) {
+        uint64_t v = g.perm[p];
+        uint64_t src = g.ref_row_ptr[g.ref_var_val_base[v]], dst = g.row_ptr[g.v_row[p]];
+        uint64_t n = g.row_ptr[g.v_row[p + 1]] - dst;
+        for (uint64_t i = 0; i < n; ++i) {
+          uint32_t f = g.ref_fidx[src + i];
+          uint64_t lo = d.fac_edge_offset[f], a = d.fac_edge_offset[f + 1] - lo;
+          EdgeRec r;
+          r.wid = (uint32_t)d.fac_weight_id[f];
+          r.aux = a == 1 ? edge_dense[lo] : vif_base[f];
+          r.packed = (uint32_t)d.fac_func[f] | ((uint32_t)a << EDGE_ARITY_SHIFT);
+          double fv = d.fac_feature_value[f];
+          r.fval = (float)fv;
+          if (!((double)r.fval == fv)) { r.packed |= EDGE_F64_FLAG; need64 = true; }
+          g.edges[dst + i] = r;
+        }
+      }
+    });
+    if (need64) {
+      g.has_f64_fval = true;
+      g.edge_fval64.resize(g.NIdx);
+      parallel_ranges(V, nth, [&](uint64_t pb, uint64_t pe) {
+        for (uint64_t p = pb; p < pe; ++p) {
+          uint64_t v = g.perm[p];
+          uint64_t src = g.ref_row_ptr[g.ref_var_val_base[v]], dst = g.row_ptr[g.v_row[p]];
+          uint64_t n = g.row_ptr[g.v_row[p + 1]] - dst;
+          for (uint64_t i = 0; i < n; ++i) g.edge_fval64[dst + i] = d.fac_feature_value[g.ref_fidx[src + i]];
+        }
+      });
+    }
+
+    // ---- workgroup tiles: <= tile_vars variables of one type whose value rows and
+    //      edge records fit the LDS budget; an oversized variable gets a tile alone ----
+    g.ecap = o.tile_edges ? o.tile_edges : 3072;
+    g.rcap = o.tile_rows ? o.tile_rows : (g.has_categorical ? 2048 : g.tile_vars);
+    if (g.rcap < g.tile_vars && !g.has_categorical) g.rcap = g.tile_vars;
+    g.tile_v.clear(); g.launch_tile.clear();
+    const uint64_t nl = g.launch_off.size() - 1;
+    for (uint64_t l = 0; l < nl; ++l) {
+      g.launch_tile.push_back((uint32_t)g.tile_v.size());
+      uint64_t p = g.launch_off[l], pend = g.launch_off[l + 1];
+      while (p < pend) {
+        uint64_t t0 = p;
+        uint32_t cat = g.v_meta[p] & VM_CATEGORICAL;
+        uint64_t rows = 0, edges = 0;
+        while (p < pend && p - t0 < g.tile_vars && (g.v_meta[p] & VM_CATEGORICAL) == cat) {
+          uint64_t nr = g.v_row[p + 1] - g.v_row[p];
+          uint64_t ne = g.row_ptr[g.v_row[p + 1]] - g.row_ptr[g.v_row[p]];
+          if (p > t0 && (rows + nr > g.rcap || edges + ne > g.ecap)) break;
+          rows += nr; edges += ne; ++p;
+          if (rows > g.rcap || edges > g.ecap) break;   // oversized single variable
+        }
+        if (rows > g.rcap || edges > g.ecap) ++g.n_giant_tiles;
+        g.tile_v.push_back((uint32_t)t0);
+      }
+    }
+    g.launch_tile.push_back((uint32_t)g.tile_v.size());
+    g.tile_v.push_back((uint32_t)V);
+
+    g.w_init.assign(d.w_initial_value, d.w_initial_value + W);
+    g.w_fixed.assign(d.w_is_fixed, d.w_is_fixed + W);
+    g.ref_row_has.clear();
+  } catch (const LimitError &) {
+    *limit = true;
+    throw;
+  }
+}
+
+}  // namespace dwx

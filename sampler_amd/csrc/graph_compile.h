@@ -1,0 +1,67 @@
+// graph_compile.h -- host-side graph compiler: from the columnar image of the
+// reference's input files (dwx_graph_desc) to the compact device layout.
+//
+// Restates, MI355X-first, what the reference does in FactorGraph::load_factors /
+// load_domains (dense predicate conversion, src/binary_format.cc:128-226) and
+// FactorGraph::construct_index (sort + dedup of (value, factor) back-refs,
+// src/factor_graph.cc:90-199), then adds what the device needs: a chromatic
+// partition of the variable conflict graph, a colour-major variable order, 16-byte
+// variable-major edge records and LDS-sized workgroup tiles.
+#ifndef DWX_GRAPH_COMPILE_H_
+#define DWX_GRAPH_COMPILE_H_
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/dwx.h"
+#include "device_types.h"
+
+namespace dwx {
+
+struct CompiledGraph {
+  uint64_t V = 0, F = 0, E = 0, W = 0;
+  uint64_t R = 0;      // value rows (== num_values)
+  uint64_t NIdx = 0;   // edge records (== |factor_index| after dedup)
+  uint64_t NVif = 0;   // vif entries of factors with arity >= 2
+  uint32_t n_colors = 0, n_giant_tiles = 0, max_card = 2;
+  bool has_categorical = false, has_truthiness = false, has_f64_fval = false;
+  bool order_is_identity = true;
+  uint32_t tile_vars = 256, ecap = 3072, rcap = 256;
+
+  // ---- reference numbering (for dumps and parity) ----
+  std::vector<uint64_t> ref_var_val_base;  // [V]
+  std::vector<uint64_t> value_sparse;      // [R]   values[].value
+  std::vector<uint64_t> ref_row_ptr;       // [R+1] into ref_fidx
+  std::vector<uint32_t> ref_fidx;          // [NIdx] factor ids, reference order
+  std::vector<uint8_t> ref_row_has;        // [R] whether the row has any factor
+
+  // ---- device order ----
+  std::vector<uint32_t> perm;      // [V] position -> original variable id
+  std::vector<uint32_t> pos;       // [V] original id -> position
+  std::vector<uint32_t> v_meta;    // [V]
+  std::vector<uint32_t> v_init;    // [V]
+  std::vector<uint32_t> v_row;     // [V+1]
+  std::vector<uint32_t> row_ptr;   // [R+1]
+  std::vector<double> row_truth;   // [R] or empty
+  std::vector<EdgeRec> edges;      // [NIdx]
+  std::vector<double> edge_fval64; // [NIdx] or empty
+  std::vector<VifRec> vifs;        // [NVif]
+  std::vector<uint32_t> tile_v;       // [n_tiles+1]
+  std::vector<uint32_t> launch_tile;  // [n_launches+1] into tile_v
+  std::vector<uint64_t> launch_off;   // [n_launches+1] variable positions
+  std::vector<uint8_t> var_is_evid;   // [V] original order (for nsamples)
+
+  std::vector<double> w_init;      // [W]
+  std::vector<uint8_t> w_fixed;    // [W]
+
+  uint64_t device_bytes() const;
+};
+
+// Throws std::runtime_error (message for dwx_last_error) on malformed input;
+// `limit` is set when the failure is a 32-bit layout limit.
+void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledGraph &g,
+                   bool *limit);
+
+}  // namespace dwx
+#endif

@@ -1,0 +1,85 @@
+// rt_hip.h -- the thin HIP runtime layer under the C ABI (device memory, stream,
+// events, launches).  tests/hipemu/rt_emu.h provides the same names on the host so the
+// kernels can run under sanitizers in CI; the product library only ever uses this file.
+#ifndef DWX_RT_HIP_H_
+#define DWX_RT_HIP_H_
+
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace dwx {
+namespace rt {
+
+inline void check(hipError_t e, const char *what) {
+  if (e != hipSuccess)
+    throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+#define DWX_HIP(x) ::dwx::rt::check((x), #x)
+
+typedef hipStream_t stream_t;
+typedef hipEvent_t event_t;
+
+inline void init_device(int dev) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw std::runtime_error("no HIP device available (the dwx sampler has no CPU fallback)");
+  if (dev < 0 || dev >= n)
+    throw std::runtime_error("HIP device ordinal " + std::to_string(dev) + " out of range");
+  DWX_HIP(hipSetDevice(dev));
+}
+inline void set_device(int dev) { DWX_HIP(hipSetDevice(dev)); }
+
+inline void *dmalloc(size_t n) {
+  void *p = nullptr;
+  DWX_HIP(hipMalloc(&p, n ? n : 16));
+  return p;
+}
+inline void dfree(void *p) { if (p) (void)hipFree(p); }
+inline void h2d(void *d, const void *h, size_t n, stream_t s) {
+  if (n) DWX_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s));
+}
+inline void d2h(void *h, const void *d, size_t n, stream_t s) {
+  if (n) DWX_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
+}
+inline void dmemset(void *d, int v, size_t n, stream_t s) {
+  if (n) DWX_HIP(hipMemsetAsync(d, v, n, s));
+}
+inline stream_t stream_create() {
+  stream_t s;
+  DWX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
+}
+inline void stream_destroy(stream_t s) { (void)hipStreamDestroy(s); }
+inline void stream_sync(stream_t s) { DWX_HIP(hipStreamSynchronize(s)); }
+inline event_t event_create() {
+  event_t e;
+  DWX_HIP(hipEventCreate(&e));
+  return e;
+}
+inline void event_destroy(event_t e) { (void)hipEventDestroy(e); }
+inline void event_record(event_t e, stream_t s) { DWX_HIP(hipEventRecord(e, s)); }
+inline double event_elapsed_ms(event_t a, event_t b) {
+  float ms = 0;
+  DWX_HIP(hipEventElapsedTime(&ms, a, b));
+  return ms;
+}
+
+template <class K>
+inline void allow_dynamic_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024)
+    DWX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+template <class K, class... A>
+inline void launch(K kernel, unsigned grid, unsigned block, size_t lds, stream_t s, A... args) {
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, args...);
+  DWX_HIP(hipGetLastError());
+}
+
+}  // namespace rt
+}  // namespace dwx
+#endif

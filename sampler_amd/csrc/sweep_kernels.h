@@ -1,0 +1,386 @@
+// sweep_kernels.h -- the Gibbs sweep as hand-written HIP for gfx950 (CDNA4).
+//
+// One workgroup (256 threads = 4 wave64) owns one TILE of consecutive variables of one
+// colour.  The tile's value-row pointers and its 16-byte edge records are ONE
+// contiguous HBM range each (variable-major layout, graph_compile.cc), staged into
+// LDS with coalesced 16 B/lane loads; then one lane per variable walks its rows out
+// of LDS in the reference's order (ascending (value, factor id)), gathers
+// weight[wid] (L2 / Infinity-Cache resident) and neighbour assignments, draws with a
+// counter-based Philox4x32-10 stream and writes its assignment + tally.  Variables
+// of one launch form an independent set, so a launch is exactly a sequential Gibbs
+// scan of those variables.  This path is gather/stream bound: no MFMA.
+//
+// Reference functions restated here (paths relative to /root/reference):
+//   sample_single_variable      src/gibbs_sampler.h:151-169
+//   sample_sgd_single_variable  src/gibbs_sampler.h:127-149
+//   sample_evid / draw_sample   src/gibbs_sampler.h:171-254
+//   FactorGraph::potential      src/factor_graph.h:127-145
+//   Factor::potential + signs   src/factor.h:59-299
+//   sgd_on_variable / _factor   src/factor_graph.cc:243-314
+//   update_weight               src/inference_result.h:66-85 (batched: apply_kernel)
+//   logadd                      src/common.h:118-132
+//
+// The file is HIP source; tests/hipemu compiles the very same text for the host
+// (fibers stand in for a workgroup) so the kernels run under ASan/UBSan in CI.
+#ifndef DWX_SWEEP_KERNELS_H_
+#define DWX_SWEEP_KERNELS_H_
+
+#include "device_types.h"
+
+#ifndef DWX_DEV
+#define DWX_DEV __device__ __forceinline__
+#endif
+
+namespace dwx {
+
+constexpr uint32_t kNoVar = 0xFFFFFFFFu;
+
+// ---------------------------------------------------------------- RNG
+// Philox4x32-10 (Salmon et al., SC'11).  key = seed, counter = (variable id, sweep).
+DWX_DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t &c0, uint32_t &c1, uint32_t &c2,
+                           uint32_t &c3) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+}
+
+// two uniforms in [0,1) with 53 random bits each
+DWX_DEV void philox_uniforms(uint64_t seed, uint64_t vid, uint64_t sweep, double &A, double &B) {
+  uint32_t c0 = (uint32_t)vid, c1 = (uint32_t)(vid >> 32), c2 = (uint32_t)sweep,
+           c3 = (uint32_t)(sweep >> 32);
+  philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c0, c1, c2, c3);
+  uint64_t a = (uint64_t)c0 | ((uint64_t)c1 << 32);
+  uint64_t b = (uint64_t)c2 | ((uint64_t)c3 << 32);
+  A = (double)(a >> 11) * (1.0 / 9007199254740992.0);
+  B = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ---------------------------------------------------------------- math
+// src/common.h:118-132
+DWX_DEV double logadd(double a, double b) {
+  if (a < b) { double t = a; a = b; b = t; }
+  else if (a <= b && b <= a) return 0.693147180559945 + a;
+  double nd = b - a;
+  if (nd < -18.42) return a;
+  return a + log1p(exp(nd));
+}
+
+DWX_DEV bool is_linear_zero(double x) {
+  return x <= LINEAR_ZERO_THRESHOLD && x >= -LINEAR_ZERO_THRESHOLD;
+}
+
+// ---------------------------------------------------------------- factor functions
+// src/factor.h:94-100: the variable being sampled takes `proposal`, others their
+// current assignment on the chain.
+DWX_DEV bool vif_sat(const VifRec vf, uint32_t me, uint32_t proposal, const uint32_t *assign) {
+  uint32_t val = (vf.vid == me) ? proposal : assign[vf.vid];
+  return val == vf.equal_to;
+}
+
+// sign functions of src/factor.h:112-299 (returned as double, before * feature_value)
+DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const VifRec *vifs,
+                           const uint32_t *assign, uint32_t me, uint32_t proposal) {
+  if (arity == 1) {
+    // the only predicate is on the sampled variable itself
+    const bool s = (proposal == aux);
+    switch (func) {
+      case FUNC_AND: case FUNC_ISTRUE: case FUNC_OR: case FUNC_IMPLY_NATURAL:
+        return s ? 1.0 : -1.0;
+      case FUNC_EQUAL:
+        return 1.0;
+      default:  // AND_CATEGORICAL, IMPLY_MLN, LINEAR, RATIO (log2(1+s)), LOGICAL
+        return s ? 1.0 : 0.0;
+    }
+  }
+  const VifRec *v = vifs + aux;
+  switch (func) {
+    case FUNC_AND: case FUNC_ISTRUE: {
+      for (uint32_t i = 0; i < arity; ++i) if (!vif_sat(v[i], me, proposal, assign)) return -1.0;
+      return 1.0;
+    }
+    case FUNC_AND_CATEGORICAL: {
+      for (uint32_t i = 0; i < arity; ++i) if (!vif_sat(v[i], me, proposal, assign)) return 0.0;
+      return 1.0;
+    }
+    case FUNC_OR: {
+      for (uint32_t i = 0; i < arity; ++i) if (vif_sat(v[i], me, proposal, assign)) return 1.0;
+      return -1.0;
+    }
+    case FUNC_EQUAL: {
+      const bool first = vif_sat(v[0], me, proposal, assign);
+      for (uint32_t i = 1; i < arity; ++i) if (vif_sat(v[i], me, proposal, assign) != first) return -1.0;
+      return 1.0;
+    }
+    case FUNC_IMPLY_MLN: case FUNC_IMPLY_NATURAL: {
+      bool body = true;
+      for (uint32_t i = 0; i + 1 < arity; ++i) body &= vif_sat(v[i], me, proposal, assign);
+      if (!body) return func == FUNC_IMPLY_MLN ? 1.0 : 0.0;
+      const bool head = vif_sat(v[arity - 1], me, proposal, assign);
+      return func == FUNC_IMPLY_MLN ? (head ? 1.0 : 0.0) : (head ? 1.0 : -1.0);
+    }
+    default: {  // LINEAR, RATIO, LOGICAL (src/factor.h:244-296)
+      const bool head = vif_sat(v[arity - 1], me, proposal, assign);
+      double res = (func == FUNC_RATIO) ? 1.0 : 0.0;
+      for (uint32_t i = 0; i + 1 < arity; ++i) {
+        const bool s = vif_sat(v[i], me, proposal, assign);
+        res += ((!s) || head) ? 1.0 : 0.0;
+      }
+      if (func == FUNC_LINEAR) return res;
+      if (func == FUNC_RATIO) return log2(res);
+      return res > 0.0 ? 1.0 : 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- tile view
+// Where a lane reads its row pointers / edge records / potential scratch from:
+// the LDS-staged tile (normal) or HBM directly (a variable too big for one tile).
+struct TileView {
+  const uint32_t *rowptr;  // indexed by (row - row_bias)
+  uint32_t row_bias;
+  const EdgeRec *edges;    // indexed by (edge - edge_bias)
+  uint32_t edge_bias;
+  double *pot;             // per-row potential scratch (row - row_bias), or null
+};
+
+DWX_DEV uint32_t edge_func(const EdgeRec &e) { return e.packed & EDGE_FUNC_MASK; }
+DWX_DEV uint32_t edge_arity(const EdgeRec &e) { return e.packed >> EDGE_ARITY_SHIFT; }
+DWX_DEV double edge_fval(const KernelParams &P, const EdgeRec &e, uint32_t idx) {
+  return (e.packed & EDGE_F64_FLAG) ? P.edge_fval64[idx] : (double)e.fval;
+}
+
+// FactorGraph::potential for one value row (src/factor_graph.h:127-145):
+// pot = sum_i weight[wid_i] * (sign_i * feature_value_i), in row order.
+DWX_DEV double row_potential(const KernelParams &P, const TileView &T, uint32_t row,
+                             const uint32_t *assign, uint32_t me, uint32_t proposal) {
+  const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
+  double pot = 0.0;
+  for (uint32_t e = es; e < ee; ++e) {
+    const EdgeRec er = T.edges[e - T.edge_bias];
+    const double w = P.weights[er.wid];
+    const double s = factor_sign(edge_func(er), edge_arity(er), er.aux, P.vifs, assign, me, proposal);
+    pot += w * (s * edge_fval(P, er, e));
+  }
+  return pot;
+}
+
+// boolean variable: both proposals in one pass over the row (same sums, same order
+// as two calls of FactorGraph::potential, src/gibbs_sampler.h:201-202)
+DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t row,
+                             const uint32_t *assign, uint32_t me, double &pp, double &pn) {
+  const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
+  pp = 0.0; pn = 0.0;
+  for (uint32_t e = es; e < ee; ++e) {
+    const EdgeRec er = T.edges[e - T.edge_bias];
+    const double w = P.weights[er.wid];
+    const double fv = edge_fval(P, er, e);
+    const uint32_t fn = edge_func(er), ar = edge_arity(er);
+    const double s1 = factor_sign(fn, ar, er.aux, P.vifs, assign, me, 1u);
+    const double s0 = factor_sign(fn, ar, er.aux, P.vifs, assign, me, 0u);
+    pp += w * (s1 * fv);
+    pn += w * (s0 * fv);
+  }
+}
+
+// src/gibbs_sampler.h:204-214
+DWX_DEV uint32_t bool_draw(double r, double pp, double pn) {
+  return (r * (1.0 + exp(pn - pp)) < 1.0) ? 1u : 0u;
+}
+
+// categorical draw, src/gibbs_sampler.h:217-246 (inverse CDF with ONE uniform)
+DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row0, uint32_t card,
+                          const uint32_t *assign, uint32_t me, double r) {
+  double sum = -100000.0;
+  for (uint32_t d = 0; d < card; ++d) {
+    const double pot = row_potential(P, T, row0 + d, assign, me, d);
+    if (T.pot) T.pot[row0 + d - T.row_bias] = pot;
+    sum = logadd(sum, pot);
+  }
+  for (uint32_t d = 0; d < card; ++d) {
+    const double pot = T.pot ? T.pot[row0 + d - T.row_bias]
+                             : row_potential(P, T, row0 + d, assign, me, d);
+    r -= exp(pot - sum);
+    if (r <= 0) return d;
+  }
+  return card - 1;  // the reference asserts here (:243); rounding can leave r > 0
+}
+
+// sgd_on_factor (src/factor_graph.cc:243-260), gradient accumulated in fixed point:
+// G[wid] += round(2^30 * t * (pot_free - pot_evid)),  T[wid] += round(2^30 * t)
+DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uint32_t me,
+                     uint32_t evid_value, uint32_t free_value, double t) {
+  const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
+  for (uint32_t e = es; e < ee; ++e) {
+    const EdgeRec er = T.edges[e - T.edge_bias];
+    if (P.w_fixed[er.wid]) continue;
+    const double fv = edge_fval(P, er, e);
+    const uint32_t fn = edge_func(er), ar = edge_arity(er);
+    const double pot_evid = factor_sign(fn, ar, er.aux, P.vifs, P.assign_evid, me, evid_value) * fv;
+    const double pot_free = factor_sign(fn, ar, er.aux, P.vifs, P.assign_free, me, free_value) * fv;
+    const double g = pot_free - pot_evid;
+    const long long gi = llrint(FIX_SCALE * (t * g));
+    const long long ti = llrint(FIX_SCALE * t);
+    if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
+    atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)ti);
+  }
+}
+
+// ---------------------------------------------------------------- one variable
+template <bool LEARN>
+DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t p) {
+  const uint32_t meta = P.v_meta[p];
+  const bool is_cat = meta & VM_CATEGORICAL;
+  const bool is_evid = meta & VM_EVIDENCE;
+  const uint32_t card = meta >> VM_CARD_SHIFT;
+  const uint32_t row0 = P.v_row[p];
+  if (!LEARN) {
+    // sample_single_variable (src/gibbs_sampler.h:151-169)
+    if (is_evid && !(P.flags & OPT_SAMPLE_EVIDENCE)) return;
+    double A, B;
+    philox_uniforms(P.seed, P.v_orig[p], P.sweep, A, B);
+    uint32_t prop;
+    if (!is_cat) {
+      double pp, pn;
+      bool_potentials(P, T, row0, P.assign_evid, p, pp, pn);
+      prop = bool_draw(A, pp, pn);
+      if (prop) P.tally[row0] += 1;
+    } else {
+      prop = cat_draw(P, T, row0, card, P.assign_evid, p, A);
+      P.tally[row0 + prop] += 1;
+    }
+    P.assign_evid[p] = prop;
+    return;
+  }
+  // sample_sgd_single_variable (src/gibbs_sampler.h:127-149)
+  const bool noise_aware = P.flags & OPT_NOISE_AWARE;
+  const bool has_truth = meta & VM_TRUTHINESS;
+  double A, B;
+  philox_uniforms(P.seed, P.v_orig[p], P.sweep, A, B);
+  // free chain
+  uint32_t p_free;
+  if (!is_cat) {
+    double pp, pn;
+    bool_potentials(P, T, row0, P.assign_free, p, pp, pn);
+    p_free = bool_draw(A, pp, pn);
+  } else {
+    p_free = cat_draw(P, T, row0, card, P.assign_free, p, A);
+  }
+  P.assign_free[p] = p_free;
+  // evidence chain: sample_evid (src/gibbs_sampler.h:171-190)
+  const uint32_t evid_value = P.v_init[p];
+  uint32_t p_evid;
+  if (!noise_aware && is_evid) {
+    p_evid = evid_value;
+  } else if (noise_aware && has_truth) {
+    double sum = 0;
+    p_evid = 0;
+    for (uint32_t i = 0; i < card; ++i) {
+      sum += P.row_truth[row0 + i];
+      if (sum >= B) { p_evid = i; break; }
+    }
+  } else if (!is_cat) {
+    double pp, pn;
+    bool_potentials(P, T, row0, P.assign_evid, p, pp, pn);
+    p_evid = bool_draw(B, pp, pn);
+  } else {
+    p_evid = cat_draw(P, T, row0, card, P.assign_evid, p, B);
+  }
+  P.assign_evid[p] = p_evid;
+  // src/gibbs_sampler.h:144-146
+  if (!(P.flags & OPT_LEARN_NON_EVIDENCE) &&
+      ((!noise_aware && !is_evid) || (noise_aware && !has_truth)))
+    return;
+  // sgd_on_variable (src/factor_graph.cc:262-314)
+  if (!is_cat) {
+    sgd_row(P, T, row0, p, evid_value, p_free, 1.0);
+    return;
+  }
+  for (uint32_t val = 0; val < card; ++val) {
+    if (!noise_aware && val != evid_value) continue;
+    double t = 1.0;
+    if (noise_aware) {
+      t = P.row_truth ? P.row_truth[row0 + val] : 0.0;
+      if (is_linear_zero(t)) continue;
+    }
+    sgd_row(P, T, row0 + val, p, val, p_free, t);
+    if (val == p_free) continue;
+    sgd_row(P, T, row0 + p_free, p, val, p_free, t);
+  }
+}
+
+// ---------------------------------------------------------------- kernels
+#ifndef DWX_DYN_LDS
+#define DWX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
+template <bool LEARN>
+__global__ void __launch_bounds__(BLOCK_THREADS) sweep_kernel(const KernelParams P) {
+  DWX_DYN_LDS(dyn_lds);
+  const uint32_t tile = P.tile_begin + blockIdx.x;
+  const uint32_t v0 = P.tile_v[tile], v1 = P.tile_v[tile + 1];
+  const uint32_t r0 = P.v_row[v0], r1 = P.v_row[v1];
+  const uint32_t e0 = P.row_ptr[r0], e1 = P.row_ptr[r1];
+  const uint32_t nrows = r1 - r0, nedges = e1 - e0;
+  const uint32_t t = threadIdx.x;
+  // workgroup-uniform: does the tile fit the LDS budget? (the compiler only builds
+  // an oversized tile around a single variable)
+  if (nrows <= P.rcap && nedges <= P.ecap) {
+    uint32_t *s_rowptr = (uint32_t *)dyn_lds;
+    double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
+    EdgeRec *s_edges = (EdgeRec *)(dyn_lds + P.lds_edge_off);
+    for (uint32_t i = t; i <= nrows; i += BLOCK_THREADS) s_rowptr[i] = P.row_ptr[r0 + i];
+    // 16 B per lane, consecutive lanes -> consecutive records: one coalesced stream
+    for (uint32_t i = t; i < nedges; i += BLOCK_THREADS) s_edges[i] = P.edges[e0 + i];
+    __syncthreads();
+    if (t < v1 - v0) {
+      TileView T{s_rowptr, r0, s_edges, e0, P.lds_pot_off ? s_pot : nullptr};
+      process_variable<LEARN>(P, T, v0 + t);
+    }
+  } else if (t == 0) {
+    TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr};
+    for (uint32_t p = v0; p < v1; ++p) process_variable<LEARN>(P, T, p);
+  }
+}
+
+// Batched InferenceResult::update_weight (src/inference_result.h:66-85): apply one
+// sweep's accumulated gradient to every non-fixed weight that received updates,
+// then clear the accumulators.
+__global__ void __launch_bounds__(BLOCK_THREADS)
+apply_kernel(double *weights, const uint8_t *w_fixed, long long *grad, uint32_t W, double stepsize,
+             double step_cap, double reg_param, int l2) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride) {
+    const long long G = grad[i], Tn = grad[W + i];
+    if (G == 0 && Tn == 0) continue;
+    grad[i] = 0; grad[W + i] = 0;
+    if (w_fixed[i] || Tn == 0) continue;
+    const double Tt = (double)Tn / FIX_SCALE, Gg = (double)G / FIX_SCALE;
+    double eta = stepsize;
+    if (step_cap > 0 && eta * Tt > step_cap) eta = step_cap / Tt;
+    double x = weights[i];
+    if (l2) x *= pow(1.0 / (1.0 + reg_param * eta), Tt);
+    else x += reg_param * Tt * (x < 0 ? 1.0 : 0.0);
+    x -= eta * Gg;
+    weights[i] = x;
+  }
+}
+
+// test hook: one factor function evaluated on the device (test/factor_test.cc)
+__global__ void test_sign_kernel(uint32_t func, uint32_t arity, const VifRec *vifs,
+                                 const uint32_t *assign, double *out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (arity == 1) out[0] = factor_sign(func, 1, 1u, vifs, assign, 0u, assign[0]);
+    else out[0] = factor_sign(func, arity, 0u, vifs, assign, kNoVar, 0u);
+  }
+}
+
+}  // namespace dwx
+#endif  // DWX_SWEEP_KERNELS_H_

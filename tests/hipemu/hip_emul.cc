@@ -1,0 +1,112 @@
+// hip_emul.cc -- fiber scheduler of the TEST-ONLY HIP emulation (see hip_emul.h).
+#include "hip_emul.h"
+
+#include <ucontext.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/common_interface_defs.h>
+#define EMU_ASAN 1
+#else
+#define EMU_ASAN 0
+#endif
+
+namespace emu {
+
+dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
+unsigned char *g_lds = nullptr;
+
+namespace {
+constexpr size_t kStack = 256 * 1024;
+struct Fiber {
+  ucontext_t ctx;
+  char *stack = nullptr;
+  bool done = false;
+};
+ucontext_t g_sched;
+std::vector<Fiber> g_fibers;
+Fiber *g_cur = nullptr;
+const std::function<void()> *g_body = nullptr;
+#if EMU_ASAN
+void *g_sched_fake = nullptr;
+const void *g_sched_bottom = nullptr;
+size_t g_sched_size = 0;
+#endif
+
+void to_sched(bool dying) {
+#if EMU_ASAN
+  void *fake = nullptr;
+  __sanitizer_start_switch_fiber(dying ? nullptr : &fake, g_sched_bottom, g_sched_size);
+#endif
+  Fiber *self = g_cur;
+  swapcontext(&self->ctx, &g_sched);
+#if EMU_ASAN
+  __sanitizer_finish_switch_fiber(fake, &g_sched_bottom, &g_sched_size);
+#endif
+  (void)dying;
+}
+
+void entry() {
+#if EMU_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &g_sched_bottom, &g_sched_size);
+#endif
+  (*g_body)();
+  g_cur->done = true;
+  to_sched(true);
+}
+}  // namespace
+
+void syncthreads() { to_sched(false); }
+
+void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::function<void()> &body) {
+  if (g_fibers.size() < block) {
+    size_t old = g_fibers.size();
+    g_fibers.resize(block);
+    for (size_t i = old; i < block; ++i) g_fibers[i].stack = (char *)malloc(kStack);
+  }
+  gridDim_ = dim3(grid);
+  blockDim_ = dim3(block);
+  g_body = &body;
+  unsigned char *lds = (unsigned char *)malloc(lds_bytes ? lds_bytes : 16);
+  for (unsigned b = 0; b < grid; ++b) {
+    memset(lds, 0xA5, lds_bytes);  // LDS is uninitialised on the device
+    g_lds = lds;
+    blockIdx_ = dim3(b);
+    for (unsigned t = 0; t < block; ++t) {
+      Fiber &f = g_fibers[t];
+      f.done = false;
+      getcontext(&f.ctx);
+      f.ctx.uc_stack.ss_sp = f.stack;
+      f.ctx.uc_stack.ss_size = kStack;
+      f.ctx.uc_link = nullptr;
+      makecontext(&f.ctx, (void (*)())entry, 0);
+    }
+    unsigned alive = block;
+    while (alive) {
+      for (unsigned t = 0; t < block; ++t) {
+        Fiber &f = g_fibers[t];
+        if (f.done) continue;
+        threadIdx_ = dim3(t);
+        g_cur = &f;
+#if EMU_ASAN
+        void *fake = nullptr;
+        __sanitizer_start_switch_fiber(&fake, f.stack, kStack);
+#endif
+        swapcontext(&g_sched, &f.ctx);
+#if EMU_ASAN
+        __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
+        if (f.done) --alive;
+      }
+    }
+  }
+  free(lds);
+  g_lds = nullptr;
+  g_body = nullptr;
+}
+
+}  // namespace emu

@@ -1,0 +1,59 @@
+// hip_emul.h -- TEST-ONLY host emulation of the handful of HIP constructs the dwx
+// kernels use, so that sampler_amd/csrc/sweep_kernels.h (the product's kernel source,
+// unmodified) can be compiled by g++ and run under ASan/UBSan without a GPU.
+//
+// This is NOT a CPU backend of the product: nothing under sampler_amd/ includes or
+// loads it, the product library (libdwx.so) is always the hipcc/gfx950 build and
+// fails loudly without a device.  A workgroup is emulated by ucontext fibers (one per
+// thread); __syncthreads() yields to a round-robin scheduler, which is a correct
+// barrier for non-divergent barriers.  LDS is a freshly poisoned buffer per block.
+#ifndef DWX_HIP_EMUL_H_
+#define DWX_HIP_EMUL_H_
+
+#include <stdint.h>
+
+#include <cmath>
+#include <cstddef>
+#include <functional>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace emu {
+extern dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
+extern unsigned char *g_lds;
+void syncthreads();
+// run `body` once per (block, thread) of the grid, blocks sequentially
+void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::function<void()> &body);
+}  // namespace emu
+
+#define threadIdx (::emu::threadIdx_)
+#define blockIdx (::emu::blockIdx_)
+#define blockDim (::emu::blockDim_)
+#define gridDim (::emu::gridDim_)
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define DWX_DEV inline
+#define DWX_DYN_LDS(name) unsigned char *name = ::emu::g_lds
+
+inline void __syncthreads() { ::emu::syncthreads(); }
+
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
+  unsigned long long old = *p;
+  *p = old + v;
+  return old;
+}
+
+using std::exp;
+using std::log1p;
+using std::log2;
+using std::pow;
+using std::llrint;
+
+#endif

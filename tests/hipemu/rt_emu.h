@@ -1,0 +1,48 @@
+// rt_emu.h -- TEST-ONLY stand-in for sampler_amd/csrc/rt_hip.h: "device" memory is
+// host memory, a launch runs the grid on fibers (hip_emul.h).  Used only by
+// tests/hipemu/Makefile to build libdwx_emu.so for sanitizer runs of the kernel source.
+#ifndef DWX_RT_EMU_H_
+#define DWX_RT_EMU_H_
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+#include "hip_emul.h"
+
+namespace dwx {
+namespace rt {
+
+typedef void *stream_t;
+typedef std::chrono::steady_clock::time_point *event_t;
+
+inline void init_device(int dev) {
+  if (dev != 0) throw std::runtime_error("emulated device ordinal must be 0");
+}
+inline void set_device(int) {}
+inline void *dmalloc(size_t n) { return malloc(n ? n : 16); }
+inline void dfree(void *p) { free(p); }
+inline void h2d(void *d, const void *h, size_t n, stream_t) { if (n) memcpy(d, h, n); }
+inline void d2h(void *h, const void *d, size_t n, stream_t) { if (n) memcpy(h, d, n); }
+inline void dmemset(void *d, int v, size_t n, stream_t) { if (n) memset(d, v, n); }
+inline stream_t stream_create() { return (stream_t)1; }
+inline void stream_destroy(stream_t) {}
+inline void stream_sync(stream_t) {}
+inline event_t event_create() { return new std::chrono::steady_clock::time_point(); }
+inline void event_destroy(event_t e) { delete e; }
+inline void event_record(event_t e, stream_t) { *e = std::chrono::steady_clock::now(); }
+inline double event_elapsed_ms(event_t a, event_t b) {
+  return std::chrono::duration<double, std::milli>(*b - *a).count();
+}
+template <class K>
+inline void allow_dynamic_lds(K, size_t) {}
+
+template <class K, class... A>
+inline void launch(K kernel, unsigned grid, unsigned block, size_t lds, stream_t, A... args) {
+  emu::run_grid(grid, block, lds, [&]() { kernel(args...); });
+}
+
+}  // namespace rt
+}  // namespace dwx
+#endif

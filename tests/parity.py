@@ -1,0 +1,79 @@
+"""Shared parity driver: run the dwx sampler (HIP library on a GPU, or the test-only
+host emulation of the same kernel source) and the CPU oracle in schedule mode on the
+same graph, seed and sweeps, and compare state exactly."""
+import os
+import subprocess
+
+import numpy as np
+
+from oracle import binding as orc
+from sampler_amd import dwx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
+
+
+def emu_library(asan=False):
+    subprocess.run(["make", "-s", "-C", EMU_DIR], check=True)
+    name = "libdwx_emu_asan.so" if asan else "libdwx_emu.so"
+    return dwx.Library(os.path.join(EMU_DIR, "build", name))
+
+
+def gpu_library():
+    return dwx.default_library()
+
+
+def check_index_parity(graph: dwx.Graph, oracle: orc.Oracle):
+    """construct_index parity: same value rows, same factor lists per row."""
+    base, sparse = graph.values()
+    assert np.array_equal(base, oracle.var_val_base)
+    assert np.array_equal(sparse, oracle.value_sparse)
+    ib, il, fi = graph.index()
+    ob, ol, of = oracle.value_index_base, oracle.value_index_len, oracle.factor_index
+    assert np.array_equal(il, ol)
+    assert len(fi) == len(of)
+    for r in range(len(il)):
+        n = int(il[r])
+        if n:
+            assert np.array_equal(fi[int(ib[r]):int(ib[r]) + n], of[int(ob[r]):int(ob[r]) + n])
+
+
+def run_parity(lib, raw, n_learn=3, n_infer=5, stepsize=0.05, decay=0.9, seed=77,
+               sample_evidence=False, learn_non_evidence=False, noise_aware=False,
+               regularization="l2", reg_param=0.01, step_cap=1.0, compile_opts=None,
+               check_index=True, wtol=1e-12):
+    """Returns (sampler, oracle) after asserting exact parity of assignments and tallies
+    after every sweep and weights within wtol."""
+    kw = dict(sample_evidence=sample_evidence, learn_non_evidence=learn_non_evidence,
+              noise_aware=noise_aware, regularization=regularization, reg_param=reg_param)
+    g = dwx.Graph(raw, lib=lib, **(compile_opts or {}))
+    o = orc.Oracle(raw, **kw)
+    if check_index:
+        check_index_parity(g, o)
+    order, off = g.schedule()
+    assert sorted(order.tolist()) == list(range(raw.num_variables))
+    assert o.sched_check_independent(order, off), "a launch is not an independent set"
+    s = dwx.GibbsSampler(g, seed=seed, step_cap=step_cap, **kw)
+    assert np.array_equal(s.assignments("free"), o.assignments("free"))
+    assert np.array_equal(s.assignments("evid"), o.assignments("evid"))
+    sweep = 0
+    cur = stepsize
+    for _ in range(n_learn):
+        s.sample_sgd(cur); s.wait()
+        o.sched_sample_sgd(order, off, seed, sweep, cur, step_cap)
+        sweep += 1
+        cur *= decay
+        assert np.array_equal(s.assignments("free"), o.assignments("free")), "free chain differs"
+        assert np.array_equal(s.assignments("evid"), o.assignments("evid")), "evid chain differs"
+        np.testing.assert_allclose(s.weights, o.weights, rtol=wtol, atol=wtol)
+    s.clear_tallies(); o.clear_tallies()
+    for _ in range(n_infer):
+        s.sample(); s.wait()
+        o.sched_sample(order, off, seed, sweep)
+        sweep += 1
+        assert np.array_equal(s.assignments("evid"), o.assignments("evid")), "inference chain differs"
+    t, n = s.tallies()
+    assert np.array_equal(t, o.tallies), "tallies differ"
+    assert np.array_equal(n, o.nsamples), "nsamples differ"
+    assert s.sweep == sweep
+    return s, o

@@ -1,0 +1,89 @@
+"""CPU-side (no GPU) parity of the PRODUCT'S KERNEL SOURCE against the oracle: the
+file sampler_amd/csrc/sweep_kernels.h is compiled for the host against the test-only
+HIP emulation (tests/hipemu) and must reproduce the oracle's schedule-mode state
+exactly.  The same comparisons run on the real GPU in tests/test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES, GOLDEN, parse_dw_args
+from parity import emu_library, run_parity
+from sampler_amd import binary_format, synthetic
+
+
+@pytest.fixture(scope="module")
+def lib():
+    # DWX_EMU_ASAN=1 (with libasan preloaded) selects the ASan+UBSan build; see
+    # test_sanitizers.py, which re-runs this file that way in a subprocess
+    return emu_library(asan=bool(os.environ.get("DWX_EMU_ASAN")))
+
+
+@pytest.mark.parametrize("fx", FIXTURES)
+def test_fixture_parity(lib, fx):
+    d = os.path.join(GOLDEN, fx)
+    o = parse_dw_args(open(os.path.join(d, "dw-args")).read())
+    raw = binary_format.read_graph_dir(d)
+    run_parity(lib, raw, n_learn=0 if o["l"] == 0 else 25, n_infer=25, stepsize=o["alpha"],
+               decay=o["diminish"], sample_evidence=o["sample_evidence"],
+               noise_aware=o["noise_aware"], reg_param=o["reg_param"])
+
+
+@pytest.mark.parametrize("fx", ["biased_coin", "sparse_domains", "partial_observation"])
+def test_fixture_parity_flags(lib, fx):
+    raw = binary_format.read_graph_dir(os.path.join(GOLDEN, fx))
+    run_parity(lib, raw, n_learn=10, n_infer=10, learn_non_evidence=True, sample_evidence=True,
+               regularization="l1", reg_param=0.001)
+    run_parity(lib, raw, n_learn=10, n_infer=10, noise_aware=True, step_cap=0.0)
+
+
+def test_synth_cfg2(lib):
+    run_parity(lib, synthetic.cfg2(1500, n_weights=100, seed=3), n_learn=0, n_infer=6)
+
+
+def test_synth_cfg3(lib):
+    run_parity(lib, synthetic.cfg3(1500, n_weights=100, seed=4), n_learn=4, n_infer=4)
+
+
+def test_synth_cfg3b_colouring(lib):
+    raw = synthetic.cfg3b(1200, n_weights=64, seed=5)
+    s, _ = run_parity(lib, raw, n_learn=4, n_infer=4)
+    assert s.graph.info.num_colors >= 2
+
+
+def test_synth_cfg4(lib):
+    run_parity(lib, synthetic.cfg4(700, card=8, seed=6, learn=False), n_learn=0, n_infer=5)
+    run_parity(lib, synthetic.cfg4(700, card=5, seed=7, learn=True), n_learn=5, n_infer=3,
+               stepsize=0.01)
+
+
+def test_small_tiles_and_giant_variable(lib):
+    # tiny LDS budgets force ragged tiles and the direct-from-HBM path for
+    # variables that do not fit one tile
+    raw = synthetic.cfg3b(300, n_weights=16, seed=8)
+    s, _ = run_parity(lib, raw, n_learn=3, n_infer=3,
+                      compile_opts=dict(tile_vars=7, tile_edges=16, tile_rows=7))
+    raw = synthetic.cfg4(60, card=9, seed=9, learn=True)
+    s, _ = run_parity(lib, raw, n_learn=3, n_infer=3,
+                      compile_opts=dict(tile_vars=5, tile_edges=8, tile_rows=8))
+    assert s.graph.info.num_giant_tiles > 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_mixed_graphs(lib, seed):
+    from randgraph import random_graph
+    raw = random_graph(seed, truthy=bool(seed % 2))
+    s, o = run_parity(lib, raw, n_learn=6, n_infer=6, stepsize=0.1,
+                      noise_aware=bool(seed % 2), learn_non_evidence=seed in (2, 3),
+                      sample_evidence=seed in (1, 2))
+    assert not np.array_equal(s.weights, raw.w_initial_value)      # learning moved weights
+    assert np.array_equal(s.weights[raw.w_is_fixed == 1], raw.w_initial_value[raw.w_is_fixed == 1])
+    assert s.tallies()[0].sum() > 0
+
+
+def test_learning_is_doing_something(lib):
+    raw = synthetic.cfg3(1500, n_weights=100, seed=4)
+    s, o = run_parity(lib, raw, n_learn=4, n_infer=4)
+    assert np.abs(s.weights).max() > 1e-3
+    t, n = s.tallies()
+    assert t.sum() > 0 and n.max() == 4
