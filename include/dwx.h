@@ -100,6 +100,8 @@ typedef struct dwx_options {
   double step_cap;             /* cap on stepsize x (updates of one weight per sweep);
                                   <= 0 disables; default via dwx_default_options: 1.0  */
   uint64_t seed;               /* Philox key                                           */
+  uint64_t var_id_offset;      /* added to local variable ids in the Philox counter: the
+                                  global id of this shard's variable 0 (multi-GPU)     */
 } dwx_options;
 
 typedef struct dwx_graph dwx_graph;

@@ -65,6 +65,10 @@ def lib():
         L.orc_erand48.restype = dbl; L.orc_erand48.argtypes = [vp]
         L.orc_sched_sample.argtypes = [vp, vp, u64, u64]
         L.orc_sched_sample_sgd.argtypes = [vp, vp, u64, u64, dbl, dbl]
+        L.orc_sched_accumulate.argtypes = [vp, vp, u64, u64]
+        L.orc_sched_apply.argtypes = [vp, dbl, dbl]
+        L.orc_grad.restype = vp; L.orc_grad.argtypes = [vp]
+        L.orc_set_var_id_offset.argtypes = [vp, u64]
         L.orc_sched_check_independent.restype = i32
         L.orc_sched_check_independent.argtypes = [vp, vp]
         L.orc_philox_uniforms.argtypes = [u64, u64, u64, vp]
@@ -194,6 +198,20 @@ class Oracle:
     def sched_sample_sgd(self, order, launch_off, seed, sweep, stepsize, step_cap=1.0):
         s = self._sched(order, launch_off)
         self.L.orc_sched_sample_sgd(self.h, C.addressof(s), seed, sweep, stepsize, step_cap)
+
+    def sched_accumulate(self, order, launch_off, seed, sweep):
+        s = self._sched(order, launch_off)
+        self.L.orc_sched_accumulate(self.h, C.addressof(s), seed, sweep)
+
+    def sched_apply(self, stepsize, step_cap=1.0):
+        self.L.orc_sched_apply(self.h, stepsize, step_cap)
+
+    @property
+    def grad(self):
+        return _view(self.L.orc_grad(self.h), 2 * self.W, np.int64)
+
+    def set_var_id_offset(self, off):
+        self.L.orc_set_var_id_offset(self.h, off)
 
     # ---- result files (src/inference_result.cc:101-105,211-243) ----
     def weights_text(self):

@@ -113,7 +113,8 @@ struct orc_sampler {
   // exported columns
   std::vector<uint64_t> c_var_val_base, c_value_sparse, c_index_base, c_index_len, c_assign_dense;
   // schedule-mode accumulators
-  std::vector<int64_t> G, T;
+  std::vector<int64_t> GT;   // G[W] then T[W]
+  uint64_t vid_offset = 0;
 
   // ---- src/factor.h:94-100 is_variable_satisfied ----
   inline bool sat(const Vif &vif, uint64_t vid, const uint64_t *assign, uint64_t proposal) const {
@@ -417,7 +418,7 @@ extern "C" orc_sampler *orc_create(const orc_graph_desc *d, const orc_opts *opts
       s->a_free[v] = s->a_evid[v] = s->vars[v].is_evid ? s->vars[v].assignment_dense : 0;
     s->tallies.assign(nval, 0);
     s->nsamples.assign(s->V, 0);
-    s->G.assign(s->W, 0); s->T.assign(s->W, 0);
+    s->GT.assign(2 * s->W, 0);
     // exported columns
     s->c_var_val_base.resize(s->V); s->c_assign_dense.resize(s->V);
     for (uint64_t v = 0; v < s->V; ++v) {
@@ -620,6 +621,9 @@ extern "C" int orc_sched_check_independent(orc_sampler *s, const orc_schedule *s
   return 1;
 }
 
+extern "C" void orc_set_var_id_offset(orc_sampler *s, uint64_t off) { s->vid_offset = off; }
+extern "C" int64_t *orc_grad(orc_sampler *s) { return s->GT.data(); }
+
 extern "C" void orc_sched_sample(orc_sampler *s, const orc_schedule *sch, uint64_t seed, uint64_t sweep) {
   std::vector<double> buf;
   for (uint64_t i = 0; i < sch->n_order; ++i) {
@@ -627,34 +631,39 @@ extern "C" void orc_sched_sample(orc_sampler *s, const orc_schedule *sch, uint64
     const Var &var = s->vars[vid];
     if (var.is_evid && !s->opts.sample_evidence) continue;
     double A, B;
-    philox_uniforms(seed, vid, sweep, A, B);
+    philox_uniforms(seed, s->vid_offset + vid, sweep, A, B);
     uint64_t p = s->draw_sample(vid, s->a_evid.data(), s->weight_values.data(), OneShot{A}, buf);
     s->record_sample(vid, p);
   }
 }
 
-extern "C" void orc_sched_sample_sgd(orc_sampler *s, const orc_schedule *sch, uint64_t seed,
-                                     uint64_t sweep, double stepsize, double step_cap) {
+extern "C" void orc_sched_accumulate(orc_sampler *s, const orc_schedule *sch, uint64_t seed,
+                                     uint64_t sweep) {
   std::vector<double> buf;
-  std::fill(s->G.begin(), s->G.end(), 0);
-  std::fill(s->T.begin(), s->T.end(), 0);
+  int64_t *G = s->GT.data(), *T = s->GT.data() + s->W;
   for (uint64_t i = 0; i < sch->n_order; ++i) {
     uint64_t vid = sch->order[i];
     double A, B;
-    philox_uniforms(seed, vid, sweep, A, B);
+    philox_uniforms(seed, s->vid_offset + vid, sweep, A, B);
     uint64_t p = s->draw_sample(vid, s->a_free.data(), s->weight_values.data(), OneShot{A}, buf);
     s->a_free[vid] = p;
     s->a_evid[vid] = s->sample_evid(vid, OneShot{B}, buf);
     if (!s->sgd_triggers(s->vars[vid])) continue;
-    // stepsize carries only the truthiness factor here (base step applied at the end)
-    s->sgd_on_variable(vid, 1.0, [s](uint64_t wid, double t, double g) {
-      s->G[wid] += llrint(kFixScale * (t * g));
-      s->T[wid] += llrint(kFixScale * t);
+    // stepsize carries only the truthiness factor here (base step applied in apply)
+    s->sgd_on_variable(vid, 1.0, [G, T](uint64_t wid, double t, double g) {
+      G[wid] += llrint(kFixScale * (t * g));
+      T[wid] += llrint(kFixScale * t);
     });
   }
+}
+
+extern "C" void orc_sched_apply(orc_sampler *s, double stepsize, double step_cap) {
+  int64_t *G = s->GT.data(), *T = s->GT.data() + s->W;
   for (uint64_t w = 0; w < s->W; ++w) {
-    if (s->weights_isfixed[w] || s->T[w] == 0) continue;
-    double Tt = (double)s->T[w] / kFixScale, Gg = (double)s->G[w] / kFixScale;
+    const int64_t g = G[w], t = T[w];
+    G[w] = 0; T[w] = 0;
+    if (s->weights_isfixed[w] || t == 0) continue;
+    double Tt = (double)t / kFixScale, Gg = (double)g / kFixScale;
     double eta = stepsize;
     if (step_cap > 0 && eta * Tt > step_cap) eta = step_cap / Tt;
     double x = s->weight_values[w];
@@ -663,4 +672,10 @@ extern "C" void orc_sched_sample_sgd(orc_sampler *s, const orc_schedule *sch, ui
     x -= eta * Gg;
     s->weight_values[w] = x;
   }
+}
+
+extern "C" void orc_sched_sample_sgd(orc_sampler *s, const orc_schedule *sch, uint64_t seed,
+                                     uint64_t sweep, double stepsize, double step_cap) {
+  orc_sched_accumulate(s, sch, seed, sweep);
+  orc_sched_apply(s, stepsize, step_cap);
 }

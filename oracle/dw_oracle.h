@@ -116,6 +116,13 @@ typedef struct orc_schedule {
 void orc_sched_sample(orc_sampler *s, const orc_schedule *sch, uint64_t seed, uint64_t sweep);
 void orc_sched_sample_sgd(orc_sampler *s, const orc_schedule *sch, uint64_t seed, uint64_t sweep,
                           double stepsize, double step_cap);
+/* the two halves of orc_sched_sample_sgd: sample + accumulate G,T; then apply + clear */
+void orc_sched_accumulate(orc_sampler *s, const orc_schedule *sch, uint64_t seed, uint64_t sweep);
+void orc_sched_apply(orc_sampler *s, double stepsize, double step_cap);
+/* int64[2W]: fixed-point gradient sums G[W] then update counts T[W] */
+int64_t *orc_grad(orc_sampler *s);
+/* global id of local variable 0: added to ids in the Philox counter (shards) */
+void orc_set_var_id_offset(orc_sampler *s, uint64_t off);
 /* returns 1 if every launch of the schedule is an independent set */
 int orc_sched_check_independent(orc_sampler *s, const orc_schedule *sch);
 /* two uniforms in [0,1) from Philox4x32-10 (test hook) */

@@ -81,6 +81,7 @@ struct KernelParams {
   long long *grad;            // [2W]: G then T (fixed point)
   // launch
   uint64_t seed, sweep;
+  uint64_t vid_offset;        // global id of local variable 0 (Philox counter)
   uint32_t tile_begin;        // first tile of this launch
   uint32_t num_weights;
   uint32_t flags;

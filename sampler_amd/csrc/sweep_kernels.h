@@ -245,7 +245,7 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
     // sample_single_variable (src/gibbs_sampler.h:151-169)
     if (is_evid && !(P.flags & OPT_SAMPLE_EVIDENCE)) return;
     double A, B;
-    philox_uniforms(P.seed, P.v_orig[p], P.sweep, A, B);
+    philox_uniforms(P.seed, P.vid_offset + P.v_orig[p], P.sweep, A, B);
     uint32_t prop;
     if (!is_cat) {
       double pp, pn;
@@ -263,7 +263,7 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
   const bool noise_aware = P.flags & OPT_NOISE_AWARE;
   const bool has_truth = meta & VM_TRUTHINESS;
   double A, B;
-  philox_uniforms(P.seed, P.v_orig[p], P.sweep, A, B);
+  philox_uniforms(P.seed, P.vid_offset + P.v_orig[p], P.sweep, A, B);
   // free chain
   uint32_t p_free;
   if (!is_cat) {

@@ -1,0 +1,99 @@
+"""Multi-GPU driver: one process per GPU (torch.distributed; backend "nccl" is RCCL on
+ROCm), the graph sharded by contiguous VARIABLE BLOCK across ranks.
+
+Per learning sweep each rank samples its block and accumulates the fixed-point
+weight-gradient vector [G | T]; ONE all-reduce(sum) of that int64 vector over xGMI
+replaces the reference's per-epoch replica weight averaging
+(src/dimmwitted.cc:209-216) and its dormant merge_gradients_from
+(src/inference_result.cc:57-62); every rank then applies the identical update, so the
+weights stay bit-identical on all ranks without a broadcast.  Integer sums are
+order-independent, so the result does not depend on the ring order.  Inference
+tallies stay sharded (no collective) and are gathered only for the dump.
+
+The engine is abstract so that the collective logic is testable on CPU (gloo,
+world_size 2) with an oracle-backed engine living in tests/.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class _CudaArray:
+    """Expose a raw device pointer to torch through __cuda_array_interface__."""
+
+    def __init__(self, ptr, nbytes, typestr, itemsize):
+        self.__cuda_array_interface__ = {
+            "shape": (nbytes // itemsize,), "typestr": typestr, "data": (ptr, False),
+            "version": 2, "strides": None,
+        }
+
+
+class HipEngine:
+    """The product engine: a dwx.GibbsSampler on this rank's GPU.  Collectives run on
+    the sampler's own HIP stream (made torch's current stream), so kernels and RCCL
+    calls are ordered on the device without host synchronisation."""
+
+    def __init__(self, sampler):
+        from . import dwx
+        self.s = sampler
+        ptr, nbytes = sampler.device_buffer(dwx.BUF_GRAD)
+        dev = torch.device("cuda", sampler.opts.device)
+        self._holder = _CudaArray(ptr, nbytes, "<i8", 8)
+        self.grad = torch.as_tensor(self._holder, device=dev)
+        self.stream = torch.cuda.ExternalStream(sampler.stream(), device=dev)
+
+    def sgd_accumulate(self):
+        self.s.sgd_accumulate()
+
+    def sgd_apply(self, stepsize):
+        self.s.sgd_apply(stepsize)
+
+    def sample(self):
+        self.s.sample()
+
+    def wait(self):
+        self.s.wait()
+
+    def allreduce_grad(self, group=None):
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+
+
+class ShardedDimmWitted:
+    """Epoch driver over variable-block shards (DimmWitted::learn / inference,
+    src/dimmwitted.cc:121-207, with the replica loop replaced by ranks)."""
+
+    def __init__(self, engine, n_learning_epoch, n_inference_epoch, stepsize=0.01, decay=0.95,
+                 group=None):
+        self.e = engine
+        self.n_learning_epoch = n_learning_epoch
+        self.n_inference_epoch = n_inference_epoch
+        self.stepsize = stepsize
+        self.decay = decay
+        self.group = group
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def learn_epoch(self, stepsize):
+        self.e.sgd_accumulate()
+        if self.distributed:
+            self.e.allreduce_grad(self.group)
+        self.e.sgd_apply(stepsize)
+
+    def learn(self):
+        cur = self.stepsize
+        for _ in range(self.n_learning_epoch):
+            self.learn_epoch(cur)
+            cur *= self.decay
+        self.e.wait()
+
+    def inference(self):
+        for _ in range(self.n_inference_epoch):
+            self.e.sample()
+        self.e.wait()
+
+
+def shard_range(total, rank, world):
+    """Contiguous variable block of a rank: [begin, end)."""
+    per = (total + world - 1) // world
+    b = min(total, per * rank)
+    return b, min(total, b + per)

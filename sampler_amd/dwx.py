@@ -56,7 +56,8 @@ class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("sample_evidence", C.c_int32),
                 ("learn_non_evidence", C.c_int32), ("noise_aware", C.c_int32),
                 ("regularization", C.c_int32), ("reserved", C.c_int32),
-                ("reg_param", C.c_double), ("step_cap", C.c_double), ("seed", C.c_uint64)]
+                ("reg_param", C.c_double), ("step_cap", C.c_double), ("seed", C.c_uint64),
+                ("var_id_offset", C.c_uint64)]
 
 
 class Library:
@@ -167,7 +168,7 @@ class GibbsSampler:
 
     def __init__(self, graph: Graph, device=0, sample_evidence=False, learn_non_evidence=False,
                  noise_aware=False, regularization="l2", reg_param=0.01, seed=0x5eed5eed,
-                 step_cap=1.0):
+                 step_cap=1.0, var_id_offset=0):
         self.lib = graph.lib
         self.graph = graph
         o = Options()
@@ -180,6 +181,7 @@ class GibbsSampler:
         o.reg_param = float(reg_param)
         o.seed = int(seed)
         o.step_cap = float(step_cap)
+        o.var_id_offset = int(var_id_offset)
         self.opts = o
         h = C.c_void_p()
         self.lib.check(self.lib.L.dwx_sampler_create(graph.h, C.byref(o), C.byref(h)))

@@ -133,6 +133,7 @@ def synth_goldens():
         "synth_cfg4": (synthetic.cfg4(1000, card=8, seed=1234, learn=False),
                        ["-l", "0", "-i", "400"]),
     }
+    sums = {}
     for name, (g, args) in cases.items():
         dst = os.path.join(HERE, name)
         os.makedirs(dst, exist_ok=True)
@@ -145,6 +146,17 @@ def synth_goldens():
                         os.path.join(dst, "ref.weights.text"))
             shutil.copy(os.path.join(out, "inference_result.out.text"),
                         os.path.join(dst, "ref.text"))
+        # the graph files themselves are not committed (0.3-1 MB each): tests rebuild
+        # them from sampler_amd.synthetic with the same arguments and check the sha256
+        import hashlib
+        sums[name] = {f: hashlib.sha256(open(os.path.join(dst, f), "rb").read()).hexdigest()
+                      for f in sorted(os.listdir(dst)) if f.startswith("graph.")}
+        for f in list(os.listdir(dst)):
+            if f.startswith("graph."):
+                os.remove(os.path.join(dst, f))
+    import json
+    json.dump(sums, open(os.path.join(HERE, "synth_graph_sha256.json"), "w"), indent=1,
+              sort_keys=True)
 
 
 if __name__ == "__main__":
