@@ -154,11 +154,15 @@ def main():
 
     if rank == 0:
         total_vars = 2.0 * V * n_gpus * args.steps
+        # units one launch processes: a learning launch visits every variable of the
+        # block (both chains); an inference launch visits the query variables only
+        # (evidence is skipped, as in the reference, but still counted in vars/sec)
+        Vq = int(graph.info.num_query_variables)
         if ms_l >= ms_i:
-            kname, per_launch_ms, bpv = "sweep_kernel<LEARN=true>", ms_l / max(nl_l, 1), B_LEARN
+            kname, per_launch_ms, bpv, units = "sweep_kernel<LEARN=true>", ms_l / max(nl_l, 1), B_LEARN, V
         else:
-            kname, per_launch_ms, bpv = "sweep_kernel<LEARN=false>", ms_i / max(nl_i, 1), B_INFER
-        achieved = bpv * V / (per_launch_ms * 1e-3) / 1e9
+            kname, per_launch_ms, bpv, units = "sweep_kernel<LEARN=false>", ms_i / max(nl_i, 1), B_INFER, Vq
+        achieved = bpv * units / (per_launch_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
@@ -186,7 +190,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_var": bpv,
-                         "avg_launch_ms": per_launch_ms},
+                         "vars_per_launch": units, "avg_launch_ms": per_launch_ms},
+            "infer_roofline_frac": (B_INFER * Vq / (ms_i / max(nl_i, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if nl_i else None,
+            "learn_roofline_frac": (B_LEARN * V / (ms_l / max(nl_l, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if nl_l else None,
+            "sampled_vars_per_sec": (V + Vq) * n_gpus * args.steps / elapsed,
             "infer_vars_per_sec": V * n_gpus / (ms_i / max(ns_i, 1) * 1e-3) if ns_i else None,
             "learn_vars_per_sec": V * n_gpus / (ms_l / max(ns_l, 1) * 1e-3) if ns_l else None,
             "infer_kernel_ms": ms_i / max(nl_i, 1), "learn_kernel_ms": ms_l / max(nl_l, 1),

@@ -83,6 +83,8 @@ typedef struct dwx_graph_info {
   uint64_t num_vif_entries;    /* factor->variable entries kept for arity >= 2         */
   uint64_t num_colors, num_launches, num_tiles, num_giant_tiles;
   uint64_t max_cardinality;
+  uint64_t num_query_variables; /* non-evidence variables (sampled by an inference sweep
+                                   unless --sample_evidence)                            */
   uint64_t device_bytes;       /* bytes the sampler will hold in HBM                   */
   uint32_t has_categorical, order_is_identity;
 } dwx_graph_info;
@@ -173,7 +175,10 @@ enum {
                                then update counts T[W]                             */
   DWX_BUF_ASSIGN_FREE = 2,  /* uint32[V] in device order                           */
   DWX_BUF_ASSIGN_EVID = 3,  /* uint32[V] in device order                           */
-  DWX_BUF_TALLIES = 4       /* uint32[num_values] in device order                  */
+  DWX_BUF_TALLIES = 4,      /* uint32[num_values] in device order                  */
+  DWX_BUF_TSTATIC = 5       /* int64[W]: per-sweep update counts of boolean variables
+                               (fixed point, static); a multi-GPU driver sums it
+                               across shards once after create                     */
 };
 int dwx_device_buffer(dwx_sampler *s, int which, void **dev_ptr, uint64_t *nbytes);
 /* The HIP stream (hipStream_t) the sampler enqueues on. */

@@ -69,6 +69,7 @@ def lib():
         L.orc_sched_apply.argtypes = [vp, dbl, dbl]
         L.orc_grad.restype = vp; L.orc_grad.argtypes = [vp]
         L.orc_set_var_id_offset.argtypes = [vp, u64]
+        L.orc_set_sampling_weight_f32.argtypes = [vp, i32]
         L.orc_sched_check_independent.restype = i32
         L.orc_sched_check_independent.argtypes = [vp, vp]
         L.orc_philox_uniforms.argtypes = [u64, u64, u64, vp]
@@ -150,6 +151,7 @@ class Oracle:
 
     # ---- reference mode ----
     def set_workers(self, n):
+        self.L.orc_set_sampling_weight_f32(self.h, 0)
         self.L.orc_ref_set_workers(self.h, n)
 
     def set_seed(self, worker, s0, s1, s2):
@@ -192,14 +194,17 @@ class Oracle:
         return bool(self.L.orc_sched_check_independent(self.h, C.addressof(s)))
 
     def sched_sample(self, order, launch_off, seed, sweep):
+        self.L.orc_set_sampling_weight_f32(self.h, 1)
         s = self._sched(order, launch_off)
         self.L.orc_sched_sample(self.h, C.addressof(s), seed, sweep)
 
     def sched_sample_sgd(self, order, launch_off, seed, sweep, stepsize, step_cap=1.0):
+        self.L.orc_set_sampling_weight_f32(self.h, 1)
         s = self._sched(order, launch_off)
         self.L.orc_sched_sample_sgd(self.h, C.addressof(s), seed, sweep, stepsize, step_cap)
 
     def sched_accumulate(self, order, launch_off, seed, sweep):
+        self.L.orc_set_sampling_weight_f32(self.h, 1)
         s = self._sched(order, launch_off)
         self.L.orc_sched_accumulate(self.h, C.addressof(s), seed, sweep)
 

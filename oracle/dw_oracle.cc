@@ -115,6 +115,7 @@ struct orc_sampler {
   // schedule-mode accumulators
   std::vector<int64_t> GT;   // G[W] then T[W]
   uint64_t vid_offset = 0;
+  bool f32w = false;  // schedule mode: potentials use the weight rounded to f32 (device's sampling copy)
 
   // ---- src/factor.h:94-100 is_variable_satisfied ----
   inline bool sat(const Vif &vif, uint64_t vid, const uint64_t *assign, uint64_t proposal) const {
@@ -195,7 +196,8 @@ struct orc_sampler {
     const Value &vv = values[var.var_val_base + (var.is_bool ? 0 : proposal)];
     for (uint64_t i = 0; i < vv.index_len; ++i) {
       const Factor &f = factors[factor_index[vv.index_base + i]];
-      pot += w[f.weight_id] * factor_potential(f, assign, vid, proposal);
+      const double wv = f32w ? (double)(float)w[f.weight_id] : w[f.weight_id];
+      pot += wv * factor_potential(f, assign, vid, proposal);
     }
     return pot;
   }
@@ -622,6 +624,7 @@ extern "C" int orc_sched_check_independent(orc_sampler *s, const orc_schedule *s
 }
 
 extern "C" void orc_set_var_id_offset(orc_sampler *s, uint64_t off) { s->vid_offset = off; }
+extern "C" void orc_set_sampling_weight_f32(orc_sampler *s, int on) { s->f32w = on != 0; }
 extern "C" int64_t *orc_grad(orc_sampler *s) { return s->GT.data(); }
 
 extern "C" void orc_sched_sample(orc_sampler *s, const orc_schedule *sch, uint64_t seed, uint64_t sweep) {

@@ -123,6 +123,9 @@ void orc_sched_apply(orc_sampler *s, double stepsize, double step_cap);
 int64_t *orc_grad(orc_sampler *s);
 /* global id of local variable 0: added to ids in the Philox counter (shards) */
 void orc_set_var_id_offset(orc_sampler *s, uint64_t off);
+/* device semantics: FactorGraph::potential multiplies with the weight rounded to f32
+ * (the device's L2-resident sampling copy); off in reference mode */
+void orc_set_sampling_weight_f32(orc_sampler *s, int on);
 /* returns 1 if every launch of the schedule is an independent set */
 int orc_sched_check_independent(orc_sampler *s, const orc_schedule *sch);
 /* two uniforms in [0,1) from Philox4x32-10 (test hook) */

@@ -58,6 +58,8 @@ constexpr double FIX_SCALE = 1073741824.0;  // 2^30: gradient fixed-point scale
 constexpr double LINEAR_ZERO_THRESHOLD = 0.000001;  // src/common.h:15
 
 constexpr uint32_t BLOCK_THREADS = 256;
+constexpr uint32_t STAGE_UNROLL = 12;                       // edge records staged per lane
+constexpr uint32_t MAX_ECAP = BLOCK_THREADS * STAGE_UNROLL;  // 3072 records = 48 KiB
 
 // Everything one sweep launch needs; passed by value.
 struct KernelParams {
@@ -76,7 +78,7 @@ struct KernelParams {
   uint32_t *assign_free;      // [V]
   uint32_t *assign_evid;      // [V]
   uint32_t *tally;            // [R]
-  const double *weights;      // [W]
+  const float *w32;           // [W] sampling copy of the weights, rounded to f32 (fits L2)
   const uint8_t *w_fixed;     // [W]
   long long *grad;            // [2W]: G then T (fixed point)
   // launch
@@ -88,6 +90,7 @@ struct KernelParams {
   uint32_t ecap, rcap;        // LDS capacities (edge records / value rows per tile)
   uint32_t lds_pot_off;       // byte offset of the potentials scratch in dynamic LDS
   uint32_t lds_edge_off;      // byte offset of the staged edge records
+  uint32_t lds_w_off;         // byte offset of the staged f32 weights (learning kernel)
 };
 
 }  // namespace dwx

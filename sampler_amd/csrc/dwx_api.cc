@@ -78,10 +78,12 @@ struct dwx_sampler {
   VifRec *d_vifs = nullptr;
   uint32_t *d_assign_free = nullptr, *d_assign_evid = nullptr, *d_tally = nullptr;
   double *d_weights = nullptr;
+  float *d_w32 = nullptr;
+  long long *d_t_static = nullptr;
   uint8_t *d_w_fixed = nullptr;
   long long *d_grad = nullptr;
   KernelParams base{};
-  size_t lds_bytes = 0;
+  size_t lds_bytes[2] = {0, 0};  // [0] inference kernel, [1] learning kernel
   uint64_t sweep = 0;
   uint64_t infer_sweeps = 0;  // inference sweeps since the last clear_tallies
   // kernel timing
@@ -95,7 +97,7 @@ struct dwx_sampler {
     rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
     rt::dfree(d_row_ptr); rt::dfree(d_tile_v); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
     rt::dfree(d_edges); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
-    rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w_fixed); rt::dfree(d_grad);
+    rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_t_static); rt::dfree(d_w_fixed); rt::dfree(d_grad);
     if (stream) rt::stream_destroy(stream);
   }
 };
@@ -115,10 +117,14 @@ void enqueue_sweep(dwx_sampler *s) {
   const size_t nl = c.launch_off.size() - 1;
   uint32_t launches = 0;
   for (size_t l = 0; l < nl; ++l) {
-    const uint32_t t0 = c.launch_tile[l], t1 = c.launch_tile[l + 1];
+    // an inference sweep only visits the query variables' tiles unless
+    // --sample_evidence (src/gibbs_sampler.h:157); a learning sweep visits all
+    const uint32_t t0 = c.launch_tile[l];
+    const uint32_t t1 = (LEARN || s->opts.sample_evidence) ? c.launch_tile[l + 1]
+                                                           : c.launch_query_tile_end[l];
     if (t1 == t0) continue;
     P.tile_begin = t0;
-    rt::launch(sweep_kernel<LEARN>, t1 - t0, BLOCK_THREADS, s->lds_bytes, s->stream, P);
+    rt::launch(sweep_kernel<LEARN>, t1 - t0, BLOCK_THREADS, s->lds_bytes[LEARN ? 1 : 0], s->stream, P);
     ++launches;
   }
   if (s->timing) {
@@ -184,6 +190,7 @@ int dwx_graph_get_info(const dwx_graph *g, dwx_graph_info *out) {
   out->num_colors = c.n_colors; out->num_launches = c.launch_off.size() - 1;
   out->num_tiles = c.tile_v.size() - 1; out->num_giant_tiles = c.n_giant_tiles;
   out->max_cardinality = c.max_card; out->device_bytes = c.device_bytes();
+  out->num_query_variables = c.n_query;
   out->has_categorical = c.has_categorical; out->order_is_identity = c.order_is_identity;
   return DWX_OK;
 }
@@ -247,6 +254,26 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     s->d_tally = (uint32_t *)rt::dmalloc(c.R * 4);
     rt::dmemset(s->d_tally, 0, c.R * 4, st);
     s->d_weights = upload(c.w_init, st);
+    {
+      std::vector<float> w32(c.W);
+      for (uint64_t i = 0; i < c.W; ++i) w32[i] = (float)c.w_init[i];
+      s->d_w32 = upload(w32, st);
+      // static per-sweep update counts: a boolean variable that triggers SGD visits
+      // every factor of its row once per learning sweep with t = 1
+      // (src/factor_graph.cc:265-273), independent of the samples drawn
+      std::vector<long long> ts(c.W, 0);
+      const long long one = (long long)FIX_SCALE;
+      for (uint64_t p = 0; p < c.V; ++p) {
+        const uint32_t m = c.v_meta[p];
+        if (m & VM_CATEGORICAL) continue;
+        const bool is_evid = m & VM_EVIDENCE;
+        const bool trig = opts->learn_non_evidence || (!opts->noise_aware && is_evid);
+        if (!trig) continue;
+        for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p] + 1]; ++e)
+          if (!c.w_fixed[c.edges[e].wid]) ts[c.edges[e].wid] += one;
+      }
+      s->d_t_static = upload(ts, st);
+    }
     s->d_w_fixed = upload(c.w_fixed, st);
     s->d_grad = (long long *)rt::dmalloc(c.W * 16);
     rt::dmemset(s->d_grad, 0, c.W * 16, st);
@@ -256,23 +283,28 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     P.row_ptr = s->d_row_ptr; P.row_truth = s->d_row_truth; P.edges = s->d_edges;
     P.edge_fval64 = s->d_edge_fval64; P.vifs = s->d_vifs; P.tile_v = s->d_tile_v;
     P.assign_free = s->d_assign_free; P.assign_evid = s->d_assign_evid; P.tally = s->d_tally;
-    P.weights = s->d_weights; P.w_fixed = s->d_w_fixed; P.grad = s->d_grad;
+    P.w32 = s->d_w32; P.w_fixed = s->d_w_fixed; P.grad = s->d_grad;
     P.seed = opts->seed; P.sweep = 0; P.vid_offset = opts->var_id_offset; P.tile_begin = 0; P.num_weights = (uint32_t)c.W;
     P.flags = (opts->sample_evidence ? OPT_SAMPLE_EVIDENCE : 0) |
               (opts->learn_non_evidence ? OPT_LEARN_NON_EVIDENCE : 0) |
               (opts->noise_aware ? OPT_NOISE_AWARE : 0) |
               (c.has_f64_fval ? OPT_HAS_F64_FVAL : 0) | (c.has_truthiness ? OPT_HAS_TRUTHINESS : 0);
     P.ecap = c.ecap; P.rcap = c.rcap;
-    // dynamic LDS layout: [row pointers | potentials scratch (categorical) | edge records]
+    // dynamic LDS layout: [row pointers | potentials scratch (categorical) | edge
+    // records | f32 weights (learning kernel only)]
+    if (c.ecap > MAX_ECAP) throw std::invalid_argument("tile_edges exceeds the staging capacity");
     size_t off = ((size_t)(c.rcap + 1) * 4 + 15) & ~(size_t)15;
     P.lds_pot_off = c.has_categorical ? (uint32_t)off : 0u;
     if (c.has_categorical) off += (size_t)c.rcap * 8;
     off = (off + 15) & ~(size_t)15;
     P.lds_edge_off = (uint32_t)off;
-    s->lds_bytes = off + (size_t)c.ecap * sizeof(EdgeRec);
-    if (s->lds_bytes > 160 * 1024) throw std::invalid_argument("tile does not fit the 160 KiB LDS");
-    rt::allow_dynamic_lds(sweep_kernel<false>, s->lds_bytes);
-    rt::allow_dynamic_lds(sweep_kernel<true>, s->lds_bytes);
+    off += (size_t)c.ecap * sizeof(EdgeRec);
+    P.lds_w_off = (uint32_t)off;
+    s->lds_bytes[0] = off;
+    s->lds_bytes[1] = off + (size_t)c.ecap * 4;
+    if (s->lds_bytes[1] > 160 * 1024) throw std::invalid_argument("tile does not fit the 160 KiB LDS");
+    rt::allow_dynamic_lds(sweep_kernel<false>, s->lds_bytes[0]);
+    rt::allow_dynamic_lds(sweep_kernel<true>, s->lds_bytes[1]);
     rt::stream_sync(st);
   });
   if (rc != DWX_OK) return rc;
@@ -311,9 +343,9 @@ int dwx_sgd_apply_async(dwx_sampler *s, double stepsize) {
     const uint32_t W = (uint32_t)s->cg->W;
     if (!W) return;
     const unsigned grid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 2048u);
-    rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights,
-               (const uint8_t *)s->d_w_fixed, s->d_grad, W, stepsize, s->opts.step_cap,
-               s->opts.reg_param, (int)(s->opts.regularization == 1));
+    rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
+               (const uint8_t *)s->d_w_fixed, s->d_grad, (const long long *)s->d_t_static, W,
+               stepsize, s->opts.step_cap, s->opts.reg_param, (int)(s->opts.regularization == 1));
   });
 }
 
@@ -344,7 +376,13 @@ int dwx_set_weights(dwx_sampler *s, const double *in) {
   if (!s || !in) return fail(DWX_E_INVALID, "null argument");
   return guarded([&]() {
     rt::set_device(s->device);
-    rt::h2d(s->d_weights, in, s->cg->W * 8, s->stream);
+    const uint32_t W = (uint32_t)s->cg->W;
+    rt::h2d(s->d_weights, in, (size_t)W * 8, s->stream);
+    if (W) {
+      const unsigned grid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 2048u);
+      rt::launch(refresh_w32_kernel, grid, BLOCK_THREADS, 0, s->stream,
+                 (const double *)s->d_weights, s->d_w32, W);
+    }
     rt::stream_sync(s->stream);
   });
 }
@@ -423,6 +461,7 @@ int dwx_device_buffer(dwx_sampler *s, int which, void **dev_ptr, uint64_t *nbyte
     case DWX_BUF_ASSIGN_FREE: *dev_ptr = s->d_assign_free; *nbytes = c.V * 4; break;
     case DWX_BUF_ASSIGN_EVID: *dev_ptr = s->d_assign_evid; *nbytes = c.V * 4; break;
     case DWX_BUF_TALLIES: *dev_ptr = s->d_tally; *nbytes = c.R * 4; break;
+    case DWX_BUF_TSTATIC: *dev_ptr = s->d_t_static; *nbytes = c.W * 8; break;
     default: return fail(DWX_E_INVALID, "unknown buffer id");
   }
   return DWX_OK;

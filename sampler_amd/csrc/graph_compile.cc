@@ -70,7 +70,7 @@ uint64_t CompiledGraph::device_bytes() const {
   b += 16 * NIdx + (edge_fval64.empty() ? 0 : 8 * NIdx) + 8 * NVif;
   b += 4 * tile_v.size();
   b += 4 * V * 2 + 4 * R;                     // assignments x2, tallies
-  b += W * (8 + 1 + 16);                      // weights, fixed, grad G/T
+  b += W * (8 + 4 + 1 + 16 + 8);              // weights f64 + f32 copy, fixed, grad G/T, T static
   return b;
 }
 
@@ -294,23 +294,29 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       g.n_colors = V ? ncol : 0;
     }
 
-    // ---- device order: colour-major, booleans before categoricals, then id ----
-    const uint32_t nkeys = std::max(1u, g.n_colors) * 2;
+    // ---- device order: colour-major; inside a colour query variables before evidence
+    //      variables (an inference sweep launches over the query part only, like the
+    //      reference skips evidence, src/gibbs_sampler.h:157), booleans before
+    //      categoricals, then id ----
+    const uint32_t nkeys = std::max(1u, g.n_colors) * 4;
+    auto key_of = [&](uint64_t v) { return color[v] * 4 + (g.var_is_evid[v] ? 2u : 0u) + is_cat[v]; };
     std::vector<uint64_t> key_start(nkeys + 1, 0);
-    for (uint64_t v = 0; v < V; ++v) ++key_start[color[v] * 2 + is_cat[v] + 1];
+    for (uint64_t v = 0; v < V; ++v) ++key_start[key_of(v) + 1];
     for (uint32_t k = 0; k < nkeys; ++k) key_start[k + 1] += key_start[k];
     g.perm.resize(V); g.pos.resize(V);
     {
       std::vector<uint64_t> cur(key_start.begin(), key_start.end() - 1);
       for (uint64_t v = 0; v < V; ++v) {
-        uint64_t p = cur[color[v] * 2 + is_cat[v]]++;
+        uint64_t p = cur[key_of(v)]++;
         g.perm[p] = (uint32_t)v; g.pos[v] = (uint32_t)p;
         if (p != v) g.order_is_identity = false;
       }
     }
     g.launch_off.clear();
-    for (uint32_t c = 0; c < g.n_colors; ++c) g.launch_off.push_back(key_start[2 * c]);
+    for (uint32_t c = 0; c < g.n_colors; ++c) g.launch_off.push_back(key_start[4 * c]);
     g.launch_off.push_back(V);
+    g.n_query = 0;
+    for (uint64_t v = 0; v < V; ++v) g.n_query += !g.var_is_evid[v];
     if (g.n_colors == 0) g.launch_off.assign(1, 0);
 
     // ---- device rows ----
@@ -393,19 +399,25 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
 
     // ---- workgroup tiles: <= tile_vars variables of one type whose value rows and
     //      edge records fit the LDS budget; an oversized variable gets a tile alone ----
-    g.ecap = o.tile_edges ? o.tile_edges : 3072;
+    g.ecap = o.tile_edges ? std::min(o.tile_edges, MAX_ECAP) : MAX_ECAP;
     g.rcap = o.tile_rows ? o.tile_rows : (g.has_categorical ? 2048 : g.tile_vars);
     if (g.rcap < g.tile_vars && !g.has_categorical) g.rcap = g.tile_vars;
-    g.tile_v.clear(); g.launch_tile.clear();
+    g.tile_v.clear(); g.launch_tile.clear(); g.launch_query_tile_end.clear();
     const uint64_t nl = g.launch_off.size() - 1;
+    const uint32_t kTypeMask = VM_CATEGORICAL | VM_EVIDENCE;
     for (uint64_t l = 0; l < nl; ++l) {
       g.launch_tile.push_back((uint32_t)g.tile_v.size());
       uint64_t p = g.launch_off[l], pend = g.launch_off[l + 1];
+      bool seen_evid = false;
       while (p < pend) {
         uint64_t t0 = p;
-        uint32_t cat = g.v_meta[p] & VM_CATEGORICAL;
+        uint32_t type = g.v_meta[p] & kTypeMask;
+        if ((type & VM_EVIDENCE) && !seen_evid) {
+          seen_evid = true;
+          g.launch_query_tile_end.push_back((uint32_t)g.tile_v.size());
+        }
         uint64_t rows = 0, edges = 0;
-        while (p < pend && p - t0 < g.tile_vars && (g.v_meta[p] & VM_CATEGORICAL) == cat) {
+        while (p < pend && p - t0 < g.tile_vars && (g.v_meta[p] & kTypeMask) == type) {
           uint64_t nr = g.v_row[p + 1] - g.v_row[p];
           uint64_t ne = g.row_ptr[g.v_row[p + 1]] - g.row_ptr[g.v_row[p]];
           if (p > t0 && (rows + nr > g.rcap || edges + ne > g.ecap)) break;
@@ -415,6 +427,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
         if (rows > g.rcap || edges > g.ecap) ++g.n_giant_tiles;
         g.tile_v.push_back((uint32_t)t0);
       }
+      if (!seen_evid) g.launch_query_tile_end.push_back((uint32_t)g.tile_v.size());
     }
     g.launch_tile.push_back((uint32_t)g.tile_v.size());
     g.tile_v.push_back((uint32_t)V);

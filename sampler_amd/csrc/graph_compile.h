@@ -24,6 +24,7 @@ struct CompiledGraph {
   uint64_t R = 0;      // value rows (== num_values)
   uint64_t NIdx = 0;   // edge records (== |factor_index| after dedup)
   uint64_t NVif = 0;   // vif entries of factors with arity >= 2
+  uint64_t n_query = 0; // non-evidence variables
   uint32_t n_colors = 0, n_giant_tiles = 0, max_card = 2;
   bool has_categorical = false, has_truthiness = false, has_f64_fval = false;
   bool order_is_identity = true;
@@ -49,6 +50,7 @@ struct CompiledGraph {
   std::vector<VifRec> vifs;        // [NVif]
   std::vector<uint32_t> tile_v;       // [n_tiles+1]
   std::vector<uint32_t> launch_tile;  // [n_launches+1] into tile_v
+  std::vector<uint32_t> launch_query_tile_end;  // [n_launches] end of the query-variable tiles
   std::vector<uint64_t> launch_off;   // [n_launches+1] variable positions
   std::vector<uint8_t> var_is_evid;   // [V] original order (for nsamples)
 

@@ -10,6 +10,10 @@
 // of one launch form an independent set, so a launch is exactly a sequential Gibbs
 // scan of those variables.  This path is gather/stream bound: no MFMA.
 //
+// Precision: potentials, the logistic / log-sum-exp draw and the SGD update are f64
+// like the reference; the weight each factor is multiplied with is the f64 master
+// weight rounded to f32 (the sampling copy: 4 MB for 1M weights, L2-resident).
+//
 // Reference functions restated here (paths relative to /root/reference):
 //   sample_single_variable      src/gibbs_sampler.h:151-169
 //   sample_sgd_single_variable  src/gibbs_sampler.h:127-149
@@ -141,13 +145,22 @@ DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const Vi
 }
 
 // ---------------------------------------------------------------- tile view
-// Where a lane reads its row pointers / edge records / potential scratch from:
-// the LDS-staged tile (normal) or HBM directly (a variable too big for one tile).
+// Where a lane reads its row pointers / edge records / weights / potential scratch
+// from: the LDS-staged tile (normal) or HBM directly (a variable too big for a tile).
+// WMODE says where the weight of an edge record lives:
+//   W_GLOBAL   gather w32[rec.wid] from memory (oversized variables only)
+//   W_ARRAY    staged f32 array parallel to the staged records (learning kernel:
+//              the records keep their weight id for the gradient scatter)
+//   W_INRECORD the staging pass overwrote rec.wid with the f32 weight bits
+//              (inference kernel: no extra LDS)
+enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2 };
+
 struct TileView {
   const uint32_t *rowptr;  // indexed by (row - row_bias)
   uint32_t row_bias;
   const EdgeRec *edges;    // indexed by (edge - edge_bias)
   uint32_t edge_bias;
+  const float *w;          // W_ARRAY: staged weights, indexed like edges
   double *pot;             // per-row potential scratch (row - row_bias), or null
 };
 
@@ -156,16 +169,26 @@ DWX_DEV uint32_t edge_arity(const EdgeRec &e) { return e.packed >> EDGE_ARITY_SH
 DWX_DEV double edge_fval(const KernelParams &P, const EdgeRec &e, uint32_t idx) {
   return (e.packed & EDGE_F64_FLAG) ? P.edge_fval64[idx] : (double)e.fval;
 }
+DWX_DEV float bits_to_float(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+DWX_DEV uint32_t float_to_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+
+template <int WMODE>
+DWX_DEV double edge_weight(const KernelParams &P, const TileView &T, const EdgeRec &er, uint32_t e) {
+  if (WMODE == W_INRECORD) return (double)bits_to_float(er.wid);
+  if (WMODE == W_ARRAY) return (double)T.w[e - T.edge_bias];
+  return (double)P.w32[er.wid];
+}
 
 // FactorGraph::potential for one value row (src/factor_graph.h:127-145):
 // pot = sum_i weight[wid_i] * (sign_i * feature_value_i), in row order.
+template <int WMODE>
 DWX_DEV double row_potential(const KernelParams &P, const TileView &T, uint32_t row,
                              const uint32_t *assign, uint32_t me, uint32_t proposal) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   double pot = 0.0;
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
-    const double w = P.weights[er.wid];
+    const double w = edge_weight<WMODE>(P, T, er, e);
     const double s = factor_sign(edge_func(er), edge_arity(er), er.aux, P.vifs, assign, me, proposal);
     pot += w * (s * edge_fval(P, er, e));
   }
@@ -174,13 +197,14 @@ DWX_DEV double row_potential(const KernelParams &P, const TileView &T, uint32_t 
 
 // boolean variable: both proposals in one pass over the row (same sums, same order
 // as two calls of FactorGraph::potential, src/gibbs_sampler.h:201-202)
+template <int WMODE>
 DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t row,
                              const uint32_t *assign, uint32_t me, double &pp, double &pn) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   pp = 0.0; pn = 0.0;
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
-    const double w = P.weights[er.wid];
+    const double w = edge_weight<WMODE>(P, T, er, e);
     const double fv = edge_fval(P, er, e);
     const uint32_t fn = edge_func(er), ar = edge_arity(er);
     const double s1 = factor_sign(fn, ar, er.aux, P.vifs, assign, me, 1u);
@@ -196,17 +220,18 @@ DWX_DEV uint32_t bool_draw(double r, double pp, double pn) {
 }
 
 // categorical draw, src/gibbs_sampler.h:217-246 (inverse CDF with ONE uniform)
+template <int WMODE>
 DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row0, uint32_t card,
                           const uint32_t *assign, uint32_t me, double r) {
   double sum = -100000.0;
   for (uint32_t d = 0; d < card; ++d) {
-    const double pot = row_potential(P, T, row0 + d, assign, me, d);
+    const double pot = row_potential<WMODE>(P, T, row0 + d, assign, me, d);
     if (T.pot) T.pot[row0 + d - T.row_bias] = pot;
     sum = logadd(sum, pot);
   }
   for (uint32_t d = 0; d < card; ++d) {
     const double pot = T.pot ? T.pot[row0 + d - T.row_bias]
-                             : row_potential(P, T, row0 + d, assign, me, d);
+                             : row_potential<WMODE>(P, T, row0 + d, assign, me, d);
     r -= exp(pot - sum);
     if (r <= 0) return d;
   }
@@ -214,7 +239,10 @@ DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row
 }
 
 // sgd_on_factor (src/factor_graph.cc:243-260), gradient accumulated in fixed point:
-// G[wid] += round(2^30 * t * (pot_free - pot_evid)),  T[wid] += round(2^30 * t)
+// G[wid] += round(2^30 * t * (pot_free - pot_evid)),  T[wid] += round(2^30 * t).
+// COUNT_T = false for boolean variables: their update counts are static and were
+// folded into T_static on the host (dwx_sampler_create).
+template <bool COUNT_T>
 DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uint32_t me,
                      uint32_t evid_value, uint32_t free_value, double t) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
@@ -227,14 +255,16 @@ DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uin
     const double pot_free = factor_sign(fn, ar, er.aux, P.vifs, P.assign_free, me, free_value) * fv;
     const double g = pot_free - pot_evid;
     const long long gi = llrint(FIX_SCALE * (t * g));
-    const long long ti = llrint(FIX_SCALE * t);
     if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
-    atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)ti);
+    if (COUNT_T) {
+      const long long ti = llrint(FIX_SCALE * t);
+      atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)ti);
+    }
   }
 }
 
 // ---------------------------------------------------------------- one variable
-template <bool LEARN>
+template <bool LEARN, int WMODE>
 DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t p) {
   const uint32_t meta = P.v_meta[p];
   const bool is_cat = meta & VM_CATEGORICAL;
@@ -249,11 +279,11 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
     uint32_t prop;
     if (!is_cat) {
       double pp, pn;
-      bool_potentials(P, T, row0, P.assign_evid, p, pp, pn);
+      bool_potentials<WMODE>(P, T, row0, P.assign_evid, p, pp, pn);
       prop = bool_draw(A, pp, pn);
       if (prop) P.tally[row0] += 1;
     } else {
-      prop = cat_draw(P, T, row0, card, P.assign_evid, p, A);
+      prop = cat_draw<WMODE>(P, T, row0, card, P.assign_evid, p, A);
       P.tally[row0 + prop] += 1;
     }
     P.assign_evid[p] = prop;
@@ -268,10 +298,10 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
   uint32_t p_free;
   if (!is_cat) {
     double pp, pn;
-    bool_potentials(P, T, row0, P.assign_free, p, pp, pn);
+    bool_potentials<WMODE>(P, T, row0, P.assign_free, p, pp, pn);
     p_free = bool_draw(A, pp, pn);
   } else {
-    p_free = cat_draw(P, T, row0, card, P.assign_free, p, A);
+    p_free = cat_draw<WMODE>(P, T, row0, card, P.assign_free, p, A);
   }
   P.assign_free[p] = p_free;
   // evidence chain: sample_evid (src/gibbs_sampler.h:171-190)
@@ -288,10 +318,10 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
     }
   } else if (!is_cat) {
     double pp, pn;
-    bool_potentials(P, T, row0, P.assign_evid, p, pp, pn);
+    bool_potentials<WMODE>(P, T, row0, P.assign_evid, p, pp, pn);
     p_evid = bool_draw(B, pp, pn);
   } else {
-    p_evid = cat_draw(P, T, row0, card, P.assign_evid, p, B);
+    p_evid = cat_draw<WMODE>(P, T, row0, card, P.assign_evid, p, B);
   }
   P.assign_evid[p] = p_evid;
   // src/gibbs_sampler.h:144-146
@@ -300,7 +330,7 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
     return;
   // sgd_on_variable (src/factor_graph.cc:262-314)
   if (!is_cat) {
-    sgd_row(P, T, row0, p, evid_value, p_free, 1.0);
+    sgd_row<false>(P, T, row0, p, evid_value, p_free, 1.0);
     return;
   }
   for (uint32_t val = 0; val < card; ++val) {
@@ -310,15 +340,28 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
       t = P.row_truth ? P.row_truth[row0 + val] : 0.0;
       if (is_linear_zero(t)) continue;
     }
-    sgd_row(P, T, row0 + val, p, val, p_free, t);
+    sgd_row<true>(P, T, row0 + val, p, val, p_free, t);
     if (val == p_free) continue;
-    sgd_row(P, T, row0 + p_free, p, val, p_free, t);
+    sgd_row<true>(P, T, row0 + p_free, p, val, p_free, t);
   }
 }
 
 // ---------------------------------------------------------------- kernels
 #ifndef DWX_DYN_LDS
 #define DWX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
+// The edge-record stream is read exactly once per sweep: load it non-temporally so it
+// does not evict the (re-used) f32 weight table from the XCD's L2.
+#ifndef DWX_STREAM_LOAD_EDGE
+typedef uint32_t dwx_u32x4 __attribute__((ext_vector_type(4)));
+DWX_DEV EdgeRec stream_load_edge(const EdgeRec *p) {
+  dwx_u32x4 v = __builtin_nontemporal_load((const dwx_u32x4 *)p);
+  EdgeRec r;
+  r.wid = v.x; r.aux = v.y; r.packed = v.z; r.fval = bits_to_float(v.w);
+  return r;
+}
+#define DWX_STREAM_LOAD_EDGE(p) stream_load_edge(p)
 #endif
 
 template <bool LEARN>
@@ -330,37 +373,64 @@ __global__ void __launch_bounds__(BLOCK_THREADS) sweep_kernel(const KernelParams
   const uint32_t e0 = P.row_ptr[r0], e1 = P.row_ptr[r1];
   const uint32_t nrows = r1 - r0, nedges = e1 - e0;
   const uint32_t t = threadIdx.x;
+  constexpr int WMODE = LEARN ? W_ARRAY : W_INRECORD;
   // workgroup-uniform: does the tile fit the LDS budget? (the compiler only builds
   // an oversized tile around a single variable)
   if (nrows <= P.rcap && nedges <= P.ecap) {
     uint32_t *s_rowptr = (uint32_t *)dyn_lds;
     double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
     EdgeRec *s_edges = (EdgeRec *)(dyn_lds + P.lds_edge_off);
+    float *s_w = (float *)(dyn_lds + P.lds_w_off);
     for (uint32_t i = t; i <= nrows; i += BLOCK_THREADS) s_rowptr[i] = P.row_ptr[r0 + i];
-    // 16 B per lane, consecutive lanes -> consecutive records: one coalesced stream
-    for (uint32_t i = t; i < nedges; i += BLOCK_THREADS) s_edges[i] = P.edges[e0 + i];
+    // Staging: lane t takes records t, t+256, ...  (16 B per lane, consecutive lanes ->
+    // consecutive records: one coalesced non-temporal stream), then gathers the f32
+    // weight of every record it holds -- all STAGE_UNROLL gathers of a lane are
+    // independent and in flight together -- and only then writes LDS.
+    EdgeRec rec[STAGE_UNROLL];
+    float w[STAGE_UNROLL];
+#pragma unroll
+    for (uint32_t k = 0; k < STAGE_UNROLL; ++k) {
+      const uint32_t i = t + k * BLOCK_THREADS;
+      if (i < nedges) rec[k] = DWX_STREAM_LOAD_EDGE(&P.edges[e0 + i]);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < STAGE_UNROLL; ++k) {
+      const uint32_t i = t + k * BLOCK_THREADS;
+      if (i < nedges) w[k] = P.w32[rec[k].wid];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < STAGE_UNROLL; ++k) {
+      const uint32_t i = t + k * BLOCK_THREADS;
+      if (i < nedges) {
+        if (LEARN) { s_w[i] = w[k]; } else { rec[k].wid = float_to_bits(w[k]); }
+        s_edges[i] = rec[k];
+      }
+    }
     __syncthreads();
     if (t < v1 - v0) {
-      TileView T{s_rowptr, r0, s_edges, e0, P.lds_pot_off ? s_pot : nullptr};
-      process_variable<LEARN>(P, T, v0 + t);
+      TileView T{s_rowptr, r0, s_edges, e0, s_w, P.lds_pot_off ? s_pot : nullptr};
+      process_variable<LEARN, WMODE>(P, T, v0 + t);
     }
   } else if (t == 0) {
-    TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr};
-    for (uint32_t p = v0; p < v1; ++p) process_variable<LEARN>(P, T, p);
+    TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr};
+    for (uint32_t p = v0; p < v1; ++p) process_variable<LEARN, W_GLOBAL>(P, T, p);
   }
 }
 
 // Batched InferenceResult::update_weight (src/inference_result.h:66-85): apply one
 // sweep's accumulated gradient to every non-fixed weight that received updates,
-// then clear the accumulators.
+// then clear the accumulators.  T = dynamic counts (categorical variables, atomics)
+// + static counts (boolean variables, precomputed).  Also refreshes the f32 sampling
+// copy of each weight it changes.
 __global__ void __launch_bounds__(BLOCK_THREADS)
-apply_kernel(double *weights, const uint8_t *w_fixed, long long *grad, uint32_t W, double stepsize,
-             double step_cap, double reg_param, int l2) {
+apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *grad,
+             const long long *t_static, uint32_t W, double stepsize, double step_cap,
+             double reg_param, int l2) {
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride) {
-    const long long G = grad[i], Tn = grad[W + i];
-    if (G == 0 && Tn == 0) continue;
-    grad[i] = 0; grad[W + i] = 0;
+    const long long G = grad[i], Td = grad[W + i];
+    if (G != 0 || Td != 0) { grad[i] = 0; grad[W + i] = 0; }
+    const long long Tn = Td + t_static[i];
     if (w_fixed[i] || Tn == 0) continue;
     const double Tt = (double)Tn / FIX_SCALE, Gg = (double)G / FIX_SCALE;
     double eta = stepsize;
@@ -370,7 +440,16 @@ apply_kernel(double *weights, const uint8_t *w_fixed, long long *grad, uint32_t 
     else x += reg_param * Tt * (x < 0 ? 1.0 : 0.0);
     x -= eta * Gg;
     weights[i] = x;
+    w32[i] = (float)x;
   }
+}
+
+// f64 master weights -> f32 sampling copy (after dwx_set_weights)
+__global__ void __launch_bounds__(BLOCK_THREADS)
+refresh_w32_kernel(const double *weights, float *w32, uint32_t W) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride)
+    w32[i] = (float)weights[i];
 }
 
 // test hook: one factor function evaluated on the device (test/factor_test.cc)

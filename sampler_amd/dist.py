@@ -40,7 +40,15 @@ class HipEngine:
         dev = torch.device("cuda", sampler.opts.device)
         self._holder = _CudaArray(ptr, nbytes, "<i8", 8)
         self.grad = torch.as_tensor(self._holder, device=dev)
+        tp, tn = sampler.device_buffer(dwx.BUF_TSTATIC)
+        self._tholder = _CudaArray(tp, tn, "<i8", 8)
+        self.t_static = torch.as_tensor(self._tholder, device=dev)
         self.stream = torch.cuda.ExternalStream(sampler.stream(), device=dev)
+
+    def allreduce_static_counts(self, group=None):
+        """Once after create: every rank only counted its own shard's boolean updates."""
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(self.t_static, op=dist.ReduceOp.SUM, group=group)
 
     def sgd_accumulate(self):
         self.s.sgd_accumulate()
@@ -72,6 +80,8 @@ class ShardedDimmWitted:
         self.decay = decay
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if self.distributed:
+            self.e.allreduce_static_counts(group)
 
     def learn_epoch(self, stepsize):
         self.e.sgd_accumulate()

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libdwx.so")
 
 DWX_OK, DWX_E_INVALID, DWX_E_LIMIT, DWX_E_DEVICE, DWX_E_NOMEM = 0, -1, -2, -3, -4
-BUF_WEIGHTS, BUF_GRAD, BUF_ASSIGN_FREE, BUF_ASSIGN_EVID, BUF_TALLIES = range(5)
+BUF_WEIGHTS, BUF_GRAD, BUF_ASSIGN_FREE, BUF_ASSIGN_EVID, BUF_TALLIES, BUF_TSTATIC = range(6)
 
 # every symbol include/dwx.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -48,7 +48,7 @@ class GraphInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "num_variables", "num_factors", "num_edges", "num_weights", "num_values",
         "num_index_entries", "num_vif_entries", "num_colors", "num_launches", "num_tiles",
-        "num_giant_tiles", "max_cardinality", "device_bytes")] + [
+        "num_giant_tiles", "max_cardinality", "num_query_variables", "device_bytes")] + [
         ("has_categorical", C.c_uint32), ("order_is_identity", C.c_uint32)]
 
 
