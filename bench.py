@@ -84,6 +84,8 @@ def main():
                     help="override the per-GPU variable count (default 10M at 1 GPU, 12.5M else)")
     ap.add_argument("--cpu-sample-vars", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile-vars", type=int, default=0, help="graph-compile knob (experiments)")
+    ap.add_argument("--tile-edges", type=int, default=0, help="graph-compile knob (experiments)")
     args = ap.parse_args()
 
     import torch
@@ -110,7 +112,7 @@ def main():
     stepsize, decay, reg = 0.001, 0.95, 0.01       # SURVEY.md §8(d) config-3 run flags
     t0 = time.time()
     raw = synthetic.cfg3(V, n_weights=W, seed=1234, shard=rank)
-    graph = dwx.Graph(raw)
+    graph = dwx.Graph(raw, tile_vars=args.tile_vars, tile_edges=args.tile_edges)
     sampler = dwx.GibbsSampler(graph, device=local_rank, reg_param=reg, seed=20260103,
                                var_id_offset=rank * V)
     if rank == 0:

@@ -40,6 +40,17 @@ struct alignas(8) VifRec {
   uint32_t equal_to;  // dense predicate value
 };
 
+// One workgroup tile: a run of consecutive variables (device order) of one colour and
+// one type whose value rows and edge records fit the LDS budget -- or ONE oversized
+// variable (rows > rcap or edges > ecap), processed straight from HBM.
+struct alignas(16) TileDesc {
+  uint32_t v0, nv;      // variables [v0, v0 + nv)
+  uint32_t r0, nrows;   // value rows [r0, r0 + nrows)
+  uint32_t e0, nedges;  // edge records [e0, e0 + nedges)
+  uint32_t pad0, pad1;
+};
+static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
+
 // v_meta bits
 constexpr uint32_t VM_CATEGORICAL = 1u << 0;
 constexpr uint32_t VM_EVIDENCE = 1u << 1;
@@ -60,6 +71,7 @@ constexpr double LINEAR_ZERO_THRESHOLD = 0.000001;  // src/common.h:15
 constexpr uint32_t BLOCK_THREADS = 256;
 constexpr uint32_t STAGE_UNROLL = 12;                       // edge records staged per lane
 constexpr uint32_t MAX_ECAP = BLOCK_THREADS * STAGE_UNROLL;  // 3072 records = 48 KiB
+constexpr uint32_t ROWPTR_UNROLL = 2;                       // row pointers prefetched per lane
 
 // Everything one sweep launch needs; passed by value.
 struct KernelParams {
@@ -73,7 +85,7 @@ struct KernelParams {
   const EdgeRec *edges;       // [NIdx]
   const double *edge_fval64;  // [NIdx] or null
   const VifRec *vifs;         // [NVif]
-  const uint32_t *tile_v;     // [n_tiles+1] variable positions
+  const TileDesc *tiles;      // [n_tiles]
   // state
   uint32_t *assign_free;      // [V]
   uint32_t *assign_evid;      // [V]
@@ -85,6 +97,7 @@ struct KernelParams {
   uint64_t seed, sweep;
   uint64_t vid_offset;        // global id of local variable 0 (Philox counter)
   uint32_t tile_begin;        // first tile of this launch
+  uint32_t tile_end;          // one past the last tile of this launch
   uint32_t num_weights;
   uint32_t flags;
   uint32_t ecap, rcap;        // LDS capacities (edge records / value rows per tile)

@@ -72,7 +72,9 @@ struct dwx_sampler {
   rt::stream_t stream = nullptr;
   // device buffers
   uint32_t *d_v_meta = nullptr, *d_v_orig = nullptr, *d_v_row = nullptr, *d_v_init = nullptr;
-  uint32_t *d_row_ptr = nullptr, *d_tile_v = nullptr;
+  uint32_t *d_row_ptr = nullptr;
+  TileDesc *d_tiles = nullptr;
+  unsigned persistent_blocks[2] = {1, 1};
   double *d_row_truth = nullptr, *d_edge_fval64 = nullptr;
   EdgeRec *d_edges = nullptr;
   VifRec *d_vifs = nullptr;
@@ -95,7 +97,7 @@ struct dwx_sampler {
   ~dwx_sampler() {
     for (auto &sp : spans) { rt::event_destroy(sp.a); rt::event_destroy(sp.b); }
     rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
-    rt::dfree(d_row_ptr); rt::dfree(d_tile_v); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
+    rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
     rt::dfree(d_edges); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
     rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_t_static); rt::dfree(d_w_fixed); rt::dfree(d_grad);
     if (stream) rt::stream_destroy(stream);
@@ -124,7 +126,10 @@ void enqueue_sweep(dwx_sampler *s) {
                                                            : c.launch_query_tile_end[l];
     if (t1 == t0) continue;
     P.tile_begin = t0;
-    rt::launch(sweep_kernel<LEARN>, t1 - t0, BLOCK_THREADS, s->lds_bytes[LEARN ? 1 : 0], s->stream, P);
+    P.tile_end = t1;
+    // persistent grid: as many workgroups as stay resident, each striding over tiles
+    const unsigned grid = std::min<unsigned>(t1 - t0, s->persistent_blocks[LEARN ? 1 : 0]);
+    rt::launch(sweep_kernel<LEARN>, grid, BLOCK_THREADS, s->lds_bytes[LEARN ? 1 : 0], s->stream, P);
     ++launches;
   }
   if (s->timing) {
@@ -240,7 +245,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     s->d_v_row = upload(c.v_row, st);
     s->d_v_init = upload(c.v_init, st);
     s->d_row_ptr = upload(c.row_ptr, st);
-    s->d_tile_v = upload(c.tile_v, st);
+    s->d_tiles = upload(c.tiles, st);
     if (!c.row_truth.empty()) s->d_row_truth = upload(c.row_truth, st);
     if (!c.edge_fval64.empty()) s->d_edge_fval64 = upload(c.edge_fval64, st);
     s->d_edges = upload(c.edges, st);
@@ -281,7 +286,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     KernelParams &P = s->base;
     P.v_meta = s->d_v_meta; P.v_orig = s->d_v_orig; P.v_row = s->d_v_row; P.v_init = s->d_v_init;
     P.row_ptr = s->d_row_ptr; P.row_truth = s->d_row_truth; P.edges = s->d_edges;
-    P.edge_fval64 = s->d_edge_fval64; P.vifs = s->d_vifs; P.tile_v = s->d_tile_v;
+    P.edge_fval64 = s->d_edge_fval64; P.vifs = s->d_vifs; P.tiles = s->d_tiles;
     P.assign_free = s->d_assign_free; P.assign_evid = s->d_assign_evid; P.tally = s->d_tally;
     P.w32 = s->d_w32; P.w_fixed = s->d_w_fixed; P.grad = s->d_grad;
     P.seed = opts->seed; P.sweep = 0; P.vid_offset = opts->var_id_offset; P.tile_begin = 0; P.num_weights = (uint32_t)c.W;
@@ -305,6 +310,8 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     if (s->lds_bytes[1] > 160 * 1024) throw std::invalid_argument("tile does not fit the 160 KiB LDS");
     rt::allow_dynamic_lds(sweep_kernel<false>, s->lds_bytes[0]);
     rt::allow_dynamic_lds(sweep_kernel<true>, s->lds_bytes[1]);
+    s->persistent_blocks[0] = rt::resident_blocks(sweep_kernel<false>, BLOCK_THREADS, s->lds_bytes[0]);
+    s->persistent_blocks[1] = rt::resident_blocks(sweep_kernel<true>, BLOCK_THREADS, s->lds_bytes[1]);
     rt::stream_sync(st);
   });
   if (rc != DWX_OK) return rc;

@@ -68,7 +68,7 @@ uint64_t CompiledGraph::device_bytes() const {
   b += 4 * (V * 4 + 1);                       // v_meta, v_orig, v_init, v_row
   b += 4 * (R + 1) + (row_truth.empty() ? 0 : 8 * R);
   b += 16 * NIdx + (edge_fval64.empty() ? 0 : 8 * NIdx) + 8 * NVif;
-  b += 4 * tile_v.size();
+  b += 32 * tiles.size();
   b += 4 * V * 2 + 4 * R;                     // assignments x2, tallies
   b += W * (8 + 4 + 1 + 16 + 8);              // weights f64 + f32 copy, fixed, grad G/T, T static
   return b;
@@ -431,6 +431,15 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     }
     g.launch_tile.push_back((uint32_t)g.tile_v.size());
     g.tile_v.push_back((uint32_t)V);
+    g.tiles.resize(g.tile_v.size() - 1);
+    for (size_t i = 0; i + 1 < g.tile_v.size(); ++i) {
+      const uint32_t v0 = g.tile_v[i], v1 = g.tile_v[i + 1];
+      TileDesc t{};
+      t.v0 = v0; t.nv = v1 - v0;
+      t.r0 = g.v_row[v0]; t.nrows = g.v_row[v1] - g.v_row[v0];
+      t.e0 = g.row_ptr[g.v_row[v0]]; t.nedges = g.row_ptr[g.v_row[v1]] - g.row_ptr[g.v_row[v0]];
+      g.tiles[i] = t;
+    }
 
     g.w_init.assign(d.w_initial_value, d.w_initial_value + W);
     g.w_fixed.assign(d.w_is_fixed, d.w_is_fixed + W);

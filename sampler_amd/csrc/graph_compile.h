@@ -49,6 +49,7 @@ struct CompiledGraph {
   std::vector<double> edge_fval64; // [NIdx] or empty
   std::vector<VifRec> vifs;        // [NVif]
   std::vector<uint32_t> tile_v;       // [n_tiles+1]
+  std::vector<TileDesc> tiles;        // [n_tiles]
   std::vector<uint32_t> launch_tile;  // [n_launches+1] into tile_v
   std::vector<uint32_t> launch_query_tile_end;  // [n_launches] end of the query-variable tiles
   std::vector<uint64_t> launch_off;   // [n_launches+1] variable positions

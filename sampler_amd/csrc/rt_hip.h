@@ -74,6 +74,17 @@ inline void allow_dynamic_lds(K kernel, size_t bytes) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
+// workgroups of this kernel that are resident on the whole chip at once
+template <class K>
+inline unsigned resident_blocks(K kernel, unsigned block, size_t lds) {
+  int dev = 0, cus = 0, per_cu = 0;
+  DWX_HIP(hipGetDevice(&dev));
+  DWX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  DWX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block, lds));
+  if (per_cu < 1) per_cu = 1;
+  return (unsigned)(cus * per_cu);
+}
+
 template <class K, class... A>
 inline void launch(K kernel, unsigned grid, unsigned block, size_t lds, stream_t s, A... args) {
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, args...);

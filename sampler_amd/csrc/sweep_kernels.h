@@ -264,27 +264,43 @@ DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uin
 }
 
 // ---------------------------------------------------------------- one variable
+// Per-lane inputs of a variable, prefetched one tile ahead.
+struct VarPre {
+  uint32_t meta, orig, row0, tally0;
+};
+
+DWX_DEV VarPre load_var_pre(const KernelParams &P, uint32_t p, bool want_tally) {
+  VarPre v;
+  v.meta = P.v_meta[p];
+  v.orig = P.v_orig[p];
+  v.row0 = P.v_row[p];
+  // boolean tally (one row per variable): read ahead so that the update is a plain
+  // store instead of a read-modify-write the wave would have to wait for
+  v.tally0 = (want_tally && !(v.meta & VM_CATEGORICAL)) ? P.tally[v.row0] : 0u;
+  return v;
+}
+
 template <bool LEARN, int WMODE>
-DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t p) {
-  const uint32_t meta = P.v_meta[p];
+DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t p,
+                              const VarPre pre, double A, double B) {
+  const uint32_t meta = pre.meta;
   const bool is_cat = meta & VM_CATEGORICAL;
   const bool is_evid = meta & VM_EVIDENCE;
   const uint32_t card = meta >> VM_CARD_SHIFT;
-  const uint32_t row0 = P.v_row[p];
+  const uint32_t row0 = pre.row0;
   if (!LEARN) {
     // sample_single_variable (src/gibbs_sampler.h:151-169)
     if (is_evid && !(P.flags & OPT_SAMPLE_EVIDENCE)) return;
-    double A, B;
-    philox_uniforms(P.seed, P.vid_offset + P.v_orig[p], P.sweep, A, B);
     uint32_t prop;
     if (!is_cat) {
       double pp, pn;
       bool_potentials<WMODE>(P, T, row0, P.assign_evid, p, pp, pn);
       prop = bool_draw(A, pp, pn);
-      if (prop) P.tally[row0] += 1;
+      if (prop) P.tally[row0] = pre.tally0 + 1;
     } else {
       prop = cat_draw<WMODE>(P, T, row0, card, P.assign_evid, p, A);
-      P.tally[row0 + prop] += 1;
+      // single owner: a no-return atomic is just a fire-and-forget increment
+      atomicAdd(&P.tally[row0 + prop], 1u);
     }
     P.assign_evid[p] = prop;
     return;
@@ -292,8 +308,6 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
   // sample_sgd_single_variable (src/gibbs_sampler.h:127-149)
   const bool noise_aware = P.flags & OPT_NOISE_AWARE;
   const bool has_truth = meta & VM_TRUTHINESS;
-  double A, B;
-  philox_uniforms(P.seed, P.vid_offset + P.v_orig[p], P.sweep, A, B);
   // free chain
   uint32_t p_free;
   if (!is_cat) {
@@ -364,56 +378,112 @@ DWX_DEV EdgeRec stream_load_edge(const EdgeRec *p) {
 #define DWX_STREAM_LOAD_EDGE(p) stream_load_edge(p)
 #endif
 
+// Everything a lane holds in registers for the tile it will stage next.
+struct TilePrefetch {
+  EdgeRec rec[STAGE_UNROLL];
+  uint32_t rp[ROWPTR_UNROLL];
+  VarPre pre;
+};
+
+DWX_DEV bool tile_fits(const KernelParams &P, const TileDesc &d) {
+  return d.nrows <= P.rcap && d.nedges <= P.ecap;
+}
+
+template <bool LEARN>
+DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t t, TilePrefetch &f) {
+  // 16 B per lane, consecutive lanes -> consecutive records: one coalesced
+  // non-temporal stream; all loads of a lane are independent and in flight together
+#pragma unroll
+  for (uint32_t k = 0; k < STAGE_UNROLL; ++k) {
+    const uint32_t i = t + k * BLOCK_THREADS;
+    if (i < d.nedges) f.rec[k] = DWX_STREAM_LOAD_EDGE(&P.edges[d.e0 + i]);
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k) {
+    const uint32_t i = t + k * BLOCK_THREADS;
+    if (i <= d.nrows) f.rp[k] = P.row_ptr[d.r0 + i];
+  }
+  if (t < d.nv) f.pre = load_var_pre(P, d.v0 + t, !LEARN);
+}
+
+// Persistent, software-pipelined sweep: workgroup b handles tiles b, b + gridDim.x, ...
+// of the launch.  While a tile is processed out of LDS, the NEXT tile's edge records,
+// row pointers and per-variable inputs are already in flight into registers, so the
+// HBM latency of a tile hides behind the previous tile's arithmetic; the Philox draw
+// of a tile is computed under the latency of its weight gathers.
 template <bool LEARN>
 __global__ void __launch_bounds__(BLOCK_THREADS) sweep_kernel(const KernelParams P) {
   DWX_DYN_LDS(dyn_lds);
-  const uint32_t tile = P.tile_begin + blockIdx.x;
-  const uint32_t v0 = P.tile_v[tile], v1 = P.tile_v[tile + 1];
-  const uint32_t r0 = P.v_row[v0], r1 = P.v_row[v1];
-  const uint32_t e0 = P.row_ptr[r0], e1 = P.row_ptr[r1];
-  const uint32_t nrows = r1 - r0, nedges = e1 - e0;
+  uint32_t *s_rowptr = (uint32_t *)dyn_lds;
+  double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
+  EdgeRec *s_edges = (EdgeRec *)(dyn_lds + P.lds_edge_off);
+  float *s_w = (float *)(dyn_lds + P.lds_w_off);
   const uint32_t t = threadIdx.x;
   constexpr int WMODE = LEARN ? W_ARRAY : W_INRECORD;
-  // workgroup-uniform: does the tile fit the LDS budget? (the compiler only builds
-  // an oversized tile around a single variable)
-  if (nrows <= P.rcap && nedges <= P.ecap) {
-    uint32_t *s_rowptr = (uint32_t *)dyn_lds;
-    double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
-    EdgeRec *s_edges = (EdgeRec *)(dyn_lds + P.lds_edge_off);
-    float *s_w = (float *)(dyn_lds + P.lds_w_off);
-    for (uint32_t i = t; i <= nrows; i += BLOCK_THREADS) s_rowptr[i] = P.row_ptr[r0 + i];
-    // Staging: lane t takes records t, t+256, ...  (16 B per lane, consecutive lanes ->
-    // consecutive records: one coalesced non-temporal stream), then gathers the f32
-    // weight of every record it holds -- all STAGE_UNROLL gathers of a lane are
-    // independent and in flight together -- and only then writes LDS.
-    EdgeRec rec[STAGE_UNROLL];
-    float w[STAGE_UNROLL];
+  uint32_t tile = P.tile_begin + blockIdx.x;
+  if (tile >= P.tile_end) return;
+  TileDesc d = P.tiles[tile];
+  TilePrefetch f;
+  if (tile_fits(P, d)) issue_tile_loads<LEARN>(P, d, t, f);
+  for (;;) {
+    const bool fits = tile_fits(P, d);   // workgroup-uniform
+    VarPre pre = f.pre;
+    double A = 0.0, B = 0.0;
+    if (fits) {
+      // gather the f32 sampling weight of every record this lane staged ...
+      float w[STAGE_UNROLL];
 #pragma unroll
-    for (uint32_t k = 0; k < STAGE_UNROLL; ++k) {
-      const uint32_t i = t + k * BLOCK_THREADS;
-      if (i < nedges) rec[k] = DWX_STREAM_LOAD_EDGE(&P.edges[e0 + i]);
+      for (uint32_t k = 0; k < STAGE_UNROLL; ++k) {
+        const uint32_t i = t + k * BLOCK_THREADS;
+        if (i < d.nedges) w[k] = P.w32[f.rec[k].wid];
+      }
+      // ... and draw this lane's uniforms while the gathers are in flight
+      if (t < d.nv) philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
+#pragma unroll
+      for (uint32_t k = 0; k < STAGE_UNROLL; ++k) {
+        const uint32_t i = t + k * BLOCK_THREADS;
+        if (i < d.nedges) {
+          EdgeRec r = f.rec[k];
+          if (LEARN) { s_w[i] = w[k]; } else { r.wid = float_to_bits(w[k]); }
+          s_edges[i] = r;
+        }
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k) {
+        const uint32_t i = t + k * BLOCK_THREADS;
+        if (i <= d.nrows) s_rowptr[i] = f.rp[k];
+      }
+      for (uint32_t i = t + ROWPTR_UNROLL * BLOCK_THREADS; i <= d.nrows; i += BLOCK_THREADS)
+        s_rowptr[i] = P.row_ptr[d.r0 + i];
+      __syncthreads();
     }
-#pragma unroll
-    for (uint32_t k = 0; k < STAGE_UNROLL; ++k) {
-      const uint32_t i = t + k * BLOCK_THREADS;
-      if (i < nedges) w[k] = P.w32[rec[k].wid];
+    // prefetch the next tile of this workgroup
+    const uint32_t next = tile + gridDim.x;
+    const bool has_next = next < P.tile_end;
+    TileDesc dn = d;
+    if (has_next) {
+      dn = P.tiles[next];
+      if (tile_fits(P, dn)) issue_tile_loads<LEARN>(P, dn, t, f);
     }
-#pragma unroll
-    for (uint32_t k = 0; k < STAGE_UNROLL; ++k) {
-      const uint32_t i = t + k * BLOCK_THREADS;
-      if (i < nedges) {
-        if (LEARN) { s_w[i] = w[k]; } else { rec[k].wid = float_to_bits(w[k]); }
-        s_edges[i] = rec[k];
+    // process the current tile
+    if (fits) {
+      if (t < d.nv) {
+        TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, P.lds_pot_off ? s_pot : nullptr};
+        process_variable<LEARN, WMODE>(P, T, d.v0 + t, pre, A, B);
+      }
+    } else if (t == 0) {
+      // oversized variable(s): one lane walks HBM directly
+      TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr};
+      for (uint32_t p = d.v0; p < d.v0 + d.nv; ++p) {
+        const VarPre vp = load_var_pre(P, p, !LEARN);
+        philox_uniforms(P.seed, P.vid_offset + vp.orig, P.sweep, A, B);
+        process_variable<LEARN, W_GLOBAL>(P, T, p, vp, A, B);
       }
     }
-    __syncthreads();
-    if (t < v1 - v0) {
-      TileView T{s_rowptr, r0, s_edges, e0, s_w, P.lds_pot_off ? s_pot : nullptr};
-      process_variable<LEARN, WMODE>(P, T, v0 + t);
-    }
-  } else if (t == 0) {
-    TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr};
-    for (uint32_t p = v0; p < v1; ++p) process_variable<LEARN, W_GLOBAL>(P, T, p);
+    if (!has_next) break;
+    __syncthreads();   // LDS is rewritten by the next iteration
+    d = dn;
+    tile = next;
   }
 }
 

@@ -51,6 +51,12 @@ inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v)
   return old;
 }
 
+inline unsigned atomicAdd(unsigned *p, unsigned v) {
+  unsigned old = *p;
+  *p = old + v;
+  return old;
+}
+
 using std::exp;
 using std::log1p;
 using std::log2;
