@@ -84,6 +84,7 @@ def main():
                     help="override the per-GPU variable count (default 10M at 1 GPU, 12.5M else)")
     ap.add_argument("--cpu-sample-vars", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--weights", type=int, default=0, help="override the weight count (experiments)")
     ap.add_argument("--tile-vars", type=int, default=0, help="graph-compile knob (experiments)")
     ap.add_argument("--tile-edges", type=int, default=0, help="graph-compile knob (experiments)")
     args = ap.parse_args()
@@ -108,7 +109,7 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     V = args.vars_per_gpu or (10_000_000 if n_gpus == 1 else 12_500_000)
-    W = 1_000_000 if V >= 1_000_000 else max(1, V // 10)
+    W = args.weights or (1_000_000 if V >= 1_000_000 else max(1, V // 10))
     stepsize, decay, reg = 0.001, 0.95, 0.01       # SURVEY.md §8(d) config-3 run flags
     t0 = time.time()
     raw = synthetic.cfg3(V, n_weights=W, seed=1234, shard=rank)

@@ -24,13 +24,14 @@ struct alignas(16) EdgeRec {
   uint32_t aux;     // arity == 1: dense equal_to of the (only) predicate;
                     // arity >= 2: base index into vifs[]
   uint32_t packed;  // bits 0-3 func id, bit 4: feature value needs the f64 side
-                    // array, bits 8-31 arity
+                    // array, bit 5: weight is fixed, bits 8-31 arity
   float fval;       // feature value (exact when bit 4 is clear)
 };
 static_assert(sizeof(EdgeRec) == 16, "EdgeRec must be 16 bytes");
 
 constexpr uint32_t EDGE_FUNC_MASK = 0xF;
 constexpr uint32_t EDGE_F64_FLAG = 1u << 4;
+constexpr uint32_t EDGE_FIXED_FLAG = 1u << 5;   // the record's weight is fixed (no SGD)
 constexpr uint32_t EDGE_ARITY_SHIFT = 8;
 constexpr uint32_t MAX_ARITY = (1u << 24) - 1;
 
@@ -47,8 +48,12 @@ struct alignas(16) TileDesc {
   uint32_t v0, nv;      // variables [v0, v0 + nv)
   uint32_t r0, nrows;   // value rows [r0, r0 + nrows)
   uint32_t e0, nedges;  // edge records [e0, e0 + nedges)
-  uint32_t pad0, pad1;
+  uint32_t flags;       // TILE_*
+  uint32_t pad1;
 };
+// every record of the tile is a unary factor with an f32-exact feature value: the
+// compute phase then needs no global load at all (everything it reads was staged)
+constexpr uint32_t TILE_SIMPLE = 1u << 0;
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
 
 // v_meta bits

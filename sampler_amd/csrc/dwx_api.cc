@@ -47,10 +47,13 @@ int guarded(Fn &&fn) {
   }
 }
 
+// `pad` extra zeroed elements behind the data (the kernels' clamped, branch-free loads
+// may touch one element past an empty tile)
 template <class T>
-T *upload(const std::vector<T> &v, rt::stream_t s) {
-  T *d = (T *)rt::dmalloc(v.size() * sizeof(T));
+T *upload(const std::vector<T> &v, rt::stream_t s, size_t pad = 0) {
+  T *d = (T *)rt::dmalloc((v.size() + pad) * sizeof(T));
   rt::h2d(d, v.data(), v.size() * sizeof(T), s);
+  if (pad) rt::dmemset(d + v.size(), 0, pad * sizeof(T), s);
   return d;
 }
 
@@ -74,6 +77,8 @@ struct dwx_sampler {
   uint32_t *d_v_meta = nullptr, *d_v_orig = nullptr, *d_v_row = nullptr, *d_v_init = nullptr;
   uint32_t *d_row_ptr = nullptr;
   TileDesc *d_tiles = nullptr;
+  uint32_t *d_giant = nullptr;
+  int stage_k = 12;
   unsigned persistent_blocks[2] = {1, 1};
   double *d_row_truth = nullptr, *d_edge_fval64 = nullptr;
   EdgeRec *d_edges = nullptr;
@@ -97,7 +102,7 @@ struct dwx_sampler {
   ~dwx_sampler() {
     for (auto &sp : spans) { rt::event_destroy(sp.a); rt::event_destroy(sp.b); }
     rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
-    rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
+    rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
     rt::dfree(d_edges); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
     rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_t_static); rt::dfree(d_w_fixed); rt::dfree(d_grad);
     if (stream) rt::stream_destroy(stream);
@@ -121,16 +126,29 @@ void enqueue_sweep(dwx_sampler *s) {
   for (size_t l = 0; l < nl; ++l) {
     // an inference sweep only visits the query variables' tiles unless
     // --sample_evidence (src/gibbs_sampler.h:157); a learning sweep visits all
+    const bool all = LEARN || s->opts.sample_evidence;
     const uint32_t t0 = c.launch_tile[l];
-    const uint32_t t1 = (LEARN || s->opts.sample_evidence) ? c.launch_tile[l + 1]
-                                                           : c.launch_query_tile_end[l];
+    const uint32_t t1 = all ? c.launch_tile[l + 1] : c.launch_query_tile_end[l];
     if (t1 == t0) continue;
     P.tile_begin = t0;
     P.tile_end = t1;
     // persistent grid: as many workgroups as stay resident, each striding over tiles
     const unsigned grid = std::min<unsigned>(t1 - t0, s->persistent_blocks[LEARN ? 1 : 0]);
-    rt::launch(sweep_kernel<LEARN>, grid, BLOCK_THREADS, s->lds_bytes[LEARN ? 1 : 0], s->stream, P);
+    const size_t lds = s->lds_bytes[LEARN ? 1 : 0];
+    switch (s->stage_k) {
+      case 3: rt::launch(sweep_kernel<LEARN, 3>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      case 6: rt::launch(sweep_kernel<LEARN, 6>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      default: rt::launch(sweep_kernel<LEARN, 12>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+    }
     ++launches;
+    // oversized variables of this launch, if any
+    const uint32_t g0 = c.launch_giant[l];
+    const uint32_t g1 = all ? c.launch_giant[l + 1] : c.launch_giant_query_end[l];
+    if (g1 > g0) {
+      rt::launch(giant_kernel<LEARN>, (g1 - g0 + 63) / 64, 64u, 0, s->stream, P,
+                 (const uint32_t *)(s->d_giant + g0), g1 - g0);
+      ++launches;
+    }
   }
   if (s->timing) {
     rt::event_record(sp.b, s->stream);
@@ -240,15 +258,16 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     const CompiledGraph &c = *s->cg;
     s->stream = rt::stream_create();
     rt::stream_t st = s->stream;
-    s->d_v_meta = upload(c.v_meta, st);
-    s->d_v_orig = upload(c.perm, st);
+    s->d_v_meta = upload(c.v_meta, st, 1);
+    s->d_v_orig = upload(c.perm, st, 1);
     s->d_v_row = upload(c.v_row, st);
-    s->d_v_init = upload(c.v_init, st);
-    s->d_row_ptr = upload(c.row_ptr, st);
+    s->d_v_init = upload(c.v_init, st, 1);
+    s->d_row_ptr = upload(c.row_ptr, st, 1);
     s->d_tiles = upload(c.tiles, st);
+    s->d_giant = upload(c.giant_tiles, st);
     if (!c.row_truth.empty()) s->d_row_truth = upload(c.row_truth, st);
     if (!c.edge_fval64.empty()) s->d_edge_fval64 = upload(c.edge_fval64, st);
-    s->d_edges = upload(c.edges, st);
+    s->d_edges = upload(c.edges, st, 1);
     s->d_vifs = upload(c.vifs, st);
     // InferenceResult init (src/inference_result.cc:24-42): both chains start at the
     // evidence value or 0, tallies zero, weights at their initial values
@@ -256,13 +275,13 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     for (uint64_t p = 0; p < c.V; ++p) a0[p] = (c.v_meta[p] & VM_EVIDENCE) ? c.v_init[p] : 0u;
     s->d_assign_free = upload(a0, st);
     s->d_assign_evid = upload(a0, st);
-    s->d_tally = (uint32_t *)rt::dmalloc(c.R * 4);
-    rt::dmemset(s->d_tally, 0, c.R * 4, st);
+    s->d_tally = (uint32_t *)rt::dmalloc((c.R + 1) * 4);
+    rt::dmemset(s->d_tally, 0, (c.R + 1) * 4, st);
     s->d_weights = upload(c.w_init, st);
     {
       std::vector<float> w32(c.W);
       for (uint64_t i = 0; i < c.W; ++i) w32[i] = (float)c.w_init[i];
-      s->d_w32 = upload(w32, st);
+      s->d_w32 = upload(w32, st, 1);
       // static per-sweep update counts: a boolean variable that triggers SGD visits
       // every factor of its row once per learning sweep with t = 1
       // (src/factor_graph.cc:265-273), independent of the samples drawn
@@ -295,23 +314,33 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
               (opts->noise_aware ? OPT_NOISE_AWARE : 0) |
               (c.has_f64_fval ? OPT_HAS_F64_FVAL : 0) | (c.has_truthiness ? OPT_HAS_TRUTHINESS : 0);
     P.ecap = c.ecap; P.rcap = c.rcap;
-    // dynamic LDS layout: [row pointers | potentials scratch (categorical) | edge
-    // records | f32 weights (learning kernel only)]
+    // dynamic LDS layout: [row pointers | potentials scratch (categorical) | K*256 edge
+    // records | K*256 f32 weights (learning kernel only)]; K = records staged per lane
     if (c.ecap > MAX_ECAP) throw std::invalid_argument("tile_edges exceeds the staging capacity");
-    size_t off = ((size_t)(c.rcap + 1) * 4 + 15) & ~(size_t)15;
+    s->stage_k = c.ecap <= 3 * BLOCK_THREADS ? 3 : (c.ecap <= 6 * BLOCK_THREADS ? 6 : 12);
+    const size_t slots = (size_t)s->stage_k * BLOCK_THREADS;
+    const size_t nrp = std::max<size_t>(c.rcap + 1, ROWPTR_UNROLL * BLOCK_THREADS);
+    size_t off = (nrp * 4 + 15) & ~(size_t)15;
     P.lds_pot_off = c.has_categorical ? (uint32_t)off : 0u;
     if (c.has_categorical) off += (size_t)c.rcap * 8;
     off = (off + 15) & ~(size_t)15;
     P.lds_edge_off = (uint32_t)off;
-    off += (size_t)c.ecap * sizeof(EdgeRec);
+    off += slots * sizeof(EdgeRec);
     P.lds_w_off = (uint32_t)off;
     s->lds_bytes[0] = off;
-    s->lds_bytes[1] = off + (size_t)c.ecap * 4;
+    s->lds_bytes[1] = off + slots * 4;
     if (s->lds_bytes[1] > 160 * 1024) throw std::invalid_argument("tile does not fit the 160 KiB LDS");
-    rt::allow_dynamic_lds(sweep_kernel<false>, s->lds_bytes[0]);
-    rt::allow_dynamic_lds(sweep_kernel<true>, s->lds_bytes[1]);
-    s->persistent_blocks[0] = rt::resident_blocks(sweep_kernel<false>, BLOCK_THREADS, s->lds_bytes[0]);
-    s->persistent_blocks[1] = rt::resident_blocks(sweep_kernel<true>, BLOCK_THREADS, s->lds_bytes[1]);
+    auto prepare = [&](auto infer, auto learn) {
+      rt::allow_dynamic_lds(infer, s->lds_bytes[0]);
+      rt::allow_dynamic_lds(learn, s->lds_bytes[1]);
+      s->persistent_blocks[0] = rt::resident_blocks(infer, BLOCK_THREADS, s->lds_bytes[0]);
+      s->persistent_blocks[1] = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_bytes[1]);
+    };
+    switch (s->stage_k) {
+      case 3: prepare(sweep_kernel<false, 3>, sweep_kernel<true, 3>); break;
+      case 6: prepare(sweep_kernel<false, 6>, sweep_kernel<true, 6>); break;
+      default: prepare(sweep_kernel<false, 12>, sweep_kernel<true, 12>); break;
+    }
     rt::stream_sync(st);
   });
   if (rc != DWX_OK) return rc;

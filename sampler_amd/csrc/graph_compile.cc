@@ -380,6 +380,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
           double fv = d.fac_feature_value[f];
           r.fval = (float)fv;
           if (!((double)r.fval == fv)) { r.packed |= EDGE_F64_FLAG; need64 = true; }
+          if (d.w_is_fixed[r.wid]) r.packed |= EDGE_FIXED_FLAG;
           g.edges[dst + i] = r;
         }
       }
@@ -438,8 +439,23 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       t.v0 = v0; t.nv = v1 - v0;
       t.r0 = g.v_row[v0]; t.nrows = g.v_row[v1] - g.v_row[v0];
       t.e0 = g.row_ptr[g.v_row[v0]]; t.nedges = g.row_ptr[g.v_row[v1]] - g.row_ptr[g.v_row[v0]];
+      bool simple = true;
+      for (uint32_t e = t.e0; e < t.e0 + t.nedges && simple; ++e)
+        simple = (g.edges[e].packed >> EDGE_ARITY_SHIFT) == 1 && !(g.edges[e].packed & EDGE_F64_FLAG);
+      t.flags = simple ? TILE_SIMPLE : 0u;
       g.tiles[i] = t;
     }
+    g.giant_tiles.clear(); g.launch_giant.clear(); g.launch_giant_query_end.clear();
+    for (uint64_t l = 0; l < nl; ++l) {
+      g.launch_giant.push_back((uint32_t)g.giant_tiles.size());
+      bool closed = false;
+      for (uint32_t i = g.launch_tile[l]; i < g.launch_tile[l + 1]; ++i) {
+        if (i == g.launch_query_tile_end[l]) { g.launch_giant_query_end.push_back((uint32_t)g.giant_tiles.size()); closed = true; }
+        if (g.tiles[i].nrows > g.rcap || g.tiles[i].nedges > g.ecap) g.giant_tiles.push_back(i);
+      }
+      if (!closed) g.launch_giant_query_end.push_back((uint32_t)g.giant_tiles.size());
+    }
+    g.launch_giant.push_back((uint32_t)g.giant_tiles.size());
 
     g.w_init.assign(d.w_initial_value, d.w_initial_value + W);
     g.w_fixed.assign(d.w_is_fixed, d.w_is_fixed + W);

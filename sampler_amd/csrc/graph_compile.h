@@ -50,6 +50,9 @@ struct CompiledGraph {
   std::vector<VifRec> vifs;        // [NVif]
   std::vector<uint32_t> tile_v;       // [n_tiles+1]
   std::vector<TileDesc> tiles;        // [n_tiles]
+  std::vector<uint32_t> giant_tiles;  // indices of oversized tiles, launch-major
+  std::vector<uint32_t> launch_giant; // [n_launches+1] into giant_tiles
+  std::vector<uint32_t> launch_giant_query_end; // [n_launches]
   std::vector<uint32_t> launch_tile;  // [n_launches+1] into tile_v
   std::vector<uint32_t> launch_query_tile_end;  // [n_launches] end of the query-variable tiles
   std::vector<uint64_t> launch_off;   // [n_launches+1] variable positions

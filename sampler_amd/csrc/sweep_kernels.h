@@ -89,21 +89,22 @@ DWX_DEV bool vif_sat(const VifRec vf, uint32_t me, uint32_t proposal, const uint
   return val == vf.equal_to;
 }
 
+// unary factor: the only predicate is on the sampled variable itself
+DWX_DEV double unary_sign(uint32_t func, bool s) {
+  switch (func) {
+    case FUNC_AND: case FUNC_ISTRUE: case FUNC_OR: case FUNC_IMPLY_NATURAL:
+      return s ? 1.0 : -1.0;
+    case FUNC_EQUAL:
+      return 1.0;
+    default:  // AND_CATEGORICAL, IMPLY_MLN, LINEAR, RATIO (log2(1+s)), LOGICAL
+      return s ? 1.0 : 0.0;
+  }
+}
+
 // sign functions of src/factor.h:112-299 (returned as double, before * feature_value)
 DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const VifRec *vifs,
                            const uint32_t *assign, uint32_t me, uint32_t proposal) {
-  if (arity == 1) {
-    // the only predicate is on the sampled variable itself
-    const bool s = (proposal == aux);
-    switch (func) {
-      case FUNC_AND: case FUNC_ISTRUE: case FUNC_OR: case FUNC_IMPLY_NATURAL:
-        return s ? 1.0 : -1.0;
-      case FUNC_EQUAL:
-        return 1.0;
-      default:  // AND_CATEGORICAL, IMPLY_MLN, LINEAR, RATIO (log2(1+s)), LOGICAL
-        return s ? 1.0 : 0.0;
-    }
-  }
+  if (arity == 1) return unary_sign(func, proposal == aux);
   const VifRec *v = vifs + aux;
   switch (func) {
     case FUNC_AND: case FUNC_ISTRUE: {
@@ -166,11 +167,25 @@ struct TileView {
 
 DWX_DEV uint32_t edge_func(const EdgeRec &e) { return e.packed & EDGE_FUNC_MASK; }
 DWX_DEV uint32_t edge_arity(const EdgeRec &e) { return e.packed >> EDGE_ARITY_SHIFT; }
-DWX_DEV double edge_fval(const KernelParams &P, const EdgeRec &e, uint32_t idx) {
-  return (e.packed & EDGE_F64_FLAG) ? P.edge_fval64[idx] : (double)e.fval;
-}
 DWX_DEV float bits_to_float(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 DWX_DEV uint32_t float_to_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+
+// SIMPLE (a per-tile, workgroup-uniform property, TILE_SIMPLE): every record is a
+// unary factor with an f32-exact feature value.  The SIMPLE variants below contain no
+// global load, so nothing in the compute phase waits on vmcnt -- which retires in
+// order and would otherwise also wait for the next tile's prefetch.
+template <bool SIMPLE>
+DWX_DEV double edge_fval(const KernelParams &P, const EdgeRec &e, uint32_t idx) {
+  if (SIMPLE) return (double)e.fval;
+  return (e.packed & EDGE_F64_FLAG) ? P.edge_fval64[idx] : (double)e.fval;
+}
+
+template <bool SIMPLE>
+DWX_DEV double edge_sign(const KernelParams &P, const EdgeRec &er, const uint32_t *assign,
+                         uint32_t me, uint32_t proposal) {
+  if (SIMPLE) return unary_sign(edge_func(er), proposal == er.aux);
+  return factor_sign(edge_func(er), edge_arity(er), er.aux, P.vifs, assign, me, proposal);
+}
 
 template <int WMODE>
 DWX_DEV double edge_weight(const KernelParams &P, const TileView &T, const EdgeRec &er, uint32_t e) {
@@ -181,7 +196,7 @@ DWX_DEV double edge_weight(const KernelParams &P, const TileView &T, const EdgeR
 
 // FactorGraph::potential for one value row (src/factor_graph.h:127-145):
 // pot = sum_i weight[wid_i] * (sign_i * feature_value_i), in row order.
-template <int WMODE>
+template <int WMODE, bool SIMPLE>
 DWX_DEV double row_potential(const KernelParams &P, const TileView &T, uint32_t row,
                              const uint32_t *assign, uint32_t me, uint32_t proposal) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
@@ -189,15 +204,15 @@ DWX_DEV double row_potential(const KernelParams &P, const TileView &T, uint32_t 
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     const double w = edge_weight<WMODE>(P, T, er, e);
-    const double s = factor_sign(edge_func(er), edge_arity(er), er.aux, P.vifs, assign, me, proposal);
-    pot += w * (s * edge_fval(P, er, e));
+    const double s = edge_sign<SIMPLE>(P, er, assign, me, proposal);
+    pot += w * (s * edge_fval<SIMPLE>(P, er, e));
   }
   return pot;
 }
 
 // boolean variable: both proposals in one pass over the row (same sums, same order
 // as two calls of FactorGraph::potential, src/gibbs_sampler.h:201-202)
-template <int WMODE>
+template <int WMODE, bool SIMPLE>
 DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t row,
                              const uint32_t *assign, uint32_t me, double &pp, double &pn) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
@@ -205,10 +220,9 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     const double w = edge_weight<WMODE>(P, T, er, e);
-    const double fv = edge_fval(P, er, e);
-    const uint32_t fn = edge_func(er), ar = edge_arity(er);
-    const double s1 = factor_sign(fn, ar, er.aux, P.vifs, assign, me, 1u);
-    const double s0 = factor_sign(fn, ar, er.aux, P.vifs, assign, me, 0u);
+    const double fv = edge_fval<SIMPLE>(P, er, e);
+    const double s1 = edge_sign<SIMPLE>(P, er, assign, me, 1u);
+    const double s0 = edge_sign<SIMPLE>(P, er, assign, me, 0u);
     pp += w * (s1 * fv);
     pn += w * (s0 * fv);
   }
@@ -220,18 +234,18 @@ DWX_DEV uint32_t bool_draw(double r, double pp, double pn) {
 }
 
 // categorical draw, src/gibbs_sampler.h:217-246 (inverse CDF with ONE uniform)
-template <int WMODE>
+template <int WMODE, bool SIMPLE>
 DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row0, uint32_t card,
                           const uint32_t *assign, uint32_t me, double r) {
   double sum = -100000.0;
   for (uint32_t d = 0; d < card; ++d) {
-    const double pot = row_potential<WMODE>(P, T, row0 + d, assign, me, d);
+    const double pot = row_potential<WMODE, SIMPLE>(P, T, row0 + d, assign, me, d);
     if (T.pot) T.pot[row0 + d - T.row_bias] = pot;
     sum = logadd(sum, pot);
   }
   for (uint32_t d = 0; d < card; ++d) {
     const double pot = T.pot ? T.pot[row0 + d - T.row_bias]
-                             : row_potential<WMODE>(P, T, row0 + d, assign, me, d);
+                             : row_potential<WMODE, SIMPLE>(P, T, row0 + d, assign, me, d);
     r -= exp(pot - sum);
     if (r <= 0) return d;
   }
@@ -242,17 +256,16 @@ DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row
 // G[wid] += round(2^30 * t * (pot_free - pot_evid)),  T[wid] += round(2^30 * t).
 // COUNT_T = false for boolean variables: their update counts are static and were
 // folded into T_static on the host (dwx_sampler_create).
-template <bool COUNT_T>
+template <bool COUNT_T, bool SIMPLE>
 DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uint32_t me,
                      uint32_t evid_value, uint32_t free_value, double t) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
-    if (P.w_fixed[er.wid]) continue;
-    const double fv = edge_fval(P, er, e);
-    const uint32_t fn = edge_func(er), ar = edge_arity(er);
-    const double pot_evid = factor_sign(fn, ar, er.aux, P.vifs, P.assign_evid, me, evid_value) * fv;
-    const double pot_free = factor_sign(fn, ar, er.aux, P.vifs, P.assign_free, me, free_value) * fv;
+    if (er.packed & EDGE_FIXED_FLAG) continue;   // weights_isfixed (src/factor_graph.cc:247)
+    const double fv = edge_fval<SIMPLE>(P, er, e);
+    const double pot_evid = edge_sign<SIMPLE>(P, er, P.assign_evid, me, evid_value) * fv;
+    const double pot_free = edge_sign<SIMPLE>(P, er, P.assign_free, me, free_value) * fv;
     const double g = pot_free - pot_evid;
     const long long gi = llrint(FIX_SCALE * (t * g));
     if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
@@ -266,21 +279,22 @@ DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uin
 // ---------------------------------------------------------------- one variable
 // Per-lane inputs of a variable, prefetched one tile ahead.
 struct VarPre {
-  uint32_t meta, orig, row0, tally0;
+  uint32_t meta, orig, row0, init;
 };
 
-DWX_DEV VarPre load_var_pre(const KernelParams &P, uint32_t p, bool want_tally) {
+// independent loads only (no load depends on another: vmcnt retires in order, so a
+// dependent load here would make the whole prefetch wait)
+template <bool LEARN>
+DWX_DEV VarPre load_var_pre(const KernelParams &P, uint32_t p) {
   VarPre v;
   v.meta = P.v_meta[p];
   v.orig = P.v_orig[p];
   v.row0 = P.v_row[p];
-  // boolean tally (one row per variable): read ahead so that the update is a plain
-  // store instead of a read-modify-write the wave would have to wait for
-  v.tally0 = (want_tally && !(v.meta & VM_CATEGORICAL)) ? P.tally[v.row0] : 0u;
+  v.init = LEARN ? P.v_init[p] : 0u;   // dense evidence value (assignment_dense)
   return v;
 }
 
-template <bool LEARN, int WMODE>
+template <bool LEARN, int WMODE, bool SIMPLE>
 DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t p,
                               const VarPre pre, double A, double B) {
   const uint32_t meta = pre.meta;
@@ -294,12 +308,13 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
     uint32_t prop;
     if (!is_cat) {
       double pp, pn;
-      bool_potentials<WMODE>(P, T, row0, P.assign_evid, p, pp, pn);
+      bool_potentials<WMODE, SIMPLE>(P, T, row0, P.assign_evid, p, pp, pn);
       prop = bool_draw(A, pp, pn);
-      if (prop) P.tally[row0] = pre.tally0 + 1;
+      // single owner per row: a no-return atomic is a fire-and-forget increment the
+      // wave never waits for (a load-add-store would stall on the load)
+      if (prop) atomicAdd(&P.tally[row0], 1u);
     } else {
-      prop = cat_draw<WMODE>(P, T, row0, card, P.assign_evid, p, A);
-      // single owner: a no-return atomic is just a fire-and-forget increment
+      prop = cat_draw<WMODE, SIMPLE>(P, T, row0, card, P.assign_evid, p, A);
       atomicAdd(&P.tally[row0 + prop], 1u);
     }
     P.assign_evid[p] = prop;
@@ -312,14 +327,14 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
   uint32_t p_free;
   if (!is_cat) {
     double pp, pn;
-    bool_potentials<WMODE>(P, T, row0, P.assign_free, p, pp, pn);
+    bool_potentials<WMODE, SIMPLE>(P, T, row0, P.assign_free, p, pp, pn);
     p_free = bool_draw(A, pp, pn);
   } else {
-    p_free = cat_draw<WMODE>(P, T, row0, card, P.assign_free, p, A);
+    p_free = cat_draw<WMODE, SIMPLE>(P, T, row0, card, P.assign_free, p, A);
   }
   P.assign_free[p] = p_free;
   // evidence chain: sample_evid (src/gibbs_sampler.h:171-190)
-  const uint32_t evid_value = P.v_init[p];
+  const uint32_t evid_value = pre.init;
   uint32_t p_evid;
   if (!noise_aware && is_evid) {
     p_evid = evid_value;
@@ -332,10 +347,10 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
     }
   } else if (!is_cat) {
     double pp, pn;
-    bool_potentials<WMODE>(P, T, row0, P.assign_evid, p, pp, pn);
+    bool_potentials<WMODE, SIMPLE>(P, T, row0, P.assign_evid, p, pp, pn);
     p_evid = bool_draw(B, pp, pn);
   } else {
-    p_evid = cat_draw<WMODE>(P, T, row0, card, P.assign_evid, p, B);
+    p_evid = cat_draw<WMODE, SIMPLE>(P, T, row0, card, P.assign_evid, p, B);
   }
   P.assign_evid[p] = p_evid;
   // src/gibbs_sampler.h:144-146
@@ -344,7 +359,7 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
     return;
   // sgd_on_variable (src/factor_graph.cc:262-314)
   if (!is_cat) {
-    sgd_row<false>(P, T, row0, p, evid_value, p_free, 1.0);
+    sgd_row<false, SIMPLE>(P, T, row0, p, evid_value, p_free, 1.0);
     return;
   }
   for (uint32_t val = 0; val < card; ++val) {
@@ -354,9 +369,9 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
       t = P.row_truth ? P.row_truth[row0 + val] : 0.0;
       if (is_linear_zero(t)) continue;
     }
-    sgd_row<true>(P, T, row0 + val, p, val, p_free, t);
+    sgd_row<true, SIMPLE>(P, T, row0 + val, p, val, p_free, t);
     if (val == p_free) continue;
-    sgd_row<true>(P, T, row0 + p_free, p, val, p_free, t);
+    sgd_row<true, SIMPLE>(P, T, row0 + p_free, p, val, p_free, t);
   }
 }
 
@@ -379,40 +394,61 @@ DWX_DEV EdgeRec stream_load_edge(const EdgeRec *p) {
 #endif
 
 // Everything a lane holds in registers for the tile it will stage next.
+template <int K>
 struct TilePrefetch {
-  EdgeRec rec[STAGE_UNROLL];
+  EdgeRec rec[K];
   uint32_t rp[ROWPTR_UNROLL];
   VarPre pre;
 };
+
+// The descriptor is workgroup-uniform: keep it in scalar registers.  Loading (vector
+// registers, no wait) and scalarising (needs the data) are separate steps so that the
+// load of the descriptor two tiles ahead can stay in flight across a whole tile.
+#ifndef DWX_UNIFORM
+#define DWX_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#endif
+DWX_DEV TileDesc scalarise(const TileDesc &v) {
+  TileDesc d;
+  d.v0 = DWX_UNIFORM(v.v0); d.nv = DWX_UNIFORM(v.nv);
+  d.r0 = DWX_UNIFORM(v.r0); d.nrows = DWX_UNIFORM(v.nrows);
+  d.e0 = DWX_UNIFORM(v.e0); d.nedges = DWX_UNIFORM(v.nedges);
+  d.flags = DWX_UNIFORM(v.flags); d.pad1 = 0;
+  return d;
+}
 
 DWX_DEV bool tile_fits(const KernelParams &P, const TileDesc &d) {
   return d.nrows <= P.rcap && d.nedges <= P.ecap;
 }
 
-template <bool LEARN>
-DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t t, TilePrefetch &f) {
-  // 16 B per lane, consecutive lanes -> consecutive records: one coalesced
-  // non-temporal stream; all loads of a lane are independent and in flight together
+DWX_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// Branch-free on purpose: a predicated load compiles to a divergent branch with an
+// s_waitcnt vmcnt(0) behind it, which serialises the loads.  Every lane therefore
+// always loads -- out-of-range lanes re-load the tile's last record / row pointer /
+// variable (the arrays carry one padding element so an empty tile stays in bounds) --
+// and all K + ROWPTR_UNROLL + 4 loads of a lane are in flight together.
+template <bool LEARN, int K>
+DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t t,
+                              TilePrefetch<K> &f) {
+  const uint32_t last_e = d.nedges ? d.nedges - 1 : 0u;
 #pragma unroll
-  for (uint32_t k = 0; k < STAGE_UNROLL; ++k) {
-    const uint32_t i = t + k * BLOCK_THREADS;
-    if (i < d.nedges) f.rec[k] = DWX_STREAM_LOAD_EDGE(&P.edges[d.e0 + i]);
-  }
+  for (int k = 0; k < K; ++k)
+    f.rec[k] = DWX_STREAM_LOAD_EDGE(&P.edges[d.e0 + umin(t + k * BLOCK_THREADS, last_e)]);
 #pragma unroll
-  for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k) {
-    const uint32_t i = t + k * BLOCK_THREADS;
-    if (i <= d.nrows) f.rp[k] = P.row_ptr[d.r0 + i];
-  }
-  if (t < d.nv) f.pre = load_var_pre(P, d.v0 + t, !LEARN);
+  for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k)
+    f.rp[k] = P.row_ptr[d.r0 + umin(t + k * BLOCK_THREADS, d.nrows)];
+  f.pre = load_var_pre<LEARN>(P, d.v0 + umin(t, d.nv - 1));
 }
 
 // Persistent, software-pipelined sweep: workgroup b handles tiles b, b + gridDim.x, ...
 // of the launch.  While a tile is processed out of LDS, the NEXT tile's edge records,
 // row pointers and per-variable inputs are already in flight into registers, so the
 // HBM latency of a tile hides behind the previous tile's arithmetic; the Philox draw
-// of a tile is computed under the latency of its weight gathers.
-template <bool LEARN>
-__global__ void __launch_bounds__(BLOCK_THREADS) sweep_kernel(const KernelParams P) {
+// of a tile is computed under the latency of its weight gathers.  K = records staged
+// per lane (LDS holds K * 256 records).  Oversized variables are skipped here and
+// handled by giant_kernel.
+template <bool LEARN, int K>
+__global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelParams P) {
   DWX_DYN_LDS(dyn_lds);
   uint32_t *s_rowptr = (uint32_t *)dyn_lds;
   double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
@@ -422,68 +458,79 @@ __global__ void __launch_bounds__(BLOCK_THREADS) sweep_kernel(const KernelParams
   constexpr int WMODE = LEARN ? W_ARRAY : W_INRECORD;
   uint32_t tile = P.tile_begin + blockIdx.x;
   if (tile >= P.tile_end) return;
-  TileDesc d = P.tiles[tile];
-  TilePrefetch f;
-  if (tile_fits(P, d)) issue_tile_loads<LEARN>(P, d, t, f);
+  const uint32_t stride = gridDim.x;
+  TileDesc d = scalarise(P.tiles[tile]);
+  uint32_t next = tile + stride;
+  bool has_next = next < P.tile_end;
+  TileDesc dn = scalarise(P.tiles[has_next ? next : tile]);   // one descriptor ahead
+  TilePrefetch<K> f;
+  issue_tile_loads<LEARN, K>(P, d, t, f);
   for (;;) {
     const bool fits = tile_fits(P, d);   // workgroup-uniform
-    VarPre pre = f.pre;
+    const VarPre pre = f.pre;
     double A = 0.0, B = 0.0;
     if (fits) {
       // gather the f32 sampling weight of every record this lane staged ...
-      float w[STAGE_UNROLL];
+      float w[K];
 #pragma unroll
-      for (uint32_t k = 0; k < STAGE_UNROLL; ++k) {
-        const uint32_t i = t + k * BLOCK_THREADS;
-        if (i < d.nedges) w[k] = P.w32[f.rec[k].wid];
-      }
+      for (int k = 0; k < K; ++k) w[k] = P.w32[f.rec[k].wid];
       // ... and draw this lane's uniforms while the gathers are in flight
-      if (t < d.nv) philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
+      philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
+      // unconditional LDS writes: slots past the tile's last record receive copies of
+      // it and are never read
 #pragma unroll
-      for (uint32_t k = 0; k < STAGE_UNROLL; ++k) {
+      for (int k = 0; k < K; ++k) {
         const uint32_t i = t + k * BLOCK_THREADS;
-        if (i < d.nedges) {
-          EdgeRec r = f.rec[k];
-          if (LEARN) { s_w[i] = w[k]; } else { r.wid = float_to_bits(w[k]); }
-          s_edges[i] = r;
-        }
+        EdgeRec r = f.rec[k];
+        if (LEARN) { s_w[i] = w[k]; } else { r.wid = float_to_bits(w[k]); }
+        s_edges[i] = r;
       }
 #pragma unroll
-      for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k) {
-        const uint32_t i = t + k * BLOCK_THREADS;
-        if (i <= d.nrows) s_rowptr[i] = f.rp[k];
-      }
+      for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k) s_rowptr[t + k * BLOCK_THREADS] = f.rp[k];
       for (uint32_t i = t + ROWPTR_UNROLL * BLOCK_THREADS; i <= d.nrows; i += BLOCK_THREADS)
         s_rowptr[i] = P.row_ptr[d.r0 + i];
       __syncthreads();
     }
-    // prefetch the next tile of this workgroup
-    const uint32_t next = tile + gridDim.x;
-    const bool has_next = next < P.tile_end;
-    TileDesc dn = d;
-    if (has_next) {
-      dn = P.tiles[next];
-      if (tile_fits(P, dn)) issue_tile_loads<LEARN>(P, dn, t, f);
-    }
-    // process the current tile
-    if (fits) {
-      if (t < d.nv) {
-        TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, P.lds_pot_off ? s_pot : nullptr};
-        process_variable<LEARN, WMODE>(P, T, d.v0 + t, pre, A, B);
-      }
-    } else if (t == 0) {
-      // oversized variable(s): one lane walks HBM directly
-      TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr};
-      for (uint32_t p = d.v0; p < d.v0 + d.nv; ++p) {
-        const VarPre vp = load_var_pre(P, p, !LEARN);
-        philox_uniforms(P.seed, P.vid_offset + vp.orig, P.sweep, A, B);
-        process_variable<LEARN, W_GLOBAL>(P, T, p, vp, A, B);
-      }
+    // Prefetch, unconditionally and branch-free (a conditional prefetch makes the
+    // compiler copy the freshly loaded registers right behind the loads, i.e. wait for
+    // them): first the descriptor two tiles ahead (vector registers; scalarised only at
+    // the bottom of the loop), then the next tile's records / row pointers / variable
+    // inputs.  Past the last tile the "next tile" is an empty one at the launch's first
+    // record: K loads of one cached line.
+    const uint32_t nn = next + stride;
+    const bool has_nn = has_next && nn < P.tile_end;
+    const TileDesc raw_nn = P.tiles[has_nn ? nn : tile];
+    TileDesc dl = dn;
+    if (!has_next) { dl.nedges = 0; dl.nrows = 0; dl.nv = 1; }
+    issue_tile_loads<LEARN, K>(P, dl, t, f);
+    // process the current tile out of LDS
+    if (fits && t < d.nv) {
+      TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, P.lds_pot_off ? s_pot : nullptr};
+      if (d.flags & TILE_SIMPLE) process_variable<LEARN, WMODE, true>(P, T, d.v0 + t, pre, A, B);
+      else process_variable<LEARN, WMODE, false>(P, T, d.v0 + t, pre, A, B);
     }
     if (!has_next) break;
     __syncthreads();   // LDS is rewritten by the next iteration
     d = dn;
-    tile = next;
+    dn = scalarise(raw_nn);
+    tile = next; next = nn; has_next = has_nn;
+  }
+}
+
+// Variables too big for one tile (rows > rcap or edge records > ecap): one lane per
+// such tile walks HBM directly.  Correct for any degree; rare by construction.
+template <bool LEARN>
+__global__ void __launch_bounds__(64) giant_kernel(const KernelParams P, const uint32_t *giant_tiles,
+                                                   uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const TileDesc d = P.tiles[giant_tiles[i]];
+  TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr};
+  for (uint32_t p = d.v0; p < d.v0 + d.nv; ++p) {
+    const VarPre vp = load_var_pre<LEARN>(P, p);
+    double A, B;
+    philox_uniforms(P.seed, P.vid_offset + vp.orig, P.sweep, A, B);
+    process_variable<LEARN, W_GLOBAL, false>(P, T, p, vp, A, B);
   }
 }
 
