@@ -54,6 +54,7 @@ struct alignas(16) TileDesc {
 // every record of the tile is a unary factor with an f32-exact feature value: the
 // compute phase then needs no global load at all (everything it reads was staged)
 constexpr uint32_t TILE_SIMPLE = 1u << 0;
+constexpr uint32_t TILE_CATEGORICAL = 1u << 1;   // the tile's variables are categorical
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
 
 // v_meta bits

@@ -442,7 +442,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       bool simple = true;
       for (uint32_t e = t.e0; e < t.e0 + t.nedges && simple; ++e)
         simple = (g.edges[e].packed >> EDGE_ARITY_SHIFT) == 1 && !(g.edges[e].packed & EDGE_F64_FLAG);
-      t.flags = simple ? TILE_SIMPLE : 0u;
+      t.flags = (simple ? TILE_SIMPLE : 0u) | ((g.v_meta[v0] & VM_CATEGORICAL) ? TILE_CATEGORICAL : 0u);
       g.tiles[i] = t;
     }
     g.giant_tiles.clear(); g.launch_giant.clear(); g.launch_giant_query_end.clear();

@@ -154,7 +154,12 @@ DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const Vi
 //              the records keep their weight id for the gradient scatter)
 //   W_INRECORD the staging pass overwrote rec.wid with the f32 weight bits
 //              (inference kernel: no extra LDS)
-enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2 };
+//   W_TERMS    (inference, SIMPLE tiles) the staging pass replaced each record by its
+//              two potential terms (w*(s1*f), w*(s0*f)); the row walk only adds
+enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3 };
+
+struct alignas(16) EdgeTerms { double t1, t0; };
+static_assert(sizeof(EdgeTerms) == sizeof(EdgeRec), "terms overlay the staged records");
 
 struct TileView {
   const uint32_t *rowptr;  // indexed by (row - row_bias)
@@ -189,7 +194,7 @@ DWX_DEV double edge_sign(const KernelParams &P, const EdgeRec &er, const uint32_
 
 template <int WMODE>
 DWX_DEV double edge_weight(const KernelParams &P, const TileView &T, const EdgeRec &er, uint32_t e) {
-  if (WMODE == W_INRECORD) return (double)bits_to_float(er.wid);
+  if (WMODE == W_INRECORD || WMODE == W_TERMS) return (double)bits_to_float(er.wid);
   if (WMODE == W_ARRAY) return (double)T.w[e - T.edge_bias];
   return (double)P.w32[er.wid];
 }
@@ -201,6 +206,11 @@ DWX_DEV double row_potential(const KernelParams &P, const TileView &T, uint32_t 
                              const uint32_t *assign, uint32_t me, uint32_t proposal) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   double pot = 0.0;
+  if (WMODE == W_TERMS) {
+    const EdgeTerms *terms = (const EdgeTerms *)T.edges;
+    for (uint32_t e = es; e < ee; ++e) pot += terms[e - T.edge_bias].t1;
+    return pot;
+  }
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     const double w = edge_weight<WMODE>(P, T, er, e);
@@ -217,6 +227,15 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
                              const uint32_t *assign, uint32_t me, double &pp, double &pn) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   pp = 0.0; pn = 0.0;
+  if (WMODE == W_TERMS) {
+    const EdgeTerms *terms = (const EdgeTerms *)T.edges;
+    for (uint32_t e = es; e < ee; ++e) {
+      const EdgeTerms tt = terms[e - T.edge_bias];
+      pp += tt.t1;
+      pn += tt.t0;
+    }
+    return;
+  }
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     const double w = edge_weight<WMODE>(P, T, er, e);
@@ -478,12 +497,34 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelPar
       philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
       // unconditional LDS writes: slots past the tile's last record receive copies of
       // it and are never read
+      if (!LEARN && (d.flags & TILE_SIMPLE)) {
+        // inference, all-unary tile: do the per-record arithmetic here, edge-parallel
+        // and straight-line, and stage the two potential terms instead of the record:
+        // t1 = w * (sign(proposal 1) * f), t0 = w * (sign(proposal 0) * f) for a boolean
+        // row; for a categorical row d the record's predicate IS value d, so the one
+        // term is w * (sign(satisfied) * f).  Same products as FactorGraph::potential.
+        const bool cat = d.flags & TILE_CATEGORICAL;
+        EdgeTerms *s_terms = (EdgeTerms *)s_edges;
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const uint32_t i = t + k * BLOCK_THREADS;
-        EdgeRec r = f.rec[k];
-        if (LEARN) { s_w[i] = w[k]; } else { r.wid = float_to_bits(w[k]); }
-        s_edges[i] = r;
+        for (int k = 0; k < K; ++k) {
+          const EdgeRec r = f.rec[k];
+          const uint32_t fn = edge_func(r);
+          const double fv = (double)r.fval, wv = (double)w[k];
+          const double s1 = unary_sign(fn, cat ? true : (r.aux == 1u));
+          const double s0 = unary_sign(fn, r.aux == 0u);
+          EdgeTerms tt;
+          tt.t1 = wv * (s1 * fv);
+          tt.t0 = wv * (s0 * fv);
+          s_terms[t + k * BLOCK_THREADS] = tt;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const uint32_t i = t + k * BLOCK_THREADS;
+          EdgeRec r = f.rec[k];
+          if (LEARN) { s_w[i] = w[k]; } else { r.wid = float_to_bits(w[k]); }
+          s_edges[i] = r;
+        }
       }
 #pragma unroll
       for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k) s_rowptr[t + k * BLOCK_THREADS] = f.rp[k];
@@ -506,8 +547,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelPar
     // process the current tile out of LDS
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, P.lds_pot_off ? s_pot : nullptr};
-      if (d.flags & TILE_SIMPLE) process_variable<LEARN, WMODE, true>(P, T, d.v0 + t, pre, A, B);
-      else process_variable<LEARN, WMODE, false>(P, T, d.v0 + t, pre, A, B);
+      if (d.flags & TILE_SIMPLE)
+        process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B);
+      else
+        process_variable<LEARN, WMODE, false>(P, T, d.v0 + t, pre, A, B);
     }
     if (!has_next) break;
     __syncthreads();   // LDS is rewritten by the next iteration
