@@ -21,8 +21,8 @@ enum : uint32_t {
 // contiguous, 16-B-aligned HBM range.
 struct alignas(16) EdgeRec {
   uint32_t wid;     // weight id
-  uint32_t aux;     // arity == 1: dense equal_to of the (only) predicate;
-                    // arity >= 2: base index into vifs[]
+  uint32_t aux;     // arity >= 2: base index into vifs[]; arity == 1: dense equal_to of
+                    // the (only) predicate, or -- EDGE_PRESIGNED -- the miss value
   uint32_t packed;  // bits 0-3 func id, bit 4: feature value needs the f64 side
                     // array, bit 5: weight is fixed, bits 8-31 arity
   float fval;       // feature value (exact when bit 4 is clear)
@@ -32,6 +32,11 @@ static_assert(sizeof(EdgeRec) == 16, "EdgeRec must be 16 bytes");
 constexpr uint32_t EDGE_FUNC_MASK = 0xF;
 constexpr uint32_t EDGE_F64_FLAG = 1u << 4;
 constexpr uint32_t EDGE_FIXED_FLAG = 1u << 5;   // the record's weight is fixed (no SGD)
+// Unary factor with an f32-exact feature value f: the host already folded the sign
+// function in.  fval = sign(hit) * f and aux = float bits of sign(miss) * f, where for
+// a boolean owner hit means "proposal == 1" and for a categorical owner "proposal ==
+// the value of the row the record sits in" (exact: signs are -1, 0 or +1).
+constexpr uint32_t EDGE_PRESIGNED = 1u << 6;
 constexpr uint32_t EDGE_ARITY_SHIFT = 8;
 constexpr uint32_t MAX_ARITY = (1u << 24) - 1;
 
@@ -51,8 +56,8 @@ struct alignas(16) TileDesc {
   uint32_t flags;       // TILE_*
   uint32_t pad1;
 };
-// every record of the tile is a unary factor with an f32-exact feature value: the
-// compute phase then needs no global load at all (everything it reads was staged)
+// every record of the tile is EDGE_PRESIGNED (unary factor, f32-exact feature value):
+// the compute phase then needs no global load at all (everything it reads was staged)
 constexpr uint32_t TILE_SIMPLE = 1u << 0;
 constexpr uint32_t TILE_CATEGORICAL = 1u << 1;   // the tile's variables are categorical
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");

@@ -183,6 +183,9 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       }
     }
     for (uint64_t v = 0; v < V; ++v)
+      if (!is_cat[v] && assign_dense[v] > 1)
+        throw std::runtime_error("boolean variable " + std::to_string(v) + " has an initial value other than 0/1");
+    for (uint64_t v = 0; v < V; ++v)
       if (is_cat[v] && g.var_is_evid[v] && assign_dense[v] >= card[v])
         throw std::runtime_error("evidence value of variable " + std::to_string(v) +
                                  " is outside its domain");
@@ -381,6 +384,24 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
           r.fval = (float)fv;
           if (!((double)r.fval == fv)) { r.packed |= EDGE_F64_FLAG; need64 = true; }
           if (d.w_is_fixed[r.wid]) r.packed |= EDGE_FIXED_FLAG;
+          if (a == 1 && !(r.packed & EDGE_F64_FLAG)) {
+            // fold the unary sign function in (src/factor.h:112-299 at arity 1)
+            auto usign = [&](bool sat) -> double {
+              switch (d.fac_func[f]) {
+                case FUNC_AND: case FUNC_ISTRUE: case FUNC_OR: case FUNC_IMPLY_NATURAL:
+                  return sat ? 1.0 : -1.0;
+                case FUNC_EQUAL: return 1.0;
+                default: return sat ? 1.0 : 0.0;
+              }
+            };
+            const uint32_t eq = edge_dense[lo];
+            const double s_hit = is_cat[v] ? usign(true) : usign(eq == 1u);
+            const double s_miss = is_cat[v] ? usign(false) : usign(eq == 0u);
+            const float fa = (float)(s_hit * fv), fb = (float)(s_miss * fv);
+            uint32_t bits;
+            std::memcpy(&bits, &fb, 4);
+            r.fval = fa; r.aux = bits; r.packed |= EDGE_PRESIGNED;
+          }
           g.edges[dst + i] = r;
         }
       }
@@ -441,7 +462,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       t.e0 = g.row_ptr[g.v_row[v0]]; t.nedges = g.row_ptr[g.v_row[v1]] - g.row_ptr[g.v_row[v0]];
       bool simple = true;
       for (uint32_t e = t.e0; e < t.e0 + t.nedges && simple; ++e)
-        simple = (g.edges[e].packed >> EDGE_ARITY_SHIFT) == 1 && !(g.edges[e].packed & EDGE_F64_FLAG);
+        simple = (g.edges[e].packed & EDGE_PRESIGNED) != 0;
       t.flags = (simple ? TILE_SIMPLE : 0u) | ((g.v_meta[v0] & VM_CATEGORICAL) ? TILE_CATEGORICAL : 0u);
       g.tiles[i] = t;
     }

@@ -179,17 +179,16 @@ DWX_DEV uint32_t float_to_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4
 // unary factor with an f32-exact feature value.  The SIMPLE variants below contain no
 // global load, so nothing in the compute phase waits on vmcnt -- which retires in
 // order and would otherwise also wait for the next tile's prefetch.
+// sign * feature_value of one record for `proposal` (= Factor::potential,
+// src/factor.h:59-86).  `hit`: boolean owner -> proposal == 1; categorical owner ->
+// proposal == value of the record's row.  Pre-signed records need nothing else.
 template <bool SIMPLE>
-DWX_DEV double edge_fval(const KernelParams &P, const EdgeRec &e, uint32_t idx) {
-  if (SIMPLE) return (double)e.fval;
-  return (e.packed & EDGE_F64_FLAG) ? P.edge_fval64[idx] : (double)e.fval;
-}
-
-template <bool SIMPLE>
-DWX_DEV double edge_sign(const KernelParams &P, const EdgeRec &er, const uint32_t *assign,
-                         uint32_t me, uint32_t proposal) {
-  if (SIMPLE) return unary_sign(edge_func(er), proposal == er.aux);
-  return factor_sign(edge_func(er), edge_arity(er), er.aux, P.vifs, assign, me, proposal);
+DWX_DEV double edge_term(const KernelParams &P, const EdgeRec &er, uint32_t idx,
+                         const uint32_t *assign, uint32_t me, uint32_t proposal, bool hit) {
+  if (SIMPLE || (er.packed & EDGE_PRESIGNED))
+    return (double)(hit ? er.fval : bits_to_float(er.aux));
+  const double fv = (er.packed & EDGE_F64_FLAG) ? P.edge_fval64[idx] : (double)er.fval;
+  return factor_sign(edge_func(er), edge_arity(er), er.aux, P.vifs, assign, me, proposal) * fv;
 }
 
 template <int WMODE>
@@ -214,8 +213,7 @@ DWX_DEV double row_potential(const KernelParams &P, const TileView &T, uint32_t 
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     const double w = edge_weight<WMODE>(P, T, er, e);
-    const double s = edge_sign<SIMPLE>(P, er, assign, me, proposal);
-    pot += w * (s * edge_fval<SIMPLE>(P, er, e));
+    pot += w * edge_term<SIMPLE>(P, er, e, assign, me, proposal, true);
   }
   return pot;
 }
@@ -239,11 +237,8 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     const double w = edge_weight<WMODE>(P, T, er, e);
-    const double fv = edge_fval<SIMPLE>(P, er, e);
-    const double s1 = edge_sign<SIMPLE>(P, er, assign, me, 1u);
-    const double s0 = edge_sign<SIMPLE>(P, er, assign, me, 0u);
-    pp += w * (s1 * fv);
-    pn += w * (s0 * fv);
+    pp += w * edge_term<SIMPLE>(P, er, e, assign, me, 1u, true);
+    pn += w * edge_term<SIMPLE>(P, er, e, assign, me, 0u, false);
   }
 }
 
@@ -275,16 +270,17 @@ DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row
 // G[wid] += round(2^30 * t * (pot_free - pot_evid)),  T[wid] += round(2^30 * t).
 // COUNT_T = false for boolean variables: their update counts are static and were
 // folded into T_static on the host (dwx_sampler_create).
+// hit_value: the proposal that "hits" a pre-signed record of this row (1 for a boolean
+// variable, the row's value for a categorical one).
 template <bool COUNT_T, bool SIMPLE>
 DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uint32_t me,
-                     uint32_t evid_value, uint32_t free_value, double t) {
+                     uint32_t evid_value, uint32_t free_value, uint32_t hit_value, double t) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     if (er.packed & EDGE_FIXED_FLAG) continue;   // weights_isfixed (src/factor_graph.cc:247)
-    const double fv = edge_fval<SIMPLE>(P, er, e);
-    const double pot_evid = edge_sign<SIMPLE>(P, er, P.assign_evid, me, evid_value) * fv;
-    const double pot_free = edge_sign<SIMPLE>(P, er, P.assign_free, me, free_value) * fv;
+    const double pot_evid = edge_term<SIMPLE>(P, er, e, P.assign_evid, me, evid_value, evid_value == hit_value);
+    const double pot_free = edge_term<SIMPLE>(P, er, e, P.assign_free, me, free_value, free_value == hit_value);
     const double g = pot_free - pot_evid;
     const long long gi = llrint(FIX_SCALE * (t * g));
     if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
@@ -378,7 +374,7 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
     return;
   // sgd_on_variable (src/factor_graph.cc:262-314)
   if (!is_cat) {
-    sgd_row<false, SIMPLE>(P, T, row0, p, evid_value, p_free, 1.0);
+    sgd_row<false, SIMPLE>(P, T, row0, p, evid_value, p_free, 1u, 1.0);
     return;
   }
   for (uint32_t val = 0; val < card; ++val) {
@@ -388,9 +384,9 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
       t = P.row_truth ? P.row_truth[row0 + val] : 0.0;
       if (is_linear_zero(t)) continue;
     }
-    sgd_row<true, SIMPLE>(P, T, row0 + val, p, val, p_free, t);
+    sgd_row<true, SIMPLE>(P, T, row0 + val, p, val, p_free, val, t);
     if (val == p_free) continue;
-    sgd_row<true, SIMPLE>(P, T, row0 + p_free, p, val, p_free, t);
+    sgd_row<true, SIMPLE>(P, T, row0 + p_free, p, val, p_free, p_free, t);
   }
 }
 
@@ -399,17 +395,34 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
 #define DWX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
 
-// The edge-record stream is read exactly once per sweep: load it non-temporally so it
-// does not evict the (re-used) f32 weight table from the XCD's L2.
-#ifndef DWX_STREAM_LOAD_EDGE
-typedef uint32_t dwx_u32x4 __attribute__((ext_vector_type(4)));
-DWX_DEV EdgeRec stream_load_edge(const EdgeRec *p) {
-  dwx_u32x4 v = __builtin_nontemporal_load((const dwx_u32x4 *)p);
-  EdgeRec r;
-  r.wid = v.x; r.aux = v.y; r.packed = v.z; r.fval = bits_to_float(v.w);
-  return r;
+// The tile's edge records: lane t takes records t, t + 256, ...  (16 B per lane,
+// consecutive lanes -> consecutive records: one coalesced stream).  Read through a
+// buffer descriptor of exactly the tile's range: the hardware bounds check returns
+// zeros for lanes past the last record (no clamping arithmetic, no branch, no memory
+// traffic), and the K loads differ only in their scalar offset, so they cost no
+// per-load address VALU.  "nt": the stream is read once per sweep and must not evict
+// the re-used f32 weight table from the XCD's L2.
+#ifdef DWX_HOST_EMU
+template <int K>
+DWX_DEV void load_tile_records(const EdgeRec *base, uint32_t nedges, uint32_t t, EdgeRec (&rec)[K]) {
+  for (int k = 0; k < K; ++k) {
+    const uint32_t i = t + k * BLOCK_THREADS;
+    rec[k] = i < nedges ? base[i] : EdgeRec{0u, 0u, 0u, 0.0f};
+  }
 }
-#define DWX_STREAM_LOAD_EDGE(p) stream_load_edge(p)
+#else
+typedef uint32_t dwx_u32x4 __attribute__((ext_vector_type(4)));
+template <int K>
+DWX_DEV void load_tile_records(const EdgeRec *base, uint32_t nedges, uint32_t t, EdgeRec (&rec)[K]) {
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(nedges * sizeof(EdgeRec)), 0x00020000);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const dwx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+        rsrc, (int)(t * sizeof(EdgeRec)), (int)(k * BLOCK_THREADS * sizeof(EdgeRec)), /*nt*/ 2);
+    rec[k].wid = v.x; rec[k].aux = v.y; rec[k].packed = v.z; rec[k].fval = bits_to_float(v.w);
+  }
+}
 #endif
 
 // Everything a lane holds in registers for the tile it will stage next.
@@ -443,16 +456,13 @@ DWX_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // Branch-free on purpose: a predicated load compiles to a divergent branch with an
 // s_waitcnt vmcnt(0) behind it, which serialises the loads.  Every lane therefore
-// always loads -- out-of-range lanes re-load the tile's last record / row pointer /
-// variable (the arrays carry one padding element so an empty tile stays in bounds) --
-// and all K + ROWPTR_UNROLL + 4 loads of a lane are in flight together.
+// always loads -- out-of-range lanes get zero records from the buffer bounds check and
+// re-load the tile's last row pointer / variable (the arrays carry one padding
+// element) -- and all K + ROWPTR_UNROLL + 4 loads of a lane are in flight together.
 template <bool LEARN, int K>
 DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t t,
                               TilePrefetch<K> &f) {
-  const uint32_t last_e = d.nedges ? d.nedges - 1 : 0u;
-#pragma unroll
-  for (int k = 0; k < K; ++k)
-    f.rec[k] = DWX_STREAM_LOAD_EDGE(&P.edges[d.e0 + umin(t + k * BLOCK_THREADS, last_e)]);
+  load_tile_records<K>(P.edges + d.e0, d.nedges, t, f.rec);
 #pragma unroll
   for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k)
     f.rp[k] = P.row_ptr[d.r0 + umin(t + k * BLOCK_THREADS, d.nrows)];
@@ -500,21 +510,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelPar
       if (!LEARN && (d.flags & TILE_SIMPLE)) {
         // inference, all-unary tile: do the per-record arithmetic here, edge-parallel
         // and straight-line, and stage the two potential terms instead of the record:
-        // t1 = w * (sign(proposal 1) * f), t0 = w * (sign(proposal 0) * f) for a boolean
-        // row; for a categorical row d the record's predicate IS value d, so the one
-        // term is w * (sign(satisfied) * f).  Same products as FactorGraph::potential.
-        const bool cat = d.flags & TILE_CATEGORICAL;
+        // t1 = w * (sign(hit) * f), t0 = w * (sign(miss) * f), the sign already folded
+        // into the record by the host.  Same products as FactorGraph::potential.
         EdgeTerms *s_terms = (EdgeTerms *)s_edges;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const EdgeRec r = f.rec[k];
-          const uint32_t fn = edge_func(r);
-          const double fv = (double)r.fval, wv = (double)w[k];
-          const double s1 = unary_sign(fn, cat ? true : (r.aux == 1u));
-          const double s0 = unary_sign(fn, r.aux == 0u);
+          const double wv = (double)w[k];
           EdgeTerms tt;
-          tt.t1 = wv * (s1 * fv);
-          tt.t0 = wv * (s0 * fv);
+          tt.t1 = wv * (double)r.fval;                 // proposal hits
+          tt.t0 = wv * (double)bits_to_float(r.aux);   // proposal misses
           s_terms[t + k * BLOCK_THREADS] = tt;
         }
       } else {

@@ -41,7 +41,7 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::functi
 #define __launch_bounds__(...)
 #define DWX_DEV inline
 #define DWX_DYN_LDS(name) unsigned char *name = ::emu::g_lds
-#define DWX_STREAM_LOAD_EDGE(p) (*(p))
+#define DWX_HOST_EMU 1
 #define DWX_UNIFORM(x) (x)
 
 inline void __syncthreads() { ::emu::syncthreads(); }
