@@ -1,0 +1,553 @@
+// dw_cli.cc -- see dw_cli.h.  Plain C++17; talks to the sampler only through the C ABI.
+#include "dw_cli.h"
+
+#include <endian.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+
+namespace dw {
+
+// ------------------------------------------------------------------ command line
+namespace {
+struct FlagSpec {
+  const char *short_name, *long_name;
+  bool takes_value;
+};
+// the `dw gibbs` flag table of src/cmd_parser.cc:59-113, plus this build's additions
+const FlagSpec kFlags[] = {
+    {"m", "fg_meta", true}, {"v", "variables", true}, {"", "domains", true},
+    {"f", "factors", true}, {"w", "weights", true}, {"o", "outputFile", true},
+    {"l", "n_learning_epoch", true}, {"i", "n_inference_epoch", true}, {"", "burn_in", true},
+    {"c", "n_datacopy", true}, {"t", "n_threads", true}, {"a", "alpha", true},
+    {"p", "stepsize", true}, {"d", "diminish", true}, {"b", "reg_param", true},
+    {"", "regularization", true}, {"q", "quiet", false}, {"", "sample_evidence", false},
+    {"", "learn_non_evidence", false}, {"", "noise_aware", false},
+    {"", "device", true}, {"", "seed", true}, {"", "step_cap", true},
+};
+
+const FlagSpec *find_flag(const std::string &tok) {
+  if (tok.size() >= 3 && tok[0] == '-' && tok[1] == '-') {
+    for (const auto &f : kFlags) if (tok.substr(2) == f.long_name) return &f;
+  } else if (tok.size() == 2 && tok[0] == '-') {
+    for (const auto &f : kFlags) if (f.short_name[0] && tok[1] == f.short_name[0]) return &f;
+  }
+  return nullptr;
+}
+
+bool to_u64(const std::string &s, uint64_t &out) {
+  if (s.empty() || s[0] == '-') return false;
+  char *end = nullptr;
+  errno = 0;
+  unsigned long long v = strtoull(s.c_str(), &end, 10);
+  if (errno || *end) return false;
+  out = v;
+  return true;
+}
+bool to_f64(const std::string &s, double &out) {
+  if (s.empty()) return false;
+  char *end = nullptr;
+  errno = 0;
+  double v = strtod(s.c_str(), &end);
+  if (errno || *end) return false;
+  out = v;
+  return true;
+}
+}  // namespace
+
+CmdLine parse_cmdline(int argc, const char *const argv[]) {
+  CmdLine a;
+  std::ostringstream err;
+  a.app_name = argc > 1 ? argv[1] : "";
+  if (a.app_name != "gibbs") {
+    ++a.num_errors;
+    if (a.app_name == "text2bin" || a.app_name == "bin2text")
+      err << a.app_name << ": not part of this build (SURVEY.md §8f rank 4); use the reference's converter\n";
+    else {
+      err << "DimmWitted (MI355X-native build)\nUsage: " << (argc ? argv[0] : "dw") << " MODE [ARG...]\n  "
+          << (argc ? argv[0] : "dw") << " gibbs\n";
+      if (argc > 1) err << a.app_name << ": Unrecognized MODE\n";
+    }
+    a.error_text = err.str();
+    return a;
+  }
+  bool have_l = false, have_i = false;
+  for (int i = 2; i < argc; ++i) {
+    std::string tok = argv[i], val;
+    // --flag=value
+    size_t eq = tok.find('=');
+    bool inline_val = false;
+    if (tok.rfind("--", 0) == 0 && eq != std::string::npos) {
+      val = tok.substr(eq + 1);
+      tok = tok.substr(0, eq);
+      inline_val = true;
+    }
+    const FlagSpec *f = find_flag(tok);
+    if (!f) {
+      ++a.num_errors;
+      err << "PARSE ERROR: Argument: " << tok << "\n             Couldn't find match for argument\n";
+      continue;
+    }
+    if (f->takes_value && !inline_val) {
+      if (i + 1 >= argc) {
+        ++a.num_errors;
+        err << "PARSE ERROR: Argument: " << tok << "\n             Missing a value for this argument!\n";
+        break;
+      }
+      val = argv[++i];
+    }
+    const std::string n = f->long_name;
+    uint64_t u = 0;
+    double d = 0;
+    auto need_u = [&]() {
+      if (!to_u64(val, u)) { ++a.num_errors; err << "PARSE ERROR: Argument: " << tok << "\n             Couldn't read argument value from string '" << val << "'\n"; return false; }
+      return true;
+    };
+    auto need_d = [&]() {
+      if (!to_f64(val, d)) { ++a.num_errors; err << "PARSE ERROR: Argument: " << tok << "\n             Couldn't read argument value from string '" << val << "'\n"; return false; }
+      return true;
+    };
+    // multi-valued file flags accumulate; scalar flags: last value wins
+    // (getLastValueOrDefault, src/cmd_parser.cc:16-21)
+    if (n == "fg_meta") a.fg_file = val;
+    else if (n == "variables") a.variable_file.push_back(val);
+    else if (n == "domains") a.domain_file.push_back(val);
+    else if (n == "factors") a.factor_file.push_back(val);
+    else if (n == "weights") a.weight_file.push_back(val);
+    else if (n == "outputFile") a.output_folder = val;
+    else if (n == "n_learning_epoch") { if (need_u()) { a.n_learning_epoch = u; have_l = true; } }
+    else if (n == "n_inference_epoch") { if (need_u()) { a.n_inference_epoch = u; have_i = true; } }
+    else if (n == "burn_in") { if (need_u()) a.burn_in = u; }
+    else if (n == "n_datacopy") { if (need_u()) a.n_datacopy = u; }
+    else if (n == "n_threads") { if (need_u()) a.n_threads = u; }
+    else if (n == "alpha") { if (need_d()) a.stepsize = d; }
+    else if (n == "stepsize") { if (need_d()) a.stepsize2 = d; }
+    else if (n == "diminish") { if (need_d()) a.decay = d; }
+    else if (n == "reg_param") { if (need_d()) a.reg_param = d; }
+    else if (n == "regularization") a.regularization_l1 = (val == "l1");
+    else if (n == "quiet") a.should_be_quiet = true;
+    else if (n == "sample_evidence") a.should_sample_evidence = true;
+    else if (n == "learn_non_evidence") a.should_learn_non_evidence = true;
+    else if (n == "noise_aware") a.is_noise_aware = true;
+    else if (n == "device") { if (need_u()) a.device = (int)u; }
+    else if (n == "seed") { if (need_u()) a.seed = u; }
+    else if (n == "step_cap") { if (need_d()) a.step_cap = d; }
+  }
+  // -l and -i are required (src/cmd_parser.cc:75-80)
+  if (!have_l) { ++a.num_errors; err << "PARSE ERROR:\n             Required argument missing: n_learning_epoch\n"; }
+  if (!have_i) { ++a.num_errors; err << "PARSE ERROR:\n             Required argument missing: n_inference_epoch\n"; }
+  // XXX hack of the reference to support two step-size flags (src/cmd_parser.cc:158-160)
+  if (a.stepsize == 0.01) a.stepsize = a.stepsize2;
+  // n_datacopy / n_threads describe CPU replicas and threads; one GPU sampler replaces
+  // them.  They are accepted and normalised so existing command lines keep working.
+  if (a.n_datacopy == 0) a.n_datacopy = 1;
+  if (a.n_threads == 0) a.n_threads = (uint64_t)std::max(1L, sysconf(_SC_NPROCESSORS_CONF));
+  a.error_text = err.str();
+  return a;
+}
+
+namespace {
+std::ostream &operator<<(std::ostream &o, const std::vector<std::string> &v) {
+  if (!v.empty()) {
+    o << '[';
+    for (auto &s : v) o << s << ", ";
+    o << "\b\b]";
+  }
+  return o;
+}
+}  // namespace
+
+std::ostream &operator<<(std::ostream &stream, const CmdLine &args) {
+  stream << "#################GIBBS SAMPLING#################" << std::endl;
+  stream << "# fg_file            : " << args.fg_file << std::endl;
+  stream << "# variable_file      : " << args.variable_file << std::endl;
+  stream << "# domain_file        : " << args.domain_file << std::endl;
+  stream << "# weight_file        : " << args.weight_file << std::endl;
+  stream << "# factor_file        : " << args.factor_file << std::endl;
+  stream << "# output_folder      : " << args.output_folder << std::endl;
+  stream << "# n_learning_epoch   : " << args.n_learning_epoch << std::endl;
+  stream << "# n_inference_epoch  : " << args.n_inference_epoch << std::endl;
+  stream << "# stepsize           : " << args.stepsize << std::endl;
+  stream << "# decay              : " << args.decay << std::endl;
+  stream << "# regularization     : " << args.reg_param << std::endl;
+  stream << "# burn_in            : " << args.burn_in << std::endl;
+  stream << "# n_datacopy         : " << args.n_datacopy << std::endl;
+  stream << "# n_threads          : " << args.n_threads << std::endl;
+  stream << "# learn_non_evidence : " << args.should_learn_non_evidence << std::endl;
+  stream << "# is_noise_aware     : " << args.is_noise_aware << std::endl;
+  stream << "# device (HIP)       : " << args.device << std::endl;
+  stream << "# seed               : " << args.seed << std::endl;
+  stream << "################################################" << std::endl;
+  return stream;
+}
+
+// ------------------------------------------------------------------ loader
+namespace {
+// whole-file read-only mapping
+struct Mapped {
+  const uint8_t *p = nullptr;
+  size_t n = 0;
+  explicit Mapped(const std::string &path) {
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); throw std::runtime_error("cannot stat " + path); }
+    n = (size_t)st.st_size;
+    if (S_ISREG(st.st_mode) && n > 0) {
+      void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m == MAP_FAILED) { close(fd); throw std::runtime_error("cannot mmap " + path); }
+      p = (const uint8_t *)m;
+      mapped_ = true;
+    } else {
+      // pipes / process substitution (the reference's tests pass <(cat ...)): slurp
+      std::vector<uint8_t> *buf = new std::vector<uint8_t>();
+      uint8_t tmp[1 << 16];
+      ssize_t r;
+      while ((r = read(fd, tmp, sizeof tmp)) > 0) buf->insert(buf->end(), tmp, tmp + r);
+      owned_ = buf;
+      p = buf->data();
+      n = buf->size();
+    }
+    close(fd);
+  }
+  ~Mapped() {
+    if (mapped_) munmap((void *)p, n);
+    delete owned_;
+  }
+  Mapped(const Mapped &) = delete;
+
+ private:
+  bool mapped_ = false;
+  std::vector<uint8_t> *owned_ = nullptr;
+};
+
+inline uint64_t be64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return be64toh(v); }
+inline uint16_t be16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return be16toh(v); }
+inline double bef64(const uint8_t *p) { uint64_t v = be64(p); double d; memcpy(&d, &v, 8); return d; }
+}  // namespace
+
+// src/binary_format.cc:23-36: numWeights,numVariables,numFactors,numEdges
+void read_meta(const std::string &path, LoadedGraph &g) {
+  std::ifstream f(path);
+  if (!f) throw std::runtime_error("cannot open meta file " + path);
+  std::string buf;
+  uint64_t *dst[4] = {&g.n_weights, &g.n_variables, &g.n_factors, &g.n_edges};
+  for (int i = 0; i < 4; ++i) {
+    if (!getline(f, buf, ',')) buf.clear();
+    *dst[i] = (uint64_t)atoll(buf.c_str());
+  }
+}
+
+// src/binary_format.cc:64-126 (27-byte records; stored at index vid)
+void load_variables(const std::vector<std::string> &files, LoadedGraph &g) {
+  const uint64_t V = g.n_variables;
+  g.var_role.assign(V, 0); g.var_init_value.assign(V, 0);
+  g.var_dtype.assign(V, 0); g.var_cardinality.assign(V, 0);
+  std::vector<uint8_t> seen(V, 0);
+  uint64_t count = 0;
+  for (const auto &path : files) {
+    Mapped m(path);
+    if (m.n % 27) throw std::runtime_error(path + ": truncated variable record");
+    for (size_t off = 0; off < m.n; off += 27) {
+      const uint8_t *r = m.p + off;
+      uint64_t vid = be64(r);
+      if (vid >= V) throw std::runtime_error(path + ": variable id " + std::to_string(vid) + " out of range");
+      uint16_t dt = be16(r + 17);
+      if (dt > 1) throw std::runtime_error("[ERROR] Only Boolean and Categorical variables are supported now!");
+      g.var_role[vid] = r[8];
+      g.var_init_value[vid] = be64(r + 9);
+      g.var_dtype[vid] = dt;
+      g.var_cardinality[vid] = be64(r + 19);
+      if (!seen[vid]) { seen[vid] = 1; ++count; (r[8] >= 1 ? g.n_evidence : g.n_query)++; }
+    }
+  }
+  // FactorGraph::safety_check (src/factor_graph.cc:201-219)
+  if (count != V) throw std::runtime_error("variable count " + std::to_string(count) + " != meta " + std::to_string(V));
+}
+
+// src/binary_format.cc:48-62 (17-byte records)
+void load_weights(const std::vector<std::string> &files, LoadedGraph &g) {
+  const uint64_t W = g.n_weights;
+  g.w_initial_value.assign(W, 0.0); g.w_is_fixed.assign(W, 0);
+  std::vector<uint8_t> seen(W, 0);
+  uint64_t count = 0;
+  for (const auto &path : files) {
+    Mapped m(path);
+    if (m.n % 17) throw std::runtime_error(path + ": truncated weight record");
+    for (size_t off = 0; off < m.n; off += 17) {
+      const uint8_t *r = m.p + off;
+      uint64_t wid = be64(r);
+      if (wid >= W) throw std::runtime_error(path + ": weight id " + std::to_string(wid) + " out of range");
+      g.w_is_fixed[wid] = r[8];
+      g.w_initial_value[wid] = bef64(r + 9);
+      if (!seen[wid]) { seen[wid] = 1; ++count; }
+    }
+  }
+  if (count != W) throw std::runtime_error("weight count " + std::to_string(count) + " != meta " + std::to_string(W));
+}
+
+// src/binary_format.cc:192-226
+void load_domains(const std::vector<std::string> &files, LoadedGraph &g) {
+  g.dom_vid.clear(); g.dom_offset.assign(1, 0); g.dom_value.clear(); g.dom_truthiness.clear();
+  for (const auto &path : files) {
+    Mapped m(path);
+    size_t off = 0;
+    while (off < m.n) {
+      if (off + 16 > m.n) throw std::runtime_error(path + ": truncated domain block");
+      uint64_t vid = be64(m.p + off), card = be64(m.p + off + 8);
+      off += 16;
+      if (card > (m.n - off) / 16) throw std::runtime_error(path + ": truncated domain block");
+      g.dom_vid.push_back(vid);
+      for (uint64_t i = 0; i < card; ++i, off += 16) {
+        g.dom_value.push_back(be64(m.p + off));
+        g.dom_truthiness.push_back(bef64(m.p + off + 8));
+      }
+      g.dom_offset.push_back(g.dom_value.size());
+    }
+  }
+}
+
+// src/binary_format.cc:128-190; factor ids are assigned in read order
+void load_factors(const std::vector<std::string> &files, LoadedGraph &g) {
+  g.fac_func.clear(); g.fac_edge_offset.assign(1, 0); g.fac_weight_id.clear();
+  g.fac_feature_value.clear(); g.edge_vid.clear(); g.edge_equal_to.clear();
+  g.fac_func.reserve(g.n_factors); g.fac_weight_id.reserve(g.n_factors);
+  g.fac_feature_value.reserve(g.n_factors); g.fac_edge_offset.reserve(g.n_factors + 1);
+  g.edge_vid.reserve(g.n_edges); g.edge_equal_to.reserve(g.n_edges);
+  for (const auto &path : files) {
+    Mapped m(path);
+    size_t off = 0;
+    while (off < m.n) {
+      if (off + 10 > m.n) throw std::runtime_error(path + ": truncated factor record");
+      uint16_t func = be16(m.p + off);
+      uint64_t arity = be64(m.p + off + 2);
+      off += 10;
+      if (arity > (m.n - off) / 16 || off + 16 * arity + 16 > m.n)
+        throw std::runtime_error(path + ": truncated factor record");
+      g.fac_func.push_back(func);
+      for (uint64_t i = 0; i < arity; ++i, off += 16) {
+        g.edge_vid.push_back(be64(m.p + off));
+        g.edge_equal_to.push_back(be64(m.p + off + 8));
+      }
+      g.fac_edge_offset.push_back(g.edge_vid.size());
+      g.fac_weight_id.push_back(be64(m.p + off));
+      g.fac_feature_value.push_back(bef64(m.p + off + 8));
+      off += 16;
+    }
+  }
+  if (g.fac_func.size() != g.n_factors)
+    throw std::runtime_error("factor count " + std::to_string(g.fac_func.size()) + " != meta " + std::to_string(g.n_factors));
+  if (g.edge_vid.size() != g.n_edges)
+    throw std::runtime_error("edge count " + std::to_string(g.edge_vid.size()) + " != meta " + std::to_string(g.n_edges));
+}
+
+dwx_graph_desc LoadedGraph::desc() const {
+  dwx_graph_desc d;
+  memset(&d, 0, sizeof d);
+  d.num_variables = n_variables; d.num_factors = n_factors; d.num_edges = n_edges; d.num_weights = n_weights;
+  d.var_role = var_role.data(); d.var_init_value = var_init_value.data();
+  d.var_dtype = var_dtype.data(); d.var_cardinality = var_cardinality.data();
+  d.num_domains = dom_vid.size();
+  d.dom_vid = dom_vid.data(); d.dom_offset = dom_offset.data();
+  d.dom_value = dom_value.data(); d.dom_truthiness = dom_truthiness.data();
+  d.fac_func = fac_func.data(); d.fac_edge_offset = fac_edge_offset.data();
+  d.fac_weight_id = fac_weight_id.data(); d.fac_feature_value = fac_feature_value.data();
+  d.edge_vid = edge_vid.data(); d.edge_equal_to = edge_equal_to.data();
+  d.w_initial_value = w_initial_value.data(); d.w_is_fixed = w_is_fixed.data();
+  return d;
+}
+
+// ------------------------------------------------------------------ dumps
+// src/inference_result.cc:101-105
+void dump_weights_in_text(std::ostream &o, const std::vector<double> &w) {
+  for (size_t j = 0; j < w.size(); ++j) o << j << " " << w[j] << std::endl;
+}
+
+// src/inference_result.cc:211-243
+void dump_marginals_in_text(std::ostream &o, const LoadedGraph &g, bool sample_evidence,
+                            const std::vector<uint64_t> &var_val_base,
+                            const std::vector<uint64_t> &value_sparse,
+                            const std::vector<uint64_t> &tallies,
+                            const std::vector<uint64_t> &nsamples) {
+  for (uint64_t v = 0; v < g.n_variables; ++v) {
+    if (g.var_role[v] >= 1 && !sample_evidence) continue;
+    const uint64_t b = var_val_base[v];
+    if (g.var_dtype[v] == 0) {
+      o << v << " " << 1 << " " << 1.0 * tallies[b] / nsamples[v] << std::endl;
+    } else {
+      for (uint64_t j = 0; j < g.var_cardinality[v]; ++j)
+        o << v << " " << value_sparse[b + j] << " " << 1.0 * tallies[b + j] / nsamples[v] << std::endl;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ driver
+namespace {
+struct Check {
+  void operator()(int rc) const {
+    if (rc != DWX_OK) throw std::runtime_error(std::string("dwx: ") + dwx_last_error());
+  }
+};
+double now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+int gibbs(const CmdLine &args) {
+  Check ok;
+  dwx_graph *graph = nullptr;
+  dwx_sampler *sampler = nullptr;
+  int exit_code = 0;
+  try {
+    if (!args.should_be_quiet) {
+      std::cout << std::endl;
+      std::cout << "#################MACHINE CONFIG#################" << std::endl;
+      std::cout << "# # HIP device       : " << args.device << std::endl;
+      std::cout << "################################################" << std::endl;
+      std::cout << std::endl;
+      std::cout << args << std::endl;
+    }
+    LoadedGraph lg;
+    read_meta(args.fg_file, lg);
+    std::cout << "Factor graph to load:\t#V=" << lg.n_variables << " #F=" << lg.n_factors
+              << " #W=" << lg.n_weights << " #E=" << lg.n_edges << " #Val=0" << std::endl;
+    std::cout << "\tinitializing factor graph..." << std::endl;
+    std::cout << "\tloading factor graph..." << std::endl;
+    // load order of the reference (src/dimmwitted.cc:66-69)
+    load_variables(args.variable_file, lg);
+    load_weights(args.weight_file, lg);
+    load_domains(args.domain_file, lg);
+    load_factors(args.factor_file, lg);
+    dwx_graph_desc desc = lg.desc();
+    ok(dwx_graph_create(&desc, nullptr, &graph));
+    dwx_graph_info info;
+    ok(dwx_graph_get_info(graph, &info));
+    auto print_size = [&](const char *what) {
+      std::cout << what << "#V=" << lg.n_variables << "(#Vqry=" << lg.n_query << " #Vevd=" << lg.n_evidence
+                << ") #F=" << lg.n_factors << " #W=" << lg.n_weights << " #E=" << lg.n_edges
+                << " #Val=" << info.num_values << std::endl;
+    };
+    print_size("Factor graph loaded:\t");
+    print_size("Factor graph indexed:\t");
+    if (!args.should_be_quiet)
+      std::cout << "Device layout: " << info.num_colors << " colour(s), " << info.num_tiles
+                << " tile(s), " << info.device_bytes << " bytes in HBM" << std::endl;
+
+    dwx_options o;
+    dwx_default_options(&o);
+    o.device = args.device;
+    o.sample_evidence = args.should_sample_evidence;
+    o.learn_non_evidence = args.should_learn_non_evidence;
+    o.noise_aware = args.is_noise_aware;
+    o.regularization = args.regularization_l1 ? 0 : 1;
+    o.reg_param = args.reg_param;
+    o.seed = args.seed;
+    o.step_cap = args.step_cap;
+    ok(dwx_sampler_create(graph, &o, &sampler));
+
+    const uint64_t V = lg.n_variables, W = lg.n_weights;
+    const bool progress = !args.should_be_quiet;
+    std::vector<double> weights(W), prev(lg.w_initial_value);
+
+    // ---- DimmWitted::learn (src/dimmwitted.cc:162-207), one sampler
+    double t_total = now(), stepsize = args.stepsize;
+    for (uint64_t e = 0; e < args.n_learning_epoch; ++e) {
+      if (progress) std::cout << std::setprecision(3) << "LEARNING EPOCH " << e << "~" << e << "...." << std::flush;
+      double t0 = now();
+      ok(dwx_sample_sgd_async(sampler, stepsize));
+      ok(dwx_wait(sampler));
+      double elapsed = now() - t0;
+      if (progress) {
+        // update_weights' norms (src/dimmwitted.cc:218-236)
+        ok(dwx_get_weights(sampler, weights.data()));
+        double lmax = -INFINITY, l2 = 0.0;
+        for (uint64_t j = 0; j < W; ++j) {
+          double diff = fabs(weights[j] - prev[j]);
+          l2 += diff * diff;
+          if (lmax < diff) lmax = diff;
+        }
+        lmax /= stepsize;
+        std::cout << std::setprecision(3) << "" << elapsed << " sec." << "," << V / elapsed
+                  << " vars/sec." << ",stepsize=" << stepsize << ",lmax=" << lmax
+                  << ",l2=" << sqrt(l2) / stepsize << std::endl << std::setprecision(6);
+        prev = weights;
+      }
+      stepsize *= args.decay;
+    }
+    std::cout << std::setprecision(6) << "TOTAL LEARNING TIME: " << now() - t_total << " sec." << std::endl;
+
+    // ---- dump_weights (src/dimmwitted.cc:245-258): before inference starts
+    ok(dwx_get_weights(sampler, weights.data()));
+    if (progress) {
+      std::cout << "LEARNING SNIPPETS (QUERY WEIGHTS):" << std::endl;
+      for (uint64_t j = 0; j < W && j < 10; ++j) std::cout << "   " << j << " " << weights[j] << std::endl;
+      std::cout << "   ..." << std::endl;
+    }
+    {
+      std::string fn = args.output_folder + "/inference_result.out.weights.text";
+      std::cout << "DUMPING... TEXT    : " << fn << std::endl;
+      std::ofstream f(fn);
+      if (!f) throw std::runtime_error("cannot write " + fn);
+      dump_weights_in_text(f, weights);
+    }
+
+    // ---- DimmWitted::inference (src/dimmwitted.cc:121-160)
+    t_total = now();
+    ok(dwx_clear_tallies(sampler));
+    for (uint64_t e = 0; e < args.n_inference_epoch; ++e) {
+      if (progress) {
+        std::cout << std::setprecision(3) << "INFERENCE EPOCH " << e << "~" << e << "...." << std::flush;
+        double t0 = now();
+        ok(dwx_sample_async(sampler));
+        ok(dwx_wait(sampler));
+        double elapsed = now() - t0;
+        std::cout << std::setprecision(3) << "" << elapsed << " sec." << "," << V / elapsed << " vars/sec"
+                  << std::endl << std::setprecision(6);
+      } else {
+        ok(dwx_sample_async(sampler));   // quiet: epochs stay queued on the stream
+      }
+    }
+    ok(dwx_wait(sampler));
+    std::cout << std::setprecision(6) << "TOTAL INFERENCE TIME: " << now() - t_total << " sec." << std::endl;
+
+    // ---- aggregate_results_and_dump (src/dimmwitted.cc:260-277), only if -i > 0
+    if (args.n_inference_epoch > 0) {
+      std::vector<uint64_t> tallies(info.num_values), nsamples(V), base(V), sparse(info.num_values);
+      ok(dwx_get_tallies(sampler, tallies.data(), nsamples.data()));
+      ok(dwx_graph_get_values(graph, base.data(), sparse.data()));
+      std::string fn = args.output_folder + "/inference_result.out.text";
+      std::cout << "DUMPING... TEXT    : " << fn << std::endl;
+      std::ofstream f(fn);
+      if (!f) throw std::runtime_error("cannot write " + fn);
+      dump_marginals_in_text(f, lg, args.should_sample_evidence, base, sparse, tallies, nsamples);
+    }
+  } catch (const std::exception &e) {
+    std::cerr << "dw: " << e.what() << std::endl;
+    exit_code = 1;
+  }
+  dwx_sampler_destroy(sampler);
+  dwx_graph_destroy(graph);
+  return exit_code;
+}
+
+int dw_main(int argc, const char *const argv[]) {
+  CmdLine a = parse_cmdline(argc, argv);
+  if (a.num_errors > 0) {
+    std::cerr << a.error_text;
+    return a.num_errors;
+  }
+  return gibbs(a);
+}
+
+}  // namespace dw

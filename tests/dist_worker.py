@@ -1,0 +1,77 @@
+"""Worker of tests/test_dist_gloo.py: one rank of the sharded epoch driver
+(sampler_amd.dist.ShardedDimmWitted) on CPU with the gloo backend and an ORACLE-backed
+engine (test infrastructure; the product engine is sampler_amd.dist.HipEngine)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import binding as orc  # noqa: E402
+from sampler_amd import synthetic  # noqa: E402
+from sampler_amd.dist import ShardedDimmWitted, shard_range  # noqa: E402
+
+
+class OracleEngine:
+    """Same interface as HipEngine, state in the CPU oracle (schedule mode)."""
+
+    def __init__(self, raw, seed, var_id_offset, reg_param):
+        self.o = orc.Oracle(raw, reg_param=reg_param)
+        self.o.set_var_id_offset(var_id_offset)
+        self.order = np.arange(raw.num_variables, dtype=np.uint64)
+        self.off = np.array([0, raw.num_variables], np.uint64)
+        self.seed = seed
+        self.sweep = 0
+        self.grad = torch.from_numpy(self.o.grad)      # int64 view of [G | T]
+        self.static_reduced = False
+
+    def allreduce_static_counts(self, group=None):
+        self.static_reduced = True                     # the oracle counts T dynamically
+
+    def sgd_accumulate(self):
+        self.o.sched_accumulate(self.order, self.off, self.seed, self.sweep)
+        self.sweep += 1
+
+    def allreduce_grad(self, group=None):
+        dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+
+    def sgd_apply(self, stepsize):
+        self.o.sched_apply(stepsize, 1.0)
+
+    def sample(self):
+        self.o.sched_sample(self.order, self.off, self.seed, self.sweep)
+        self.sweep += 1
+
+    def wait(self):
+        pass
+
+
+def shard_graph(total_vars, n_weights, rank, world, seed):
+    b, e = shard_range(total_vars, rank, world)
+    return synthetic.cfg3(e - b, n_weights=n_weights, seed=seed, shard=rank), b
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    out = sys.argv[1]
+    total, W, seed = int(sys.argv[2]), int(sys.argv[3]), 4242
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    raw, begin = shard_graph(total, W, rank, world, 1234)
+    eng = OracleEngine(raw, seed, begin, 0.01)
+    drv = ShardedDimmWitted(eng, n_learning_epoch=6, n_inference_epoch=4, stepsize=0.05, decay=0.9)
+    assert drv.distributed and eng.static_reduced
+    drv.learn()
+    eng.o.clear_tallies()
+    drv.inference()
+    np.savez(os.path.join(out, "rank%d.npz" % rank), weights=eng.o.weights, tallies=eng.o.tallies,
+             free=eng.o.assignments("free"), evid=eng.o.assignments("evid"), begin=begin)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""GPU leg of the multi-GPU plumbing (run by tests/test_gpu_dist.py with world size 1 on
+the single-GPU test box): HipEngine wraps the sampler's raw device buffers as torch
+tensors, runs RCCL all-reduces on the sampler's own HIP stream, and must leave exactly
+the state a plain sampler reaches."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from sampler_amd import dwx, synthetic  # noqa: E402
+from sampler_amd.dist import HipEngine, ShardedDimmWitted  # noqa: E402
+
+
+def main():
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    raw = synthetic.cfg3(200_000, n_weights=5000, seed=5)
+    g = dwx.Graph(raw)
+    a = dwx.GibbsSampler(g, seed=31)
+    b = dwx.GibbsSampler(g, seed=31)
+    eng = HipEngine(a)
+    # the wrapped tensors alias the sampler's buffers
+    assert eng.grad.dtype == torch.int64 and eng.grad.numel() == 2 * 5000 and eng.grad.is_cuda
+    t0 = eng.t_static.clone()
+    drv = ShardedDimmWitted(eng, 4, 3, 0.05, 0.9)
+    drv.distributed = True                      # force the collective path at world size 1
+    eng.allreduce_static_counts()
+    assert torch.equal(eng.t_static, t0) and int(t0.sum()) > 0
+    drv.learn()
+    drv.inference()
+    cur = 0.05
+    for _ in range(4):
+        b.sample_sgd(cur); cur *= 0.9
+    for _ in range(3):
+        b.sample()
+    b.wait()
+    assert np.array_equal(a.weights, b.weights) and np.abs(a.weights).max() > 0
+    assert np.array_equal(a.assignments("evid"), b.assignments("evid"))
+    assert np.array_equal(a.tallies()[0], b.tallies()[0])
+    assert int(eng.grad.abs().sum()) == 0       # apply cleared the accumulators
+    dist.destroy_process_group()
+    print("gpu dist plumbing ok")
+
+
+if __name__ == "__main__":
+    main()
