@@ -340,10 +340,10 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
   const bool has_truth = meta & VM_TRUTHINESS;
   // free chain
   uint32_t p_free;
+  double pp_f = 0.0, pn_f = 0.0;
   if (!is_cat) {
-    double pp, pn;
-    bool_potentials<WMODE, SIMPLE>(P, T, row0, P.assign_free, p, pp, pn);
-    p_free = bool_draw(A, pp, pn);
+    bool_potentials<WMODE, SIMPLE>(P, T, row0, P.assign_free, p, pp_f, pn_f);
+    p_free = bool_draw(A, pp_f, pn_f);
   } else {
     p_free = cat_draw<WMODE, SIMPLE>(P, T, row0, card, P.assign_free, p, A);
   }
@@ -361,8 +361,10 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
       if (sum >= B) { p_evid = i; break; }
     }
   } else if (!is_cat) {
-    double pp, pn;
-    bool_potentials<WMODE, SIMPLE>(P, T, row0, P.assign_evid, p, pp, pn);
+    double pp = pp_f, pn = pn_f;
+    // unary factors do not read neighbours: both chains see the same potentials
+    // (same records, same weights, same order => bit-identical sums)
+    if (!SIMPLE) bool_potentials<WMODE, SIMPLE>(P, T, row0, P.assign_evid, p, pp, pn);
     p_evid = bool_draw(B, pp, pn);
   } else {
     p_evid = cat_draw<WMODE, SIMPLE>(P, T, row0, card, P.assign_evid, p, B);
@@ -374,6 +376,9 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
     return;
   // sgd_on_variable (src/factor_graph.cc:262-314)
   if (!is_cat) {
+    // a pre-signed record's gradient is (free hits ? A : B) - (evid hits ? A : B): zero
+    // for the whole row when both chains agree (update counts are static, T_static)
+    if (SIMPLE && p_free == evid_value) return;
     sgd_row<false, SIMPLE>(P, T, row0, p, evid_value, p_free, 1u, 1.0);
     return;
   }
