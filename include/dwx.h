@@ -61,6 +61,10 @@ typedef struct dwx_graph_desc {
   const uint64_t *edge_equal_to;   /* equalPredicate as in the file               */
   const double *w_initial_value;   /* indexed by weight id                        */
   const uint8_t *w_is_fixed;
+  /* Sharding: the LAST num_ghost_variables variables are ghosts -- remote variables
+   * that local factors read.  They hold an assignment (refreshed by the caller's halo
+   * exchange) but are never sampled, tallied or given rows.  0 for a whole graph. */
+  uint64_t num_ghost_variables;
 } dwx_graph_desc;
 
 /* Graph-compilation knobs; zero-initialise for defaults. */
@@ -77,6 +81,7 @@ typedef struct dwx_compile_opts {
 
 typedef struct dwx_graph_info {
   uint64_t num_variables, num_factors, num_edges, num_weights;
+  uint64_t num_owned_variables; /* num_variables - ghosts: the variables this graph samples */
   uint64_t num_values;         /* value rows: 1 per boolean, cardinality per categorical
                                   (== FactorGraph size.num_values)                     */
   uint64_t num_index_entries;  /* |factor_index| after dedup (src/factor_graph.cc:177) */
@@ -120,13 +125,16 @@ void dwx_default_options(dwx_options *o);
 int dwx_graph_create(const dwx_graph_desc *desc, const dwx_compile_opts *opts, dwx_graph **out);
 void dwx_graph_destroy(dwx_graph *g);
 int dwx_graph_get_info(const dwx_graph *g, dwx_graph_info *out);
-/* Execution schedule: order[V] = original variable ids in device order;
+/* Execution schedule: order[num_owned_variables] = original variable ids in device order;
  * launch_off[num_launches+1] = offsets into order; every launch is an independent
  * set of the variable conflict graph. */
 int dwx_graph_get_schedule(const dwx_graph *g, uint64_t *order, uint64_t *launch_off);
 /* Value table for result dumps (src/inference_result.cc:211-243):
  * var_val_base[V] (reference numbering) and value_sparse[num_values]. */
 int dwx_graph_get_values(const dwx_graph *g, uint64_t *var_val_base, uint64_t *value_sparse);
+/* Device positions of variables (index into DWX_BUF_ASSIGN_*), for halo exchange:
+ * out[i] = position of original variable id vids[i]. */
+int dwx_graph_get_positions(const dwx_graph *g, const uint64_t *vids, uint64_t n, uint64_t *out);
 /* Reference-order CSR, for parity checks against construct_index:
  * index_base/index_len[num_values], factor_index[num_index_entries]. */
 int dwx_graph_get_index(const dwx_graph *g, uint64_t *index_base, uint64_t *index_len,

@@ -100,6 +100,7 @@ struct Worker { uint64_t start, end; uint16_t seed[3]; };
 struct orc_sampler {
   orc_opts opts;
   uint64_t V, F, E, W, NVal;
+  uint64_t Vg = 0;  // ghost variables (last Vg ids): hold assignments, never sampled
   std::vector<Var> vars;
   std::vector<Value> values;
   std::vector<Factor> factors;
@@ -316,6 +317,7 @@ extern "C" orc_sampler *orc_create(const orc_graph_desc *d, const orc_opts *opts
     auto *s = new orc_sampler();
     s->opts = *opts;
     s->V = d->num_variables; s->F = d->num_factors; s->E = d->num_edges; s->W = d->num_weights;
+    s->Vg = d->num_ghost_variables;
     s->vars.resize(s->V);
     std::vector<std::unordered_map<uint64_t, std::pair<uint64_t, double>>> domain_map(0);
     std::vector<int64_t> dom_of(s->V, -1);
@@ -369,7 +371,8 @@ extern "C" orc_sampler *orc_create(const orc_graph_desc *d, const orc_opts *opts
     }
     // construct_index (src/factor_graph.cc:90-199)
     uint64_t nval = 0;
-    for (auto &x : s->vars) nval += x.is_bool ? 1 : x.cardinality;
+    const uint64_t Vown = s->V - s->Vg;   // ghosts (ids >= Vown) get no rows and no back-refs
+    for (uint64_t v = 0; v < Vown; ++v) nval += s->vars[v].is_bool ? 1 : s->vars[v].cardinality;
     s->NVal = nval;
     s->values.assign(nval, Value{kInvalid, 0, kInvalid, 0});
     s->factor_index.reserve(s->E);
@@ -377,6 +380,7 @@ extern "C" orc_sampler *orc_create(const orc_graph_desc *d, const orc_opts *opts
     for (uint64_t v = 0; v < s->V; ++v) {
       Var &x = s->vars[v];
       x.var_val_base = vb;
+      if (v >= Vown) { std::vector<std::pair<uint64_t, uint64_t>>().swap(adj[v]); continue; }
       if (x.is_bool) {
         s->values[vb++] = Value{0, 0, 0, 0};
       } else if (dom_of[v] >= 0) {
@@ -613,12 +617,13 @@ extern "C" int orc_sched_check_independent(orc_sampler *s, const orc_schedule *s
   std::vector<uint64_t> launch_of(s->V, kInvalid);
   for (uint64_t l = 0; l < sch->n_launches; ++l)
     for (uint64_t i = sch->launch_off[l]; i < sch->launch_off[l + 1]; ++i) launch_of[sch->order[i]] = l;
-  for (uint64_t v = 0; v < s->V; ++v) if (launch_of[v] == kInvalid) return 0;
+  // every owned variable must be scheduled; ghosts (the last Vg ids) must not be
+  for (uint64_t v = 0; v < s->V; ++v) if ((launch_of[v] == kInvalid) != (v >= s->V - s->Vg)) return 0;
   for (const Factor &f : s->factors)
     for (uint64_t i = 0; i < f.num_vars; ++i)
       for (uint64_t j = i + 1; j < f.num_vars; ++j) {
         uint64_t a = s->vifs[f.vif_base + i].vid, b = s->vifs[f.vif_base + j].vid;
-        if (a != b && launch_of[a] == launch_of[b]) return 0;
+        if (a != b && launch_of[a] != kInvalid && launch_of[a] == launch_of[b]) return 0;
       }
   return 1;
 }

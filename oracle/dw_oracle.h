@@ -43,6 +43,10 @@ typedef struct orc_graph_desc {
   const uint64_t *edge_equal_to;  /* equalPredicate as in the file           */
   const double *w_initial_value;  /* indexed by weight id                    */
   const uint8_t *w_is_fixed;
+  /* Sharding: the LAST num_ghost_variables variables are ghosts -- remote variables
+   * that local factors read.  They hold an assignment (refreshed by the caller's halo
+   * exchange) but are never sampled, tallied or given rows.  0 for a whole graph. */
+  uint64_t num_ghost_variables;
 } orc_graph_desc;
 
 typedef struct orc_opts {

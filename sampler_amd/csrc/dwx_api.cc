@@ -208,6 +208,7 @@ int dwx_graph_get_info(const dwx_graph *g, dwx_graph_info *out) {
   if (!g || !out) return fail(DWX_E_INVALID, "null argument");
   const CompiledGraph &c = *g->cg;
   std::memset(out, 0, sizeof *out);
+  out->num_owned_variables = c.Vo;
   out->num_variables = c.V; out->num_factors = c.F; out->num_edges = c.E; out->num_weights = c.W;
   out->num_values = c.R; out->num_index_entries = c.NIdx; out->num_vif_entries = c.NVif;
   out->num_colors = c.n_colors; out->num_launches = c.launch_off.size() - 1;
@@ -221,7 +222,7 @@ int dwx_graph_get_info(const dwx_graph *g, dwx_graph_info *out) {
 int dwx_graph_get_schedule(const dwx_graph *g, uint64_t *order, uint64_t *launch_off) {
   if (!g || !order || !launch_off) return fail(DWX_E_INVALID, "null argument");
   const CompiledGraph &c = *g->cg;
-  for (uint64_t p = 0; p < c.V; ++p) order[p] = c.perm[p];
+  for (uint64_t p = 0; p < c.Vo; ++p) order[p] = c.perm[p];
   std::copy(c.launch_off.begin(), c.launch_off.end(), launch_off);
   return DWX_OK;
 }
@@ -231,6 +232,16 @@ int dwx_graph_get_values(const dwx_graph *g, uint64_t *var_val_base, uint64_t *v
   const CompiledGraph &c = *g->cg;
   if (var_val_base) std::copy(c.ref_var_val_base.begin(), c.ref_var_val_base.end(), var_val_base);
   if (value_sparse) std::copy(c.value_sparse.begin(), c.value_sparse.end(), value_sparse);
+  return DWX_OK;
+}
+
+int dwx_graph_get_positions(const dwx_graph *g, const uint64_t *vids, uint64_t n, uint64_t *out) {
+  if (!g || (n && (!vids || !out))) return fail(DWX_E_INVALID, "null argument");
+  const CompiledGraph &c = *g->cg;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (vids[i] >= c.V) return fail(DWX_E_INVALID, "variable id out of range");
+    out[i] = c.pos[vids[i]];
+  }
   return DWX_OK;
 }
 
@@ -287,7 +298,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       // (src/factor_graph.cc:265-273), independent of the samples drawn
       std::vector<long long> ts(c.W, 0);
       const long long one = (long long)FIX_SCALE;
-      for (uint64_t p = 0; p < c.V; ++p) {
+      for (uint64_t p = 0; p < c.Vo; ++p) {
         const uint32_t m = c.v_meta[p];
         if (m & VM_CATEGORICAL) continue;
         const bool is_evid = m & VM_EVIDENCE;
@@ -441,14 +452,14 @@ int dwx_get_tallies(dwx_sampler *s, uint64_t *tallies, uint64_t *nsamples) {
       std::vector<uint32_t> t(c.R);
       rt::d2h(t.data(), s->d_tally, c.R * 4, s->stream);
       rt::stream_sync(s->stream);
-      for (uint64_t p = 0; p < c.V; ++p) {
+      for (uint64_t p = 0; p < c.Vo; ++p) {
         const uint64_t rb = c.ref_var_val_base[c.perm[p]];
         for (uint32_t r = c.v_row[p]; r < c.v_row[p + 1]; ++r) tallies[rb + (r - c.v_row[p])] = t[r];
       }
     }
     if (nsamples)  // agg_nsamples: +1 per inference sweep for every sampled variable
       for (uint64_t v = 0; v < c.V; ++v)
-        nsamples[v] = (!c.var_is_evid[v] || s->opts.sample_evidence) ? s->infer_sweeps : 0;
+        nsamples[v] = (v < c.Vo && (!c.var_is_evid[v] || s->opts.sample_evidence)) ? s->infer_sweeps : 0;
   });
 }
 

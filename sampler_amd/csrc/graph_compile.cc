@@ -80,6 +80,9 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
   try {
     const uint64_t V = d.num_variables, F = d.num_factors, E = d.num_edges, W = d.num_weights;
     g.V = V; g.F = F; g.E = E; g.W = W;
+    if (d.num_ghost_variables > V) throw std::runtime_error("num_ghost_variables > num_variables");
+    const uint64_t Vo = V - d.num_ghost_variables;   // owned variables are ids [0, Vo)
+    g.Vo = Vo;
     if (V >= kUnset || F >= kUnset || W >= kUnset || E >= kUnset)
       throw LimitError("graph exceeds the 32-bit compact layout (V, F, W, E must be < 2^32-1)");
     uint32_t nth = o.n_threads ? o.n_threads : std::max(1u, std::thread::hardware_concurrency());
@@ -159,12 +162,12 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     // ---- reference value numbering (src/factor_graph.cc:139-175) ----
     g.ref_var_val_base.resize(V);
     uint64_t R = 0;
-    for (uint64_t v = 0; v < V; ++v) { g.ref_var_val_base[v] = R; R += is_cat[v] ? card[v] : 1; }
+    for (uint64_t v = 0; v < V; ++v) { g.ref_var_val_base[v] = R; if (v < Vo) R += is_cat[v] ? card[v] : 1; }
     if (R >= kUnset) throw LimitError("number of value rows exceeds 2^32-1");
     g.R = R;
     g.value_sparse.assign(R, 0);
     std::vector<double> ref_truth;
-    for (uint64_t v = 0; v < V; ++v) {
+    for (uint64_t v = 0; v < Vo; ++v) {
       if (!is_cat[v]) continue;
       uint64_t base = g.ref_var_val_base[v];
       if (!dom_of.empty() && dom_of[v] >= 0) {
@@ -206,7 +209,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     for (uint64_t e = 0; e < E; ++e) {
       uint64_t vid = d.edge_vid[e];
       if (vid >= V) throw std::runtime_error("factor references unknown variable");
-      ++cnt[vid + 1];
+      if (vid < Vo) ++cnt[vid + 1];   // ghosts get no back-references
     }
     std::vector<uint64_t> start(V + 1, 0);
     for (uint64_t v = 0; v < V; ++v) start[v + 1] = start[v] + cnt[v + 1];
@@ -219,6 +222,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
           uint64_t dense = domain_index(vid, d.edge_equal_to[e]);
           if (dense >= kUnset) throw LimitError("predicate value exceeds 32 bits");
           edge_dense[e] = (uint32_t)dense;
+          if (vid >= Vo) continue;
           uint64_t slot = cur[vid]++;
           pv[slot] = is_cat[vid] ? (uint32_t)dense : 0u;   // booleans index under value 0
           pf[slot] = (uint32_t)f;
@@ -276,7 +280,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     {
       std::vector<uint64_t> stamp;
       uint32_t ncol = 0;
-      for (uint64_t v = 0; v < V; ++v) {
+      for (uint64_t v = 0; v < Vo; ++v) {
         uint64_t r0 = g.ref_var_val_base[v], r1 = r0 + (is_cat[v] ? card[v] : 1);
         for (uint64_t i = g.ref_row_ptr[r0]; i < g.ref_row_ptr[r1]; ++i) {
           uint32_t f = g.ref_fidx[i];
@@ -284,7 +288,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
           if (hi - lo < 2 || hi - lo > arity_cap) continue;
           for (uint64_t e = lo; e < hi; ++e) {
             uint64_t u = d.edge_vid[e];
-            if (u == v || color[u] == kUnset) continue;
+            if (u == v || u >= Vo || color[u] == kUnset) continue;   // ghosts: Hogwild across shards
             if (color[u] >= stamp.size()) stamp.resize(color[u] + 1, 0);
             stamp[color[u]] = v + 1;
           }
@@ -294,7 +298,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
         color[v] = c;
         ncol = std::max(ncol, c + 1);
       }
-      g.n_colors = V ? ncol : 0;
+      g.n_colors = Vo ? ncol : 0;
     }
 
     // ---- device order: colour-major; inside a colour query variables before evidence
@@ -304,22 +308,23 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     const uint32_t nkeys = std::max(1u, g.n_colors) * 4;
     auto key_of = [&](uint64_t v) { return color[v] * 4 + (g.var_is_evid[v] ? 2u : 0u) + is_cat[v]; };
     std::vector<uint64_t> key_start(nkeys + 1, 0);
-    for (uint64_t v = 0; v < V; ++v) ++key_start[key_of(v) + 1];
+    for (uint64_t v = 0; v < Vo; ++v) ++key_start[key_of(v) + 1];
     for (uint32_t k = 0; k < nkeys; ++k) key_start[k + 1] += key_start[k];
     g.perm.resize(V); g.pos.resize(V);
     {
       std::vector<uint64_t> cur(key_start.begin(), key_start.end() - 1);
-      for (uint64_t v = 0; v < V; ++v) {
+      for (uint64_t v = 0; v < Vo; ++v) {
         uint64_t p = cur[key_of(v)]++;
         g.perm[p] = (uint32_t)v; g.pos[v] = (uint32_t)p;
         if (p != v) g.order_is_identity = false;
       }
+      for (uint64_t v = Vo; v < V; ++v) { g.perm[v] = (uint32_t)v; g.pos[v] = (uint32_t)v; }  // ghosts last
     }
     g.launch_off.clear();
     for (uint32_t c = 0; c < g.n_colors; ++c) g.launch_off.push_back(key_start[4 * c]);
-    g.launch_off.push_back(V);
+    g.launch_off.push_back(Vo);
     g.n_query = 0;
-    for (uint64_t v = 0; v < V; ++v) g.n_query += !g.var_is_evid[v];
+    for (uint64_t v = 0; v < Vo; ++v) g.n_query += !g.var_is_evid[v];
     if (g.n_colors == 0) g.launch_off.assign(1, 0);
 
     // ---- device rows ----
@@ -332,11 +337,11 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
                    ((is_cat[v] ? card[v] : 2u) << VM_CARD_SHIFT);
       g.v_meta[p] = m;
       g.v_init[p] = assign_dense[v];
-      g.v_row[p + 1] = g.v_row[p] + (is_cat[v] ? card[v] : 1);
+      g.v_row[p + 1] = g.v_row[p] + (v < Vo ? (is_cat[v] ? card[v] : 1) : 0);
     }
     g.row_ptr.assign(R + 1, 0);
     if (g.has_truthiness) g.row_truth.assign(R, 0.0);
-    for (uint64_t p = 0; p < V; ++p) {
+    for (uint64_t p = 0; p < Vo; ++p) {
       uint64_t v = g.perm[p], rb = g.ref_var_val_base[v];
       uint32_t nr = g.v_row[p + 1] - g.v_row[p];
       for (uint32_t j = 0; j < nr; ++j) {
@@ -368,7 +373,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     // ---- edge records, variable-major in device order ----
     g.edges.resize(g.NIdx);
     std::atomic<bool> need64{false};
-    parallel_ranges(V, nth, [&](uint64_t pb, uint64_t pe) {
+    parallel_ranges(Vo, nth, [&](uint64_t pb, uint64_t pe) {
       for (uint64_t p = pb; p < pe; ++p) {
         uint64_t v = g.perm[p];
         uint64_t src = g.ref_row_ptr[g.ref_var_val_base[v]], dst = g.row_ptr[g.v_row[p]];
@@ -409,7 +414,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     if (need64) {
       g.has_f64_fval = true;
       g.edge_fval64.resize(g.NIdx);
-      parallel_ranges(V, nth, [&](uint64_t pb, uint64_t pe) {
+      parallel_ranges(Vo, nth, [&](uint64_t pb, uint64_t pe) {
         for (uint64_t p = pb; p < pe; ++p) {
           uint64_t v = g.perm[p];
           uint64_t src = g.ref_row_ptr[g.ref_var_val_base[v]], dst = g.row_ptr[g.v_row[p]];
@@ -452,7 +457,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       if (!seen_evid) g.launch_query_tile_end.push_back((uint32_t)g.tile_v.size());
     }
     g.launch_tile.push_back((uint32_t)g.tile_v.size());
-    g.tile_v.push_back((uint32_t)V);
+    g.tile_v.push_back((uint32_t)Vo);
     g.tiles.resize(g.tile_v.size() - 1);
     for (size_t i = 0; i + 1 < g.tile_v.size(); ++i) {
       const uint32_t v0 = g.tile_v[i], v1 = g.tile_v[i + 1];

@@ -66,28 +66,101 @@ class HipEngine:
         with torch.cuda.stream(self.stream):
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
+    # ---- halo exchange support ----
+    def assign_tensor(self, chain):
+        """int32 view of a chain's assignments in DEVICE order (values < 2^31)."""
+        from . import dwx
+        which = dwx.BUF_ASSIGN_FREE if chain in (0, "free") else dwx.BUF_ASSIGN_EVID
+        ptr, nbytes = self.s.device_buffer(which)
+        holder = _CudaArray(ptr, nbytes, "<i4", 4)
+        self._keep = getattr(self, "_keep", []) + [holder]
+        return torch.as_tensor(holder, device=self.grad.device)
+
+    def positions(self, local_vids):
+        """device positions of local variable ids (index into assign_tensor)."""
+        return torch.as_tensor(self.s.graph.positions(local_vids).astype(np.int64), device=self.grad.device)
+
+    def stream_context(self):
+        return torch.cuda.stream(self.stream)
+
+
+class HaloExchange:
+    """Boundary-assignment exchange between sweeps (north_star: "halo-exchange of boundary
+    assignments between sweeps").  Rank r owns the global variable block
+    [begin_r, end_r); its ghosts are remote variables its factors read.  Built once:
+    every rank learns which of its owned variables each peer ghosts; per exchange one
+    gather -> point-to-point send/recv per peer -> scatter, 4 B per boundary variable and
+    chain, on the engine's stream.  Reads of ghosts between exchanges are stale by at
+    most one sweep -- the reference's own Hogwild semantics across threads."""
+
+    def __init__(self, engine, begin, end, ghost_global_ids, bounds, group=None):
+        self.e = engine
+        self.group = group
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ghosts = np.asarray(ghost_global_ids, np.int64)
+        n_owned = end - begin
+        # who owns each of my ghosts (bounds[k] = (begin_k, end_k))
+        starts = np.array([b for b, _ in bounds], np.int64)
+        owner = np.searchsorted(starts, ghosts, side="right") - 1
+        wanted = [ghosts[owner == k] for k in range(world)]        # ascending global ids
+        all_wanted = [None] * world
+        dist.all_gather_object(all_wanted, wanted, group=group)     # setup only (host)
+        self.send_pos, self.recv_pos = {}, {}
+        for k in range(world):
+            if k == rank:
+                continue
+            theirs = np.asarray(all_wanted[k][rank], np.int64)     # my owned vars peer k ghosts
+            if len(theirs):
+                self.send_pos[k] = engine.positions((theirs - begin).astype(np.uint64))
+            mine = wanted[k]
+            if len(mine):
+                local = n_owned + np.searchsorted(ghosts, mine)
+                self.recv_pos[k] = engine.positions(local.astype(np.uint64))
+        self.n_boundary = sum(len(v) for v in self.send_pos.values())
+
+    def exchange(self, chains=("free", "evid")):
+        with self.e.stream_context():
+            for chain in chains:
+                a = self.e.assign_tensor(chain)
+                ops, recv = [], {}
+                for k, pos in self.send_pos.items():
+                    ops.append(dist.P2POp(dist.isend, a[pos].contiguous(), k, group=self.group))
+                for k, pos in self.recv_pos.items():
+                    recv[k] = torch.empty(len(pos), dtype=a.dtype, device=a.device)
+                    ops.append(dist.P2POp(dist.irecv, recv[k], k, group=self.group))
+                if ops:
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                for k, pos in self.recv_pos.items():
+                    a[pos] = recv[k]
+
 
 class ShardedDimmWitted:
     """Epoch driver over variable-block shards (DimmWitted::learn / inference,
     src/dimmwitted.cc:121-207, with the replica loop replaced by ranks)."""
 
     def __init__(self, engine, n_learning_epoch, n_inference_epoch, stepsize=0.01, decay=0.95,
-                 group=None):
+                 group=None, halo=None):
         self.e = engine
         self.n_learning_epoch = n_learning_epoch
         self.n_inference_epoch = n_inference_epoch
         self.stepsize = stepsize
         self.decay = decay
         self.group = group
+        self.halo = halo          # HaloExchange or None (no cross-shard factors)
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         if self.distributed:
             self.e.allreduce_static_counts(group)
+        if self.halo is not None:
+            self.halo.exchange(("free", "evid"))   # ghosts start from their owners' state
 
     def learn_epoch(self, stepsize):
         self.e.sgd_accumulate()
         if self.distributed:
             self.e.allreduce_grad(self.group)
         self.e.sgd_apply(stepsize)
+        if self.halo is not None:
+            self.halo.exchange(("free", "evid"))
 
     def learn(self):
         cur = self.stepsize
@@ -99,6 +172,8 @@ class ShardedDimmWitted:
     def inference(self):
         for _ in range(self.n_inference_epoch):
             self.e.sample()
+            if self.halo is not None:
+                self.halo.exchange(("evid",))
         self.e.wait()
 
 

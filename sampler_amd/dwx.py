@@ -22,7 +22,7 @@ BUF_WEIGHTS, BUF_GRAD, BUF_ASSIGN_FREE, BUF_ASSIGN_EVID, BUF_TALLIES, BUF_TSTATI
 SYMBOLS = [
     "dwx_last_error", "dwx_version", "dwx_default_options",
     "dwx_graph_create", "dwx_graph_destroy", "dwx_graph_get_info", "dwx_graph_get_schedule",
-    "dwx_graph_get_values", "dwx_graph_get_index",
+    "dwx_graph_get_values", "dwx_graph_get_positions", "dwx_graph_get_index",
     "dwx_sampler_create", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
     "dwx_wait", "dwx_sgd_accumulate_async", "dwx_sgd_apply_async",
     "dwx_get_weights", "dwx_set_weights", "dwx_clear_tallies", "dwx_get_tallies",
@@ -46,7 +46,7 @@ class CompileOpts(C.Structure):
 
 class GraphInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
-        "num_variables", "num_factors", "num_edges", "num_weights", "num_values",
+        "num_variables", "num_factors", "num_edges", "num_weights", "num_owned_variables", "num_values",
         "num_index_entries", "num_vif_entries", "num_colors", "num_launches", "num_tiles",
         "num_giant_tiles", "max_cardinality", "num_query_variables", "device_bytes")] + [
         ("has_categorical", C.c_uint32), ("order_is_identity", C.c_uint32)]
@@ -81,6 +81,7 @@ class Library:
         L.dwx_graph_get_schedule.argtypes = [vp, vp, vp]
         L.dwx_graph_get_values.argtypes = [vp, vp, vp]
         L.dwx_graph_get_index.argtypes = [vp, vp, vp, vp]
+        L.dwx_graph_get_positions.argtypes = [vp, vp, u64, vp]
         L.dwx_sampler_create.argtypes = [vp, vp, vp]
         L.dwx_sampler_destroy.argtypes = [vp]; L.dwx_sampler_destroy.restype = None
         L.dwx_sample_async.argtypes = [vp]
@@ -142,10 +143,16 @@ class Graph:
             self.h = None
 
     def schedule(self):
-        order = np.zeros(self.info.num_variables, np.uint64)
+        order = np.zeros(self.info.num_owned_variables, np.uint64)
         off = np.zeros(self.info.num_launches + 1, np.uint64)
         self.lib.check(self.lib.L.dwx_graph_get_schedule(self.h, order.ctypes.data, off.ctypes.data))
         return order, off
+
+    def positions(self, vids):
+        vids = np.ascontiguousarray(vids, np.uint64)
+        out = np.zeros(len(vids), np.uint64)
+        self.lib.check(self.lib.L.dwx_graph_get_positions(self.h, vids.ctypes.data, len(vids), out.ctypes.data))
+        return out
 
     def values(self):
         base = np.zeros(self.info.num_variables, np.uint64)

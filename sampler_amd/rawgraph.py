@@ -39,6 +39,7 @@ class GraphDesc(C.Structure):
         ("fac_weight_id", C.c_void_p), ("fac_feature_value", C.c_void_p),
         ("edge_vid", C.c_void_p), ("edge_equal_to", C.c_void_p),
         ("w_initial_value", C.c_void_p), ("w_is_fixed", C.c_void_p),
+        ("num_ghost_variables", C.c_uint64),
     ]
 
 
@@ -68,6 +69,8 @@ class RawGraph:
     dom_offset: np.ndarray = field(default_factory=lambda: np.zeros(1, np.uint64))
     dom_value: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint64))
     dom_truthiness: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))
+    # sharding: the last num_ghost_variables variables are ghosts (remote, never sampled)
+    num_ghost_variables: int = 0
 
     def __post_init__(self):
         self.var_role = _col(self.var_role, np.uint8)
@@ -124,6 +127,7 @@ class RawGraph:
         d.num_edges = self.num_edges
         d.num_weights = self.num_weights
         d.num_domains = len(self.dom_vid)
+        d.num_ghost_variables = int(self.num_ghost_variables)
         for name in ("var_role", "var_init_value", "var_dtype", "var_cardinality",
                      "dom_vid", "dom_offset", "dom_value", "dom_truthiness",
                      "fac_func", "fac_edge_offset", "fac_weight_id", "fac_feature_value",

@@ -43,6 +43,14 @@ def main():
     assert np.array_equal(a.assignments("evid"), b.assignments("evid"))
     assert np.array_equal(a.tallies()[0], b.tallies()[0])
     assert int(eng.grad.abs().sum()) == 0       # apply cleared the accumulators
+    # halo plumbing: int32 views of the assignment buffers in device order
+    ev = eng.assign_tensor("evid")
+    pos = eng.positions(np.arange(10, dtype=np.uint64))
+    assert ev.dtype == torch.int32 and ev.numel() == 200_000
+    assert np.array_equal(ev[pos].cpu().numpy().astype(np.uint64), a.assignments("evid")[:10])
+    ev[pos] = 1 - ev[pos]                       # write through the view = what a halo scatter does
+    torch.cuda.synchronize()
+    assert np.array_equal(a.assignments("evid")[:10], 1 - b.assignments("evid")[:10])
     dist.destroy_process_group()
     print("gpu dist plumbing ok")
 

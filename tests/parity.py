@@ -51,7 +51,7 @@ def run_parity(lib, raw, n_learn=3, n_infer=5, stepsize=0.05, decay=0.9, seed=77
     if check_index:
         check_index_parity(g, o)
     order, off = g.schedule()
-    assert sorted(order.tolist()) == list(range(raw.num_variables))
+    assert sorted(order.tolist()) == list(range(raw.num_variables - raw.num_ghost_variables))
     assert o.sched_check_independent(order, off), "a launch is not an independent set"
     s = dwx.GibbsSampler(g, seed=seed, step_cap=step_cap, **kw)
     assert np.array_equal(s.assignments("free"), o.assignments("free"))
@@ -73,7 +73,7 @@ def run_parity(lib, raw, n_learn=3, n_infer=5, stepsize=0.05, decay=0.9, seed=77
         sweep += 1
         assert np.array_equal(s.assignments("evid"), o.assignments("evid")), "inference chain differs"
     t, n = s.tallies()
-    assert np.array_equal(t, o.tallies), "tallies differ"
+    assert np.array_equal(t, o.tallies[:len(t)]), "tallies differ"
     assert np.array_equal(n, o.nsamples), "nsamples differ"
     assert s.sweep == sweep
     return s, o

@@ -209,3 +209,10 @@ def test_ks_against_reference_live(lib):
     assert abs(z.var() - 1.0) < 5.0 * np.sqrt(2.0 / n) + 0.02
     assert stats.ks_normal(z[:: max(1, n // 1500)]) > 0.01
     assert stats.ks_two_sample(p_gpu, p_ref) > 0.01
+
+
+def test_ghost_variables_parity(lib):
+    """Shard-local graph with ghost variables (config 5b): see tests/test_kernels_emu.py."""
+    import test_kernels_emu as E
+    E.test_ghost_variables_parity.__wrapped__(lib) if hasattr(E.test_ghost_variables_parity, "__wrapped__") \
+        else E.test_ghost_variables_parity(lib)

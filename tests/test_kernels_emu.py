@@ -87,3 +87,35 @@ def test_learning_is_doing_something(lib):
     assert np.abs(s.weights).max() > 1e-3
     t, n = s.tallies()
     assert t.sum() > 0 and n.max() == 4
+
+
+def test_ghost_variables_parity(lib):
+    """A shard's local graph: ghost variables hold assignments (set from outside, as the
+    halo exchange does) but are never sampled; owned variables read them."""
+    from sampler_amd.shard import make_shard
+    raw = synthetic.cfg3b(600, n_weights=24, seed=21)
+    local, ghosts = make_shard(raw, 150, 420)
+    assert local.num_ghost_variables > 0
+    s, o = run_parity(lib, local, n_learn=0, n_infer=0)
+    rng = np.random.default_rng(0)
+    n_owned = local.num_variables - local.num_ghost_variables
+    order, off = s.graph.schedule()
+    sweep = 0
+    for it in range(4):
+        for chain in ("free", "evid"):     # "halo exchange": new ghost values on both sides
+            a = s.assignments(chain)
+            a[n_owned:] = rng.integers(0, 2, local.num_ghost_variables)
+            s.set_assignments(chain, a)
+            o.assignments(chain)[:] = a
+        if it % 2 == 0:
+            s.sample_sgd(0.05); s.wait()
+            o.sched_sample_sgd(order, off, 77, sweep, 0.05, 1.0)
+        else:
+            s.sample(); s.wait()
+            o.sched_sample(order, off, 77, sweep)
+        sweep += 1
+        assert np.array_equal(s.assignments("free"), o.assignments("free"))
+        assert np.array_equal(s.assignments("evid"), o.assignments("evid"))
+        np.testing.assert_allclose(s.weights, o.weights, rtol=1e-12, atol=1e-12)
+    t, n = s.tallies()
+    assert np.array_equal(t, o.tallies[:len(t)]) and (n[n_owned:] == 0).all()
