@@ -340,6 +340,11 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     P.lds_w_off = (uint32_t)off;
     s->lds_bytes[0] = off;
     s->lds_bytes[1] = off + slots * 4;
+    P.lds_agg_off = 0;
+    if (c.W > 0 && c.W <= LDS_AGG_MAX_W) {
+      P.lds_agg_off = (uint32_t)((s->lds_bytes[1] + 15) & ~(size_t)15);
+      s->lds_bytes[1] = P.lds_agg_off + (size_t)c.W * 16;
+    }
     if (s->lds_bytes[1] > 160 * 1024) throw std::invalid_argument("tile does not fit the 160 KiB LDS");
     auto prepare = [&](auto infer, auto learn) {
       rt::allow_dynamic_lds(infer, s->lds_bytes[0]);

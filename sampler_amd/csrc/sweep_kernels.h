@@ -167,6 +167,7 @@ struct TileView {
   const EdgeRec *edges;    // indexed by (edge - edge_bias)
   uint32_t edge_bias;
   const float *w;          // W_ARRAY: staged weights, indexed like edges
+  long long *agg;          // LDS gradient accumulators [2W] (learning, small W) or null
   double *pot;             // per-row potential scratch (row - row_bias), or null
 };
 
@@ -283,10 +284,13 @@ DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uin
     const double pot_free = edge_term<SIMPLE>(P, er, e, P.assign_free, me, free_value, free_value == hit_value);
     const double g = pot_free - pot_evid;
     const long long gi = llrint(FIX_SCALE * (t * g));
-    if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
-    if (COUNT_T) {
-      const long long ti = llrint(FIX_SCALE * t);
-      atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)ti);
+    const long long ti = COUNT_T ? llrint(FIX_SCALE * t) : 0;
+    if (T.agg) {   // workgroup-local accumulation in LDS (few, heavily shared weights)
+      if (gi) atomicAdd((unsigned long long *)&T.agg[er.wid], (unsigned long long)gi);
+      if (COUNT_T) atomicAdd((unsigned long long *)&T.agg[P.num_weights + er.wid], (unsigned long long)ti);
+    } else {
+      if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
+      if (COUNT_T) atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)ti);
     }
   }
 }
@@ -488,6 +492,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelPar
   double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
   EdgeRec *s_edges = (EdgeRec *)(dyn_lds + P.lds_edge_off);
   float *s_w = (float *)(dyn_lds + P.lds_w_off);
+  long long *s_agg = (LEARN && P.lds_agg_off) ? (long long *)(dyn_lds + P.lds_agg_off) : nullptr;
   const uint32_t t = threadIdx.x;
   constexpr int WMODE = LEARN ? W_ARRAY : W_INRECORD;
   uint32_t tile = P.tile_begin + blockIdx.x;
@@ -499,6 +504,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelPar
   TileDesc dn = scalarise(P.tiles[has_next ? next : tile]);   // one descriptor ahead
   TilePrefetch<K> f;
   issue_tile_loads<LEARN, K>(P, d, t, f);
+  if (s_agg) {   // the first __syncthreads of the loop orders this before any use
+    for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) s_agg[i] = 0;
+  }
   for (;;) {
     const bool fits = tile_fits(P, d);   // workgroup-uniform
     const VarPre pre = f.pre;
@@ -556,7 +564,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelPar
     issue_tile_loads<LEARN, K>(P, dl, t, f);
     // process the current tile out of LDS
     if (fits && t < d.nv) {
-      TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, P.lds_pot_off ? s_pot : nullptr};
+      TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
       if (d.flags & TILE_SIMPLE)
         process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B);
       else
@@ -568,6 +576,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelPar
     dn = scalarise(raw_nn);
     tile = next; next = nn; has_next = has_nn;
   }
+  if (s_agg) {   // one flush per persistent workgroup
+    __syncthreads();
+    for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) {
+      const long long v = s_agg[i];
+      if (v) atomicAdd((unsigned long long *)&P.grad[i], (unsigned long long)v);
+    }
+  }
 }
 
 // Variables too big for one tile (rows > rcap or edge records > ecap): one lane per
@@ -578,7 +593,7 @@ __global__ void __launch_bounds__(64) giant_kernel(const KernelParams P, const u
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const TileDesc d = P.tiles[giant_tiles[i]];
-  TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr};
+  TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr, nullptr};
   for (uint32_t p = d.v0; p < d.v0 + d.nv; ++p) {
     const VarPre vp = load_var_pre<LEARN>(P, p);
     double A, B;

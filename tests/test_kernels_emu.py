@@ -119,3 +119,11 @@ def test_ghost_variables_parity(lib):
         np.testing.assert_allclose(s.weights, o.weights, rtol=1e-12, atol=1e-12)
     t, n = s.tallies()
     assert np.array_equal(t, o.tallies[:len(t)]) and (n[n_owned:] == 0).all()
+
+
+def test_many_weights_global_atomics_path(lib):
+    # W > LDS_AGG_MAX_W (1024): gradients go straight to memory-side atomics; the small-W
+    # tests above all take the per-workgroup LDS accumulators
+    s, _ = run_parity(lib, synthetic.cfg3(3000, n_weights=1500, seed=12), n_learn=4, n_infer=2)
+    assert s.graph.info.num_weights == 1500
+    run_parity(lib, synthetic.cfg4(400, card=6, seed=13, learn=True), n_learn=4, n_infer=2, stepsize=0.01)
