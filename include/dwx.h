@@ -194,7 +194,8 @@ int dwx_stream(dwx_sampler *s, void **stream);
 
 /* Device time of the sweep kernels only, measured with HIP events on the sampler's
  * stream around every launch since the last reset: total milliseconds, number of
- * kernel launches and number of sweeps.  kind: 0 = inference, 1 = learning. */
+ * kernel launches and number of sweeps.  kind: 0 = inference sweep kernels, 1 = learning
+ * sweep kernels, 2 = the pull-based gradient kernel of learning sweeps. */
 int dwx_kernel_time(dwx_sampler *s, int kind, double *ms, uint64_t *launches, uint64_t *sweeps);
 int dwx_kernel_time_reset(dwx_sampler *s, int enable);
 

@@ -60,6 +60,11 @@ struct alignas(16) TileDesc {
 // the compute phase then needs no global load at all (everything it reads was staged)
 constexpr uint32_t TILE_SIMPLE = 1u << 0;
 constexpr uint32_t TILE_CATEGORICAL = 1u << 1;   // the tile's variables are categorical
+// Learning, all-unary boolean tile of a graph with many weights: instead of scattering
+// gradient atomics, the sweep records per variable whether (and with which sign) its two
+// chains disagree -- two wave-ballot bit-planes -- and pull_grad_kernel gathers those bits
+// through a weight-sorted incidence list.
+constexpr uint32_t TILE_PULL = 1u << 2;
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
 
 // v_meta bits
@@ -86,6 +91,7 @@ constexpr uint32_t MAX_ECAP = BLOCK_THREADS * STAGE_UNROLL;  // 3072 records = 4
 // handful of addresses serialise (14x slower per the MI355X guide), so each persistent
 // workgroup accumulates G/T in LDS and flushes once at the end.
 constexpr uint32_t LDS_AGG_MAX_W = 1024;
+constexpr uint32_t PULL_RUN = 16;                           // incidence entries per lane
 constexpr uint32_t ROWPTR_UNROLL = 2;                       // row pointers prefetched per lane
 
 // Everything one sweep launch needs; passed by value.
@@ -108,6 +114,7 @@ struct KernelParams {
   const float *w32;           // [W] sampling copy of the weights, rounded to f32 (fits L2)
   const uint8_t *w_fixed;     // [W]
   long long *grad;            // [2W]: G then T (fixed point)
+  unsigned long long *delta;  // [n_tiles*4*2] per wave: {chains disagree, free < evid} ballots
   // launch
   uint64_t seed, sweep;
   uint64_t vid_offset;        // global id of local variable 0 (Philox counter)

@@ -58,9 +58,10 @@ T *upload(const std::vector<T> &v, rt::stream_t s, size_t pad = 0) {
 }
 
 struct TimedSpan {
-  rt::event_t a, b;
+  rt::event_t a, b, c;   // a..b: sweep kernels of all colours; b..c: pull_grad_kernel (learning)
   int kind;
   uint32_t launches;
+  bool has_pull;
 };
 }  // namespace
 
@@ -87,6 +88,11 @@ struct dwx_sampler {
   double *d_weights = nullptr;
   float *d_w32 = nullptr;
   long long *d_t_static = nullptr;
+  // pull-based gradient (TILE_PULL tiles)
+  unsigned long long *d_delta = nullptr;
+  uint32_t *d_inc_wid = nullptr, *d_inc_slot = nullptr;
+  float *d_inc_d = nullptr;
+  uint32_t n_inc = 0;
   uint8_t *d_w_fixed = nullptr;
   long long *d_grad = nullptr;
   KernelParams base{};
@@ -96,15 +102,16 @@ struct dwx_sampler {
   // kernel timing
   bool timing = false;
   std::vector<TimedSpan> spans;
-  double t_ms[2] = {0, 0};
-  uint64_t t_launches[2] = {0, 0}, t_sweeps[2] = {0, 0};
+  double t_ms[3] = {0, 0, 0};   // [0] inference sweep kernels, [1] learning sweep kernels, [2] pull_grad
+  uint64_t t_launches[3] = {0, 0, 0}, t_sweeps[3] = {0, 0, 0};
 
   ~dwx_sampler() {
-    for (auto &sp : spans) { rt::event_destroy(sp.a); rt::event_destroy(sp.b); }
+    for (auto &sp : spans) { rt::event_destroy(sp.a); rt::event_destroy(sp.b); rt::event_destroy(sp.c); }
     rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
     rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
     rt::dfree(d_edges); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
-    rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_t_static); rt::dfree(d_w_fixed); rt::dfree(d_grad);
+    rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_t_static); rt::dfree(d_delta); rt::dfree(d_inc_wid);
+    rt::dfree(d_inc_slot); rt::dfree(d_inc_d); rt::dfree(d_w_fixed); rt::dfree(d_grad);
     if (stream) rt::stream_destroy(stream);
   }
 };
@@ -150,9 +157,21 @@ void enqueue_sweep(dwx_sampler *s) {
       ++launches;
     }
   }
+  if (s->timing) rt::event_record(sp.b, s->stream);
+  bool pulled = false;
+  if (LEARN && s->n_inc) {
+    const unsigned chunk = BLOCK_THREADS * PULL_RUN;
+    const unsigned grid = std::min<unsigned>((s->n_inc + chunk - 1) / chunk, 256u * 8u);
+    rt::launch(pull_grad_kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)s->d_inc_wid,
+               (const uint32_t *)s->d_inc_slot, (const float *)s->d_inc_d, s->n_inc,
+               (const unsigned long long *)s->d_delta, s->d_grad);
+    pulled = true;
+  }
   if (s->timing) {
-    rt::event_record(sp.b, s->stream);
+    sp.c = rt::event_create();
+    rt::event_record(sp.c, s->stream);
     sp.launches = launches;
+    sp.has_pull = pulled;
     s->spans.push_back(sp);
   }
   ++s->sweep;
@@ -165,7 +184,12 @@ void drain_spans(dwx_sampler *s) {
     s->t_ms[sp.kind] += rt::event_elapsed_ms(sp.a, sp.b);
     s->t_launches[sp.kind] += sp.launches;
     s->t_sweeps[sp.kind] += 1;
-    rt::event_destroy(sp.a); rt::event_destroy(sp.b);
+    if (sp.has_pull) {
+      s->t_ms[2] += rt::event_elapsed_ms(sp.b, sp.c);
+      s->t_launches[2] += 1;
+      s->t_sweeps[2] += 1;
+    }
+    rt::event_destroy(sp.a); rt::event_destroy(sp.b); rt::event_destroy(sp.c);
   }
   s->spans.clear();
 }
@@ -308,6 +332,49 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
           if (!c.w_fixed[c.edges[e].wid]) ts[c.edges[e].wid] += one;
       }
       s->d_t_static = upload(ts, st);
+      // Incidence list of the pull-based gradient: every (SGD-triggering variable of a
+      // TILE_PULL tile, non-fixed record) pair, counting-sorted by weight id.
+      std::vector<uint32_t> cnt(c.W + 1, 0);
+      auto for_each_pull_record = [&](auto &&fn) {
+        for (size_t ti = 0; ti < c.tiles.size(); ++ti) {
+          const TileDesc &td = c.tiles[ti];
+          if (!(td.flags & TILE_PULL)) continue;
+          if (td.nrows > c.rcap || td.nedges > c.ecap) continue;   // oversized: giant_kernel, atomics
+          for (uint32_t l = 0; l < td.nv; ++l) {
+            const uint32_t p = td.v0 + l, m = c.v_meta[p];
+            const bool trig = opts->learn_non_evidence || (!opts->noise_aware && (m & VM_EVIDENCE));
+            if (!trig) continue;
+            for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p] + 1]; ++e) {
+              const EdgeRec &r = c.edges[e];
+              if (r.packed & EDGE_FIXED_FLAG) continue;
+              float miss;
+              std::memcpy(&miss, &r.aux, 4);
+              const float dd = r.fval - miss;    // exact: |hit| == |miss| or one of them is 0
+              if (dd == 0.0f) continue;
+              fn(r.wid, (uint32_t)(ti * BLOCK_THREADS + l), dd);
+            }
+          }
+        }
+      };
+      for_each_pull_record([&](uint32_t wid, uint32_t, float) { ++cnt[wid + 1]; });
+      for (uint64_t i = 0; i < c.W; ++i) cnt[i + 1] += cnt[i];
+      const uint64_t n_inc = cnt[c.W];
+      if (n_inc >= 0xFFFFFFFFull) throw std::invalid_argument("incidence list exceeds 2^32-1 entries");
+      s->n_inc = (uint32_t)n_inc;
+      if (n_inc) {
+        std::vector<uint32_t> iw(n_inc), is(n_inc);
+        std::vector<float> id(n_inc);
+        std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+        for_each_pull_record([&](uint32_t wid, uint32_t slot, float dd) {
+          const uint32_t at = cur[wid]++;
+          iw[at] = wid; is[at] = slot; id[at] = dd;
+        });
+        s->d_inc_wid = upload(iw, st);
+        s->d_inc_slot = upload(is, st);
+        s->d_inc_d = upload(id, st);
+      }
+      s->d_delta = (unsigned long long *)rt::dmalloc((c.tiles.size() * 8 + 2) * 8);
+      rt::dmemset(s->d_delta, 0, (c.tiles.size() * 8 + 2) * 8, st);
     }
     s->d_w_fixed = upload(c.w_fixed, st);
     s->d_grad = (long long *)rt::dmalloc(c.W * 16);
@@ -318,7 +385,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     P.row_ptr = s->d_row_ptr; P.row_truth = s->d_row_truth; P.edges = s->d_edges;
     P.edge_fval64 = s->d_edge_fval64; P.vifs = s->d_vifs; P.tiles = s->d_tiles;
     P.assign_free = s->d_assign_free; P.assign_evid = s->d_assign_evid; P.tally = s->d_tally;
-    P.w32 = s->d_w32; P.w_fixed = s->d_w_fixed; P.grad = s->d_grad;
+    P.w32 = s->d_w32; P.w_fixed = s->d_w_fixed; P.grad = s->d_grad; P.delta = s->d_delta;
     P.seed = opts->seed; P.sweep = 0; P.vid_offset = opts->var_id_offset; P.tile_begin = 0; P.num_weights = (uint32_t)c.W;
     P.flags = (opts->sample_evidence ? OPT_SAMPLE_EVIDENCE : 0) |
               (opts->learn_non_evidence ? OPT_LEARN_NON_EVIDENCE : 0) |
@@ -530,13 +597,13 @@ int dwx_kernel_time_reset(dwx_sampler *s, int enable) {
   return guarded([&]() {
     rt::set_device(s->device);
     drain_spans(s);
-    for (int k = 0; k < 2; ++k) { s->t_ms[k] = 0; s->t_launches[k] = 0; s->t_sweeps[k] = 0; }
+    for (int k = 0; k < 3; ++k) { s->t_ms[k] = 0; s->t_launches[k] = 0; s->t_sweeps[k] = 0; }
     s->timing = enable != 0;
   });
 }
 
 int dwx_kernel_time(dwx_sampler *s, int kind, double *ms, uint64_t *launches, uint64_t *sweeps) {
-  if (!s || kind < 0 || kind > 1) return fail(DWX_E_INVALID, "bad argument");
+  if (!s || kind < 0 || kind > 2) return fail(DWX_E_INVALID, "bad argument");
   return guarded([&]() {
     rt::set_device(s->device);
     drain_spans(s);

@@ -468,7 +468,9 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       bool simple = true;
       for (uint32_t e = t.e0; e < t.e0 + t.nedges && simple; ++e)
         simple = (g.edges[e].packed & EDGE_PRESIGNED) != 0;
-      t.flags = (simple ? TILE_SIMPLE : 0u) | ((g.v_meta[v0] & VM_CATEGORICAL) ? TILE_CATEGORICAL : 0u);
+      const bool cat = g.v_meta[v0] & VM_CATEGORICAL;
+      t.flags = (simple ? TILE_SIMPLE : 0u) | (cat ? TILE_CATEGORICAL : 0u) |
+                ((simple && !cat && W > LDS_AGG_MAX_W) ? TILE_PULL : 0u);
       g.tiles[i] = t;
     }
     g.giant_tiles.clear(); g.launch_giant.clear(); g.launch_giant_query_end.clear();

@@ -313,9 +313,11 @@ DWX_DEV VarPre load_var_pre(const KernelParams &P, uint32_t p) {
   return v;
 }
 
+// `delta` (learning, TILE_PULL tiles only): receives hit(free) - hit(evid) in {-1,0,+1} for
+// a variable that triggers SGD, instead of the gradient atomics.
 template <bool LEARN, int WMODE, bool SIMPLE>
 DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t p,
-                              const VarPre pre, double A, double B) {
+                              const VarPre pre, double A, double B, int *delta = nullptr) {
   const uint32_t meta = pre.meta;
   const bool is_cat = meta & VM_CATEGORICAL;
   const bool is_evid = meta & VM_EVIDENCE;
@@ -383,6 +385,7 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
     // a pre-signed record's gradient is (free hits ? A : B) - (evid hits ? A : B): zero
     // for the whole row when both chains agree (update counts are static, T_static)
     if (SIMPLE && p_free == evid_value) return;
+    if (SIMPLE && delta) { *delta = (int)p_free - (int)evid_value; return; }
     sgd_row<false, SIMPLE>(P, T, row0, p, evid_value, p_free, 1u, 1.0);
     return;
   }
@@ -447,6 +450,9 @@ struct TilePrefetch {
 // load of the descriptor two tiles ahead can stay in flight across a whole tile.
 #ifndef DWX_UNIFORM
 #define DWX_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#endif
+#ifndef DWX_BALLOT
+#define DWX_BALLOT(pred) ((unsigned long long)__ballot(pred))
 #endif
 DWX_DEV TileDesc scalarise(const TileDesc &v) {
   TileDesc d;
@@ -563,12 +569,24 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelPar
     if (!has_next) { dl.nedges = 0; dl.nrows = 0; dl.nv = 1; }
     issue_tile_loads<LEARN, K>(P, dl, t, f);
     // process the current tile out of LDS
+    const bool pull = LEARN && fits && (d.flags & TILE_PULL);   // workgroup-uniform
+    int delta = 0;
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
       if (d.flags & TILE_SIMPLE)
-        process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B);
+        process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B,
+                                                                  pull ? &delta : nullptr);
       else
         process_variable<LEARN, WMODE, false>(P, T, d.v0 + t, pre, A, B);
+    }
+    if (pull) {
+      // every wave of the tile publishes its two ballots (also when all zero: the words
+      // are rewritten each learning sweep, so nothing needs clearing)
+      const unsigned long long nz = DWX_BALLOT(delta != 0), ng = DWX_BALLOT(delta < 0);
+      if ((t & 63u) == 0) {
+        unsigned long long *w = P.delta + ((size_t)tile * 4 + (t >> 6)) * 2;
+        w[0] = nz; w[1] = ng;
+      }
     }
     if (!has_next) break;
     __syncthreads();   // LDS is rewritten by the next iteration
@@ -599,6 +617,65 @@ __global__ void __launch_bounds__(64) giant_kernel(const KernelParams P, const u
     double A, B;
     philox_uniforms(P.seed, P.vid_offset + vp.orig, P.sweep, A, B);
     process_variable<LEARN, W_GLOBAL, false>(P, T, p, vp, A, B);
+  }
+}
+
+// Pull-based weight gradient for TILE_PULL tiles (replaces their gradient atomics).
+// inc_* is the incidence list of every (triggering boolean variable, non-fixed record)
+// pair, SORTED BY WEIGHT: inc_wid[i], inc_slot[i] = tile * 256 + lane of the owning
+// variable, inc_d[i] = sign(hit)*f - sign(miss)*f of the record (f32-exact).  The
+// record's gradient is delta(owner) * inc_d, delta in {-1, 0, +1} read from the ballot
+// bit-planes the sweep wrote (2 bits per variable: L2-resident).  A workgroup stages
+// 256 * PULL_RUN entries' contributions in LDS (coalesced loads), then every lane sums its
+// PULL_RUN consecutive entries and flushes one atomic per weight run -- neighbouring
+// lanes hit neighbouring weights.  Integer sums: the result is independent of the order
+// and identical to what the per-record atomics would have produced.
+__global__ void __launch_bounds__(BLOCK_THREADS)
+pull_grad_kernel(const uint32_t *inc_wid, const uint32_t *inc_slot, const float *inc_d,
+                 uint32_t n, const unsigned long long *delta, long long *grad) {
+  __shared__ long long s_val[BLOCK_THREADS * (PULL_RUN + 1)];
+  __shared__ uint32_t s_key[BLOCK_THREADS * (PULL_RUN + 1)];
+  const uint32_t t = threadIdx.x;
+  const uint32_t chunk = BLOCK_THREADS * PULL_RUN;
+  for (uint32_t base = blockIdx.x * chunk; base < n; base += gridDim.x * chunk) {
+#pragma unroll
+    for (uint32_t k = 0; k < PULL_RUN; ++k) {
+      const uint32_t j = t + k * BLOCK_THREADS;     // position in the chunk
+      const uint32_t i = base + j;
+      long long v = 0;
+      uint32_t key = 0xFFFFFFFFu;
+      if (i < n) {
+        const uint32_t slot = inc_slot[i];
+        const unsigned long long nz = delta[(size_t)(slot >> 6) * 2], ng = delta[(size_t)(slot >> 6) * 2 + 1];
+        const unsigned long long bit = 1ull << (slot & 63u);
+        key = inc_wid[i];
+        if (nz & bit) {
+          const long long q = llrint(FIX_SCALE * (double)inc_d[i]);
+          v = (ng & bit) ? -q : q;
+        }
+      }
+      const uint32_t at = j + j / PULL_RUN;          // pad: lane stride PULL_RUN + 1
+      s_val[at] = v;
+      s_key[at] = key;
+    }
+    __syncthreads();
+    {
+      const uint32_t at0 = t * (PULL_RUN + 1);
+      uint32_t key = s_key[at0];
+      long long acc = s_val[at0];
+      for (uint32_t k = 1; k < PULL_RUN; ++k) {
+        const uint32_t kk = s_key[at0 + k];
+        const long long vv = s_val[at0 + k];
+        if (kk != key) {
+          if (acc && key != 0xFFFFFFFFu) atomicAdd((unsigned long long *)&grad[key], (unsigned long long)acc);
+          key = kk; acc = vv;
+        } else {
+          acc += vv;
+        }
+      }
+      if (acc && key != 0xFFFFFFFFu) atomicAdd((unsigned long long *)&grad[key], (unsigned long long)acc);
+    }
+    __syncthreads();
   }
 }
 

@@ -62,6 +62,18 @@ void entry() {
 
 void syncthreads() { to_sched(false); }
 
+unsigned long long ballot(bool pred) {
+  static unsigned char preds[1024];
+  preds[threadIdx_.x] = pred ? 1 : 0;
+  syncthreads();
+  const unsigned w0 = threadIdx_.x & ~63u;
+  unsigned long long m = 0;
+  for (unsigned i = 0; i < 64 && w0 + i < blockDim_.x; ++i)
+    if (preds[w0 + i]) m |= 1ull << i;
+  syncthreads();
+  return m;
+}
+
 void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::function<void()> &body) {
   if (g_fibers.size() < block) {
     size_t old = g_fibers.size();

@@ -25,6 +25,8 @@ namespace emu {
 extern dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
 extern unsigned char *g_lds;
 void syncthreads();
+// wave64 ballot; must be reached by every thread of the workgroup
+unsigned long long ballot(bool pred);
 // run `body` once per (block, thread) of the grid, blocks sequentially
 void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::function<void()> &body);
 }  // namespace emu
@@ -42,6 +44,8 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::functi
 #define DWX_DEV inline
 #define DWX_DYN_LDS(name) unsigned char *name = ::emu::g_lds
 #define DWX_HOST_EMU 1
+#define __shared__ static
+#define DWX_BALLOT(pred) (::emu::ballot(pred))
 #define DWX_UNIFORM(x) (x)
 
 inline void __syncthreads() { ::emu::syncthreads(); }

@@ -127,3 +127,8 @@ def test_many_weights_global_atomics_path(lib):
     s, _ = run_parity(lib, synthetic.cfg3(3000, n_weights=1500, seed=12), n_learn=4, n_infer=2)
     assert s.graph.info.num_weights == 1500
     run_parity(lib, synthetic.cfg4(400, card=6, seed=13, learn=True), n_learn=4, n_infer=2, stepsize=0.01)
+    # pairwise factors + many weights: mixed pull tiles / direct global atomics
+    s, _ = run_parity(lib, synthetic.cfg3b(2500, n_weights=1400, seed=14), n_learn=4, n_infer=2)
+    from randgraph import random_graph
+    run_parity(lib, random_graph(5, V=900, F=5000, W=1300), n_learn=4, n_infer=2, stepsize=0.05,
+               learn_non_evidence=True)
