@@ -147,6 +147,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     ms_i, nl_i, ns_i = sampler.kernel_time("infer")
     ms_l, nl_l, ns_l = sampler.kernel_time("learn")
+    ms_p, nl_p, ns_p = sampler.kernel_time("pull")
     sampler.kernel_time_reset(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -200,6 +201,7 @@ def main():
             "infer_vars_per_sec": V * n_gpus / (ms_i / max(ns_i, 1) * 1e-3) if ns_i else None,
             "learn_vars_per_sec": V * n_gpus / (ms_l / max(ns_l, 1) * 1e-3) if ns_l else None,
             "infer_kernel_ms": ms_i / max(nl_i, 1), "learn_kernel_ms": ms_l / max(nl_l, 1),
+            "pull_grad_kernel_ms": (ms_p / nl_p) if nl_p else None,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:

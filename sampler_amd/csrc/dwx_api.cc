@@ -161,7 +161,7 @@ void enqueue_sweep(dwx_sampler *s) {
   bool pulled = false;
   if (LEARN && s->n_inc) {
     const unsigned chunk = BLOCK_THREADS * PULL_RUN;
-    const unsigned grid = std::min<unsigned>((s->n_inc + chunk - 1) / chunk, 256u * 8u);
+    const unsigned grid = std::min<unsigned>((s->n_inc + chunk - 1) / chunk, 256u * 16u);
     rt::launch(pull_grad_kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)s->d_inc_wid,
                (const uint32_t *)s->d_inc_slot, (const float *)s->d_inc_d, s->n_inc,
                (const unsigned long long *)s->d_delta, s->d_grad);
@@ -369,6 +369,9 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
           const uint32_t at = cur[wid]++;
           iw[at] = wid; is[at] = slot; id[at] = dd;
         });
+        // pad to a whole run with neutral entries (same weight as the last one, zero
+        // gradient contribution), so the kernel's 16-byte loads never leave the arrays
+        while (iw.size() % PULL_RUN) { iw.push_back(iw.back()); is.push_back(is.back()); id.push_back(0.0f); }
         s->d_inc_wid = upload(iw, st);
         s->d_inc_slot = upload(is, st);
         s->d_inc_d = upload(id, st);

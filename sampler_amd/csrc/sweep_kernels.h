@@ -630,52 +630,54 @@ __global__ void __launch_bounds__(64) giant_kernel(const KernelParams P, const u
 // PULL_RUN consecutive entries and flushes one atomic per weight run -- neighbouring
 // lanes hit neighbouring weights.  Integer sums: the result is independent of the order
 // and identical to what the per-record atomics would have produced.
+struct alignas(16) DeltaPair { unsigned long long nz, ng; };
+struct alignas(16) U32x4 { uint32_t v[4]; };
+struct alignas(16) F32x4 { float v[4]; };
+
+// One lane owns PULL_RUN consecutive entries (a multiple of 4: 16-byte loads straight
+// from HBM; a wave covers one contiguous 4 KiB span per array, every line is consumed
+// fully across the lane's loads), gathers their owners' bits (one 16-byte L2 hit each,
+// all in flight), sums per weight run in registers and flushes one atomic per run.
+// No LDS, no barrier.
 __global__ void __launch_bounds__(BLOCK_THREADS)
 pull_grad_kernel(const uint32_t *inc_wid, const uint32_t *inc_slot, const float *inc_d,
                  uint32_t n, const unsigned long long *delta, long long *grad) {
-  __shared__ long long s_val[BLOCK_THREADS * (PULL_RUN + 1)];
-  __shared__ uint32_t s_key[BLOCK_THREADS * (PULL_RUN + 1)];
-  const uint32_t t = threadIdx.x;
-  const uint32_t chunk = BLOCK_THREADS * PULL_RUN;
-  for (uint32_t base = blockIdx.x * chunk; base < n; base += gridDim.x * chunk) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t n_runs = (n + PULL_RUN - 1) / PULL_RUN;   // arrays are padded to a full run
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += stride) {
+    const uint32_t i0 = r * PULL_RUN;
+    uint32_t key[PULL_RUN], slot[PULL_RUN];
+    float dd[PULL_RUN];
+#pragma unroll
+    for (uint32_t k = 0; k < PULL_RUN / 4; ++k) {
+      const U32x4 a = ((const U32x4 *)(inc_wid + i0))[k];
+      const U32x4 b = ((const U32x4 *)(inc_slot + i0))[k];
+      const F32x4 c = ((const F32x4 *)(inc_d + i0))[k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { key[4 * k + j] = a.v[j]; slot[4 * k + j] = b.v[j]; dd[4 * k + j] = c.v[j]; }
+    }
+    DeltaPair dp[PULL_RUN];
+#pragma unroll
+    for (uint32_t k = 0; k < PULL_RUN; ++k) dp[k] = ((const DeltaPair *)delta)[slot[k] >> 6];
+    uint32_t cur = key[0];
+    long long acc = 0;
 #pragma unroll
     for (uint32_t k = 0; k < PULL_RUN; ++k) {
-      const uint32_t j = t + k * BLOCK_THREADS;     // position in the chunk
-      const uint32_t i = base + j;
+      const unsigned long long bit = 1ull << (slot[k] & 63u);
       long long v = 0;
-      uint32_t key = 0xFFFFFFFFu;
-      if (i < n) {
-        const uint32_t slot = inc_slot[i];
-        const unsigned long long nz = delta[(size_t)(slot >> 6) * 2], ng = delta[(size_t)(slot >> 6) * 2 + 1];
-        const unsigned long long bit = 1ull << (slot & 63u);
-        key = inc_wid[i];
-        if (nz & bit) {
-          const long long q = llrint(FIX_SCALE * (double)inc_d[i]);
-          v = (ng & bit) ? -q : q;
-        }
+      if (dp[k].nz & bit) {
+        const long long q = llrint(FIX_SCALE * (double)dd[k]);
+        v = (dp[k].ng & bit) ? -q : q;
       }
-      const uint32_t at = j + j / PULL_RUN;          // pad: lane stride PULL_RUN + 1
-      s_val[at] = v;
-      s_key[at] = key;
-    }
-    __syncthreads();
-    {
-      const uint32_t at0 = t * (PULL_RUN + 1);
-      uint32_t key = s_key[at0];
-      long long acc = s_val[at0];
-      for (uint32_t k = 1; k < PULL_RUN; ++k) {
-        const uint32_t kk = s_key[at0 + k];
-        const long long vv = s_val[at0 + k];
-        if (kk != key) {
-          if (acc && key != 0xFFFFFFFFu) atomicAdd((unsigned long long *)&grad[key], (unsigned long long)acc);
-          key = kk; acc = vv;
-        } else {
-          acc += vv;
-        }
+      if (key[k] != cur) {
+        if (acc) atomicAdd((unsigned long long *)&grad[cur], (unsigned long long)acc);
+        cur = key[k];
+        acc = v;
+      } else {
+        acc += v;
       }
-      if (acc && key != 0xFFFFFFFFu) atomicAdd((unsigned long long *)&grad[key], (unsigned long long)acc);
     }
-    __syncthreads();
+    if (acc) atomicAdd((unsigned long long *)&grad[cur], (unsigned long long)acc);
   }
 }
 
