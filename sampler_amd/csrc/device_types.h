@@ -24,7 +24,8 @@ struct alignas(16) EdgeRec {
   uint32_t aux;     // arity >= 2: base index into vifs[]; arity == 1: dense equal_to of
                     // the (only) predicate, or -- EDGE_PRESIGNED -- the miss value
   uint32_t packed;  // bits 0-3 func id, bit 4: feature value needs the f64 side
-                    // array, bit 5: weight is fixed, bits 8-31 arity
+                    // array, bit 5: weight is fixed, bit 6: pre-signed, bits 8-23
+                    // arity, bits 24-31 lane of the owning variable within its tile
   float fval;       // feature value (exact when bit 4 is clear)
 };
 static_assert(sizeof(EdgeRec) == 16, "EdgeRec must be 16 bytes");
@@ -37,8 +38,10 @@ constexpr uint32_t EDGE_FIXED_FLAG = 1u << 5;   // the record's weight is fixed 
 // a boolean owner hit means "proposal == 1" and for a categorical owner "proposal ==
 // the value of the row the record sits in" (exact: signs are -1, 0 or +1).
 constexpr uint32_t EDGE_PRESIGNED = 1u << 6;
-constexpr uint32_t EDGE_ARITY_SHIFT = 8;
-constexpr uint32_t MAX_ARITY = (1u << 24) - 1;
+constexpr uint32_t EDGE_ARITY_SHIFT = 8;      // bits 8-23: arity
+constexpr uint32_t EDGE_ARITY_MASK = 0xFFFFu;
+constexpr uint32_t EDGE_OWNER_SHIFT = 24;     // bits 24-31: lane of the owning variable in its tile
+constexpr uint32_t MAX_ARITY = EDGE_ARITY_MASK;
 
 // factor -> variable entry (src/variable.h:154-167), 8 bytes, device variable ids
 struct alignas(8) VifRec {
@@ -65,6 +68,10 @@ constexpr uint32_t TILE_CATEGORICAL = 1u << 1;   // the tile's variables are cat
 // chains disagree -- two wave-ballot bit-planes -- and pull_grad_kernel gathers those bits
 // through a weight-sorted incidence list.
 constexpr uint32_t TILE_PULL = 1u << 2;
+// Boolean tile whose every record is pre-signed or a factor of arity 2: an inference sweep
+// evaluates all records edge-parallel in the staging pass (batched vif-pair loads, then
+// batched neighbour gathers) and stages potential terms, as for TILE_SIMPLE.
+constexpr uint32_t TILE_TERMS2 = 1u << 3;
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
 
 // v_meta bits

@@ -360,7 +360,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       if (nvif >= kUnset) throw LimitError("vif entries exceed 2^32-1");
     }
     g.NVif = nvif;
-    g.vifs.resize(nvif);
+    g.vifs.resize(nvif + 2);   // + 2 padding entries: branch-free pair loads of non-binary records
     parallel_ranges(F, nth, [&](uint64_t fb, uint64_t fe) {
       for (uint64_t f = fb; f < fe; ++f) {
         uint64_t lo = d.fac_edge_offset[f], hi = d.fac_edge_offset[f + 1];
@@ -465,12 +465,21 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       t.v0 = v0; t.nv = v1 - v0;
       t.r0 = g.v_row[v0]; t.nrows = g.v_row[v1] - g.v_row[v0];
       t.e0 = g.row_ptr[g.v_row[v0]]; t.nedges = g.row_ptr[g.v_row[v1]] - g.row_ptr[g.v_row[v0]];
-      bool simple = true;
-      for (uint32_t e = t.e0; e < t.e0 + t.nedges && simple; ++e)
-        simple = (g.edges[e].packed & EDGE_PRESIGNED) != 0;
+      bool simple = true, terms2 = true;
+      for (uint32_t e = t.e0; e < t.e0 + t.nedges; ++e) {
+        const uint32_t pk = g.edges[e].packed;
+        const bool pre = (pk & EDGE_PRESIGNED) != 0;
+        simple = simple && pre;
+        terms2 = terms2 && (pre || (((pk >> EDGE_ARITY_SHIFT) & EDGE_ARITY_MASK) == 2 && !(pk & EDGE_F64_FLAG)));
+      }
       const bool cat = g.v_meta[v0] & VM_CATEGORICAL;
       t.flags = (simple ? TILE_SIMPLE : 0u) | (cat ? TILE_CATEGORICAL : 0u) |
-                ((simple && !cat && W > LDS_AGG_MAX_W) ? TILE_PULL : 0u);
+                ((simple && !cat && W > LDS_AGG_MAX_W) ? TILE_PULL : 0u) |
+                ((terms2 && !simple && !cat && t.nv <= 256) ? TILE_TERMS2 : 0u);
+      // every record learns the lane of its owning variable inside the tile
+      for (uint32_t l = 0; l < t.nv; ++l)
+        for (uint32_t e = g.row_ptr[g.v_row[v0 + l]]; e < g.row_ptr[g.v_row[v0 + l + 1]]; ++e)
+          g.edges[e].packed = (g.edges[e].packed & 0x00FFFFFFu) | ((l & 0xFFu) << EDGE_OWNER_SHIFT);
       g.tiles[i] = t;
     }
     g.giant_tiles.clear(); g.launch_giant.clear(); g.launch_giant_query_end.clear();

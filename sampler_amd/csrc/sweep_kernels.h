@@ -101,6 +101,20 @@ DWX_DEV double unary_sign(uint32_t func, bool s) {
   }
 }
 
+// binary factor from its two satisfied bits (a = first predicate, b = second / head)
+DWX_DEV double binary_sign(uint32_t func, bool a, bool b) {
+  switch (func) {
+    case FUNC_AND: case FUNC_ISTRUE: return (a && b) ? 1.0 : -1.0;
+    case FUNC_AND_CATEGORICAL: return (a && b) ? 1.0 : 0.0;
+    case FUNC_OR: return (a || b) ? 1.0 : -1.0;
+    case FUNC_EQUAL: return (a == b) ? 1.0 : -1.0;
+    case FUNC_IMPLY_NATURAL: return !a ? 0.0 : (b ? 1.0 : -1.0);
+    case FUNC_IMPLY_MLN: return !a ? 1.0 : (b ? 1.0 : 0.0);
+    case FUNC_LINEAR: case FUNC_LOGICAL: return (!a || b) ? 1.0 : 0.0;
+    default: return (!a || b) ? 1.0 : 0.0;   // FUNC_RATIO: log2(1 + [!a || b])
+  }
+}
+
 // sign functions of src/factor.h:112-299 (returned as double, before * feature_value)
 DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const VifRec *vifs,
                            const uint32_t *assign, uint32_t me, uint32_t proposal) {
@@ -172,7 +186,8 @@ struct TileView {
 };
 
 DWX_DEV uint32_t edge_func(const EdgeRec &e) { return e.packed & EDGE_FUNC_MASK; }
-DWX_DEV uint32_t edge_arity(const EdgeRec &e) { return e.packed >> EDGE_ARITY_SHIFT; }
+DWX_DEV uint32_t edge_arity(const EdgeRec &e) { return (e.packed >> EDGE_ARITY_SHIFT) & EDGE_ARITY_MASK; }
+DWX_DEV uint32_t edge_owner_lane(const EdgeRec &e) { return e.packed >> EDGE_OWNER_SHIFT; }
 DWX_DEV float bits_to_float(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 DWX_DEV uint32_t float_to_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 
@@ -526,7 +541,50 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelPar
       philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
       // unconditional LDS writes: slots past the tile's last record receive copies of
       // it and are never read
-      if (!LEARN && (d.flags & TILE_SIMPLE)) {
+      if (!LEARN && (d.flags & TILE_TERMS2)) {
+        // inference, boolean tile with pre-signed and arity-2 records: evaluate every
+        // record here.  Three batched phases so that a lane's K vif-pair loads, then its K
+        // neighbour-assignment gathers, are all in flight together (inside the per-variable
+        // loop they would be 2 dependent round trips per record, serialised).
+        EdgeTerms *s_terms = (EdgeTerms *)s_edges;
+        VifRec va[K], vb[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const bool bin = !(f.rec[k].packed & EDGE_PRESIGNED);
+          const VifRec *vp = P.vifs + (bin ? f.rec[k].aux : 0u);   // padded: always in bounds
+          va[k] = vp[0]; vb[k] = vp[1];
+        }
+        uint32_t other[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const uint32_t me = d.v0 + edge_owner_lane(f.rec[k]);
+          // the neighbour: the position that is not the owner (if both are the owner, any)
+          const VifRec o = (va[k].vid == me) ? vb[k] : va[k];
+          other[k] = P.assign_evid[o.vid];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const EdgeRec r = f.rec[k];
+          const double wv = (double)w[k];
+          EdgeTerms tt;
+          if (r.packed & EDGE_PRESIGNED) {
+            tt.t1 = wv * (double)r.fval;
+            tt.t0 = wv * (double)bits_to_float(r.aux);
+          } else {
+            const uint32_t me = d.v0 + edge_owner_lane(r);
+            const bool a_me = va[k].vid == me, b_me = vb[k].vid == me;
+            const bool a_o = other[k] == va[k].equal_to, b_o = other[k] == vb[k].equal_to;
+            // satisfied bits under proposal x: own positions compare x with their predicate
+            const bool a1 = a_me ? (va[k].equal_to == 1u) : a_o, b1 = b_me ? (vb[k].equal_to == 1u) : b_o;
+            const bool a0 = a_me ? (va[k].equal_to == 0u) : a_o, b0 = b_me ? (vb[k].equal_to == 0u) : b_o;
+            const uint32_t fn = edge_func(r);
+            const double fv = (double)r.fval;
+            tt.t1 = wv * (binary_sign(fn, a1, b1) * fv);
+            tt.t0 = wv * (binary_sign(fn, a0, b0) * fv);
+          }
+          s_terms[t + k * BLOCK_THREADS] = tt;
+        }
+      } else if (!LEARN && (d.flags & TILE_SIMPLE)) {
         // inference, all-unary tile: do the per-record arithmetic here, edge-parallel
         // and straight-line, and stage the two potential terms instead of the record:
         // t1 = w * (sign(hit) * f), t0 = w * (sign(miss) * f), the sign already folded
@@ -573,7 +631,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelPar
     int delta = 0;
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
-      if (d.flags & TILE_SIMPLE)
+      if ((d.flags & TILE_SIMPLE) || (!LEARN && (d.flags & TILE_TERMS2)))
         process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B,
                                                                   pull ? &delta : nullptr);
       else

@@ -8,7 +8,8 @@ from sampler_amd.rawgraph import RawGraph
 BOOL_FUNCS = [0, 1, 2, 3, 4, 7, 8, 9, 13]
 
 
-def random_graph(seed, V=60, F=200, W=12, p_cat=0.4, with_domains=True, truthy=False):
+def random_graph(seed, V=60, F=200, W=12, p_cat=0.4, with_domains=True, truthy=False,
+                 max_arity=4, exact_fvals=False):
     rng = np.random.default_rng(seed)
     dtype = (rng.random(V) < p_cat).astype(np.uint16)
     card = np.where(dtype == 1, rng.integers(1, 6, V), 2).astype(np.uint64)
@@ -40,7 +41,7 @@ def random_graph(seed, V=60, F=200, W=12, p_cat=0.4, with_domains=True, truthy=F
     cats = np.flatnonzero(dtype == 1)
     bools = np.flatnonzero(dtype == 0)
     for f in range(F):
-        ar = int(rng.integers(1, 5))
+        ar = int(rng.integers(1, max_arity + 1))
         if len(cats) and (rng.random() < 0.4 or not len(bools)):
             fn = 12
             vs = rng.choice(cats, size=ar, replace=True)
@@ -53,7 +54,8 @@ def random_graph(seed, V=60, F=200, W=12, p_cat=0.4, with_domains=True, truthy=F
             eeq.append(int(rng.choice(domain[int(v)])))
         off.append(len(evid))
         wid.append(int(rng.integers(0, W)))
-        fval.append(float(rng.choice([1.0, 1.0, -1.5, 0.1, 2.0, 0.3333333333333333])))
+        fval.append(float(rng.choice([1.0, 1.0, -1.5, 0.25, 2.0, 3.0] if exact_fvals else
+                                     [1.0, 1.0, -1.5, 0.1, 2.0, 0.3333333333333333])))
         if rng.random() < 0.05 and f + 1 < F:   # exact duplicate factor
             func.append(fn)
             evid.extend(evid[off[-2]:off[-1]]); eeq.extend(eeq[off[-2]:off[-1]])

@@ -216,3 +216,11 @@ def test_ghost_variables_parity(lib):
     import test_kernels_emu as E
     E.test_ghost_variables_parity.__wrapped__(lib) if hasattr(E.test_ghost_variables_parity, "__wrapped__") \
         else E.test_ghost_variables_parity(lib)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_binary_factor_tiles_all_functions(lib, seed):
+    from randgraph import random_graph
+    raw = random_graph(100 + seed, V=3000, F=15000, W=40, p_cat=0.0, max_arity=2, exact_fvals=True)
+    run_parity(lib, raw, n_learn=3, n_infer=6, stepsize=0.05, sample_evidence=bool(seed % 2),
+               learn_non_evidence=seed >= 1)

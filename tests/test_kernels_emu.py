@@ -132,3 +132,14 @@ def test_many_weights_global_atomics_path(lib):
     from randgraph import random_graph
     run_parity(lib, random_graph(5, V=900, F=5000, W=1300), n_learn=4, n_infer=2, stepsize=0.05,
                learn_non_evidence=True)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_binary_factor_tiles_all_functions(lib, seed):
+    """Boolean graphs whose factors all have arity <= 2 and f32-exact feature values: the
+    inference sweep evaluates them edge-parallel in the staging pass (TILE_TERMS2); every
+    factor function, duplicated variables inside a factor, duplicate factors."""
+    from randgraph import random_graph
+    raw = random_graph(100 + seed, V=300, F=1500, W=20, p_cat=0.0, max_arity=2, exact_fvals=True)
+    run_parity(lib, raw, n_learn=3, n_infer=8, stepsize=0.05, sample_evidence=bool(seed % 2),
+               learn_non_evidence=seed >= 2)
