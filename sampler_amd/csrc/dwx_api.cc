@@ -80,6 +80,7 @@ struct dwx_sampler {
   TileDesc *d_tiles = nullptr;
   uint32_t *d_giant = nullptr;
   int stage_k = 12;
+  bool wide_learn = false;   // the graph has TILE_TERMS2 tiles: 32-byte staged records when learning
   unsigned persistent_blocks[2] = {1, 1};
   double *d_row_truth = nullptr, *d_edge_fval64 = nullptr;
   EdgeRec *d_edges = nullptr;
@@ -142,10 +143,18 @@ void enqueue_sweep(dwx_sampler *s) {
     // persistent grid: as many workgroups as stay resident, each striding over tiles
     const unsigned grid = std::min<unsigned>(t1 - t0, s->persistent_blocks[LEARN ? 1 : 0]);
     const size_t lds = s->lds_bytes[LEARN ? 1 : 0];
-    switch (s->stage_k) {
-      case 3: rt::launch(sweep_kernel<LEARN, 3>, grid, BLOCK_THREADS, lds, s->stream, P); break;
-      case 6: rt::launch(sweep_kernel<LEARN, 6>, grid, BLOCK_THREADS, lds, s->stream, P); break;
-      default: rt::launch(sweep_kernel<LEARN, 12>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+    if (LEARN && s->wide_learn) {
+      switch (s->stage_k) {
+        case 3: rt::launch(sweep_kernel<LEARN, 3, LEARN>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+        case 6: rt::launch(sweep_kernel<LEARN, 6, LEARN>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+        default: rt::launch(sweep_kernel<LEARN, 12, LEARN>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      }
+    } else {
+      switch (s->stage_k) {
+        case 3: rt::launch(sweep_kernel<LEARN, 3>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+        case 6: rt::launch(sweep_kernel<LEARN, 6>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+        default: rt::launch(sweep_kernel<LEARN, 12>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      }
     }
     ++launches;
     // oversized variables of this launch, if any
@@ -406,10 +415,13 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     if (c.has_categorical) off += (size_t)c.rcap * 8;
     off = (off + 15) & ~(size_t)15;
     P.lds_edge_off = (uint32_t)off;
+    s->wide_learn = c.n_terms2_tiles > 0;
     off += slots * sizeof(EdgeRec);
-    P.lds_w_off = (uint32_t)off;
+    P.lds_w_off = (uint32_t)off;     // f32 weights right behind the 16-byte records
     s->lds_bytes[0] = off;
-    s->lds_bytes[1] = off + slots * 4;
+    // learning: 16-byte records + f32 weights (20 B per slot); with TILE_TERMS2 tiles the
+    // same region alternatively holds 32-byte LearnRecs (which carry their weight)
+    s->lds_bytes[1] = P.lds_edge_off + slots * (s->wide_learn ? 32 : 20);
     P.lds_agg_off = 0;
     if (c.W > 0 && c.W <= LDS_AGG_MAX_W) {
       P.lds_agg_off = (uint32_t)((s->lds_bytes[1] + 15) & ~(size_t)15);
@@ -422,10 +434,18 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       s->persistent_blocks[0] = rt::resident_blocks(infer, BLOCK_THREADS, s->lds_bytes[0]);
       s->persistent_blocks[1] = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_bytes[1]);
     };
-    switch (s->stage_k) {
-      case 3: prepare(sweep_kernel<false, 3>, sweep_kernel<true, 3>); break;
-      case 6: prepare(sweep_kernel<false, 6>, sweep_kernel<true, 6>); break;
-      default: prepare(sweep_kernel<false, 12>, sweep_kernel<true, 12>); break;
+    if (s->wide_learn) {
+      switch (s->stage_k) {
+        case 3: prepare(sweep_kernel<false, 3>, sweep_kernel<true, 3, true>); break;
+        case 6: prepare(sweep_kernel<false, 6>, sweep_kernel<true, 6, true>); break;
+        default: prepare(sweep_kernel<false, 12>, sweep_kernel<true, 12, true>); break;
+      }
+    } else {
+      switch (s->stage_k) {
+        case 3: prepare(sweep_kernel<false, 3>, sweep_kernel<true, 3>); break;
+        case 6: prepare(sweep_kernel<false, 6>, sweep_kernel<true, 6>); break;
+        default: prepare(sweep_kernel<false, 12>, sweep_kernel<true, 12>); break;
+      }
     }
     rt::stream_sync(st);
   });

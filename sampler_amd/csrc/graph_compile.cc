@@ -459,6 +459,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     g.launch_tile.push_back((uint32_t)g.tile_v.size());
     g.tile_v.push_back((uint32_t)Vo);
     g.tiles.resize(g.tile_v.size() - 1);
+    g.n_terms2_tiles = 0;
     for (size_t i = 0; i + 1 < g.tile_v.size(); ++i) {
       const uint32_t v0 = g.tile_v[i], v1 = g.tile_v[i + 1];
       TileDesc t{};
@@ -476,6 +477,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       t.flags = (simple ? TILE_SIMPLE : 0u) | (cat ? TILE_CATEGORICAL : 0u) |
                 ((simple && !cat && W > LDS_AGG_MAX_W) ? TILE_PULL : 0u) |
                 ((terms2 && !simple && !cat && t.nv <= 256) ? TILE_TERMS2 : 0u);
+      if (t.flags & TILE_TERMS2) ++g.n_terms2_tiles;
       // every record learns the lane of its owning variable inside the tile
       for (uint32_t l = 0; l < t.nv; ++l)
         for (uint32_t e = g.row_ptr[g.v_row[v0 + l]]; e < g.row_ptr[g.v_row[v0 + l + 1]]; ++e)

@@ -26,7 +26,7 @@ struct CompiledGraph {
   uint64_t NVif = 0;   // vif entries of factors with arity >= 2
   uint64_t n_query = 0; // non-evidence owned variables
   uint64_t Vo = 0;      // owned (sampled) variables: ids [0, Vo); ids [Vo, V) are ghosts
-  uint32_t n_colors = 0, n_giant_tiles = 0, max_card = 2;
+  uint32_t n_colors = 0, n_giant_tiles = 0, max_card = 2, n_terms2_tiles = 0;
   bool has_categorical = false, has_truthiness = false, has_f64_fval = false;
   bool order_is_identity = true;
   uint32_t tile_vars = 256, ecap = 3072, rcap = 256;

@@ -417,6 +417,52 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
   }
 }
 
+// ---------------------------------------------------------------- learning, TILE_TERMS2
+// Staged form of a record of a boolean TILE_TERMS2 tile in a learning sweep: the four
+// sign * feature_value products (free / evidence chain x proposal 1 / 0), evaluated
+// edge-parallel in the staging pass; exact in f32 (signs of unary and binary factors are
+// -1, 0, +1 and such a tile only holds f32-exact feature values).
+struct alignas(16) LearnRec {
+  uint32_t wid, packed;
+  float w, sf1, sf0, se1, se0;
+  uint32_t pad;
+};
+static_assert(sizeof(LearnRec) == 32, "LearnRec must be 32 bytes");
+
+// sample_sgd_single_variable (src/gibbs_sampler.h:127-149) + sgd_on_variable
+// (src/factor_graph.cc:262-275) for a boolean variable, everything out of LDS.
+DWX_DEV void learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr, uint32_t row_bias,
+                                   const LearnRec *recs, uint32_t edge_bias, long long *agg,
+                                   uint32_t p, const VarPre pre, double A, double B) {
+  const bool is_evid = pre.meta & VM_EVIDENCE;
+  const bool noise_aware = P.flags & OPT_NOISE_AWARE;
+  const uint32_t es = rowptr[pre.row0 - row_bias], ee = rowptr[pre.row0 + 1 - row_bias];
+  double ppf = 0.0, pnf = 0.0, ppe = 0.0, pne = 0.0;
+  for (uint32_t e = es; e < ee; ++e) {
+    const LearnRec r = recs[e - edge_bias];
+    const double w = (double)r.w;
+    ppf += w * (double)r.sf1; pnf += w * (double)r.sf0;
+    ppe += w * (double)r.se1; pne += w * (double)r.se0;
+  }
+  const uint32_t p_free = bool_draw(A, ppf, pnf);
+  P.assign_free[p] = p_free;
+  const uint32_t evid_value = pre.init;
+  // boolean variables carry no truthiness: sample_evid is "evidence value" or a Gibbs draw
+  const uint32_t p_evid = (!noise_aware && is_evid) ? evid_value : bool_draw(B, ppe, pne);
+  P.assign_evid[p] = p_evid;
+  if (!(P.flags & OPT_LEARN_NON_EVIDENCE) && (noise_aware || !is_evid)) return;
+  for (uint32_t e = es; e < ee; ++e) {
+    const LearnRec r = recs[e - edge_bias];
+    if (r.packed & EDGE_FIXED_FLAG) continue;
+    const double pot_free = (double)(p_free ? r.sf1 : r.sf0);
+    const double pot_evid = (double)(evid_value ? r.se1 : r.se0);
+    const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
+    if (!gi) continue;
+    if (agg) atomicAdd((unsigned long long *)&agg[r.wid], (unsigned long long)gi);
+    else atomicAdd((unsigned long long *)&P.grad[r.wid], (unsigned long long)gi);
+  }
+}
+
 // ---------------------------------------------------------------- kernels
 #ifndef DWX_DYN_LDS
 #define DWX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
@@ -506,8 +552,10 @@ DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t
 // of a tile is computed under the latency of its weight gathers.  K = records staged
 // per lane (LDS holds K * 256 records).  Oversized variables are skipped here and
 // handled by giant_kernel.
-template <bool LEARN, int K>
-__global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelParams P) {
+// WIDE (learning only): the graph has TILE_TERMS2 tiles; their records are staged as
+// 32-byte LearnRec (LDS doubles, one workgroup per CU, so registers are plentiful).
+template <bool LEARN, int K, bool WIDE = false>
+__global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : 3) sweep_kernel(const KernelParams P) {
   DWX_DYN_LDS(dyn_lds);
   uint32_t *s_rowptr = (uint32_t *)dyn_lds;
   double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
@@ -541,7 +589,48 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelPar
       philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
       // unconditional LDS writes: slots past the tile's last record receive copies of
       // it and are never read
-      if (!LEARN && (d.flags & TILE_TERMS2)) {
+      if (LEARN && WIDE && (d.flags & TILE_TERMS2)) {
+        LearnRec *s_lrec = (LearnRec *)s_edges;
+        VifRec va[K], vb[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const bool bin = !(f.rec[k].packed & EDGE_PRESIGNED);
+          const VifRec *vp = P.vifs + (bin ? f.rec[k].aux : 0u);
+          va[k] = vp[0]; vb[k] = vp[1];
+        }
+        uint32_t of[K], oe[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const uint32_t me = d.v0 + edge_owner_lane(f.rec[k]);
+          const VifRec o = (va[k].vid == me) ? vb[k] : va[k];
+          of[k] = P.assign_free[o.vid];
+          oe[k] = P.assign_evid[o.vid];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const EdgeRec r = f.rec[k];
+          LearnRec lr;
+          lr.wid = r.wid; lr.packed = r.packed; lr.w = w[k]; lr.pad = 0;
+          if (r.packed & EDGE_PRESIGNED) {
+            lr.sf1 = lr.se1 = r.fval;
+            lr.sf0 = lr.se0 = bits_to_float(r.aux);
+          } else {
+            const uint32_t me = d.v0 + edge_owner_lane(r);
+            const bool a_me = va[k].vid == me, b_me = vb[k].vid == me;
+            const bool a1 = va[k].equal_to == 1u, a0 = va[k].equal_to == 0u;
+            const bool b1 = vb[k].equal_to == 1u, b0 = vb[k].equal_to == 0u;
+            const bool af = of[k] == va[k].equal_to, bf = of[k] == vb[k].equal_to;
+            const bool ae = oe[k] == va[k].equal_to, be = oe[k] == vb[k].equal_to;
+            const uint32_t fn = edge_func(r);
+            const double fv = (double)r.fval;
+            lr.sf1 = (float)(binary_sign(fn, a_me ? a1 : af, b_me ? b1 : bf) * fv);
+            lr.sf0 = (float)(binary_sign(fn, a_me ? a0 : af, b_me ? b0 : bf) * fv);
+            lr.se1 = (float)(binary_sign(fn, a_me ? a1 : ae, b_me ? b1 : be) * fv);
+            lr.se0 = (float)(binary_sign(fn, a_me ? a0 : ae, b_me ? b0 : be) * fv);
+          }
+          s_lrec[t + k * BLOCK_THREADS] = lr;
+        }
+      } else if (!LEARN && (d.flags & TILE_TERMS2)) {
         // inference, boolean tile with pre-signed and arity-2 records: evaluate every
         // record here.  Three batched phases so that a lane's K vif-pair loads, then its K
         // neighbour-assignment gathers, are all in flight together (inside the per-variable
@@ -631,7 +720,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep_kernel(const KernelPar
     int delta = 0;
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
-      if ((d.flags & TILE_SIMPLE) || (!LEARN && (d.flags & TILE_TERMS2)))
+      if (LEARN && WIDE && (d.flags & TILE_TERMS2))
+        learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B);
+      else if ((d.flags & TILE_SIMPLE) || (!LEARN && (d.flags & TILE_TERMS2)))
         process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B,
                                                                   pull ? &delta : nullptr);
       else
