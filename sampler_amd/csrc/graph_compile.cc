@@ -426,7 +426,10 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
 
     // ---- workgroup tiles: <= tile_vars variables of one type whose value rows and
     //      edge records fit the LDS budget; an oversized variable gets a tile alone ----
-    g.ecap = o.tile_edges ? std::min(o.tile_edges, MAX_ECAP) : MAX_ECAP;
+    // Default LDS budget per tile: 3072 records (48 KiB) for all-unary graphs; graphs with
+    // wider factors stage 32-byte records when learning and keep many more registers live
+    // per staged record, so they get 1536-record tiles (3 workgroups per CU either way).
+    g.ecap = o.tile_edges ? std::min(o.tile_edges, MAX_ECAP) : (g.NVif > 0 ? MAX_ECAP / 2 : MAX_ECAP);
     g.rcap = o.tile_rows ? o.tile_rows : (g.has_categorical ? 2048 : g.tile_vars);
     if (g.rcap < g.tile_vars && !g.has_categorical) g.rcap = g.tile_vars;
     g.tile_v.clear(); g.launch_tile.clear(); g.launch_query_tile_end.clear();

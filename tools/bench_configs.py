@@ -12,9 +12,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sampler_amd import dwx, synthetic  # noqa: E402
 
 
+COMPILE = {}
+
+
 def run(name, raw, n_learn, n_infer, stepsize=0.001, **kw):
     t0 = time.time()
-    g = dwx.Graph(raw)
+    g = dwx.Graph(raw, **COMPILE)
     s = dwx.GibbsSampler(g, seed=7, **kw)
     t_setup = time.time() - t0
     for _ in range(2):
@@ -45,8 +48,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--only", default="")
+    ap.add_argument("--tile-vars", type=int, default=0)
+    ap.add_argument("--tile-edges", type=int, default=0)
     a = ap.parse_args()
     sc = a.scale
+    COMPILE.update(tile_vars=a.tile_vars, tile_edges=a.tile_edges)
     todo = a.only.split(",") if a.only else ["cfg2", "cfg3", "cfg3b", "cfg4", "cfg4learn"]
     if "cfg2" in todo:
         run("cfg2", synthetic.cfg2(int(1_000_000 * sc)), 0, 20)
