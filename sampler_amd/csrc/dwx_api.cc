@@ -307,7 +307,13 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     s->d_v_row = upload(c.v_row, st);
     s->d_v_init = upload(c.v_init, st, 1);
     s->d_row_ptr = upload(c.row_ptr, st, 1);
-    s->d_tiles = upload(c.tiles, st);
+    {
+      // edge-parallel evaluation of binary factors is compiled for K <= 6 only (register
+      // budget): with 3072-record tiles such tiles take the generic path
+      std::vector<TileDesc> tiles = c.tiles;
+      if (c.ecap > 6 * BLOCK_THREADS) for (auto &t : tiles) t.flags &= ~TILE_TERMS2;
+      s->d_tiles = upload(tiles, st);
+    }
     s->d_giant = upload(c.giant_tiles, st);
     if (!c.row_truth.empty()) s->d_row_truth = upload(c.row_truth, st);
     if (!c.edge_fval64.empty()) s->d_edge_fval64 = upload(c.edge_fval64, st);
@@ -415,7 +421,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     if (c.has_categorical) off += (size_t)c.rcap * 8;
     off = (off + 15) & ~(size_t)15;
     P.lds_edge_off = (uint32_t)off;
-    s->wide_learn = c.n_terms2_tiles > 0;
+    s->wide_learn = c.n_terms2_tiles > 0 && s->stage_k <= 6;
     off += slots * sizeof(EdgeRec);
     P.lds_w_off = (uint32_t)off;     // f32 weights right behind the 16-byte records
     s->lds_bytes[0] = off;

@@ -589,7 +589,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : 3) sweep_kernel(cons
       philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
       // unconditional LDS writes: slots past the tile's last record receive copies of
       // it and are never read
-      if (LEARN && WIDE && (d.flags & TILE_TERMS2)) {
+      // (TILE_TERMS2 staging keeps two vif records and the neighbour values per staged
+      // record live: only instantiated for K <= 6; the host clears the flag for K = 12)
+      if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
         LearnRec *s_lrec = (LearnRec *)s_edges;
         VifRec va[K], vb[K];
 #pragma unroll
@@ -630,7 +632,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : 3) sweep_kernel(cons
           }
           s_lrec[t + k * BLOCK_THREADS] = lr;
         }
-      } else if (!LEARN && (d.flags & TILE_TERMS2)) {
+      } else if (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)) {
         // inference, boolean tile with pre-signed and arity-2 records: evaluate every
         // record here.  Three batched phases so that a lane's K vif-pair loads, then its K
         // neighbour-assignment gathers, are all in flight together (inside the per-variable
@@ -720,9 +722,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : 3) sweep_kernel(cons
     int delta = 0;
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
-      if (LEARN && WIDE && (d.flags & TILE_TERMS2))
+      if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2))
         learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B);
-      else if ((d.flags & TILE_SIMPLE) || (!LEARN && (d.flags & TILE_TERMS2)))
+      else if ((d.flags & TILE_SIMPLE) || (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)))
         process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B,
                                                                   pull ? &delta : nullptr);
       else
