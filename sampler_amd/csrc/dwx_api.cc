@@ -161,7 +161,7 @@ void enqueue_sweep(dwx_sampler *s) {
     const uint32_t g0 = c.launch_giant[l];
     const uint32_t g1 = all ? c.launch_giant[l + 1] : c.launch_giant_query_end[l];
     if (g1 > g0) {
-      rt::launch(giant_kernel<LEARN>, (g1 - g0 + 63) / 64, 64u, 0, s->stream, P,
+      rt::launch(giant_kernel<LEARN>, g1 - g0, BLOCK_THREADS, 0, s->stream, P,
                  (const uint32_t *)(s->d_giant + g0), g1 - g0);
       ++launches;
     }

@@ -754,20 +754,96 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : 3) sweep_kernel(cons
   }
 }
 
-// Variables too big for one tile (rows > rcap or edge records > ecap): one lane per
-// such tile walks HBM directly.  Correct for any degree; rare by construction.
+// Variables too big for one tile (rows > rcap or edge records > ecap), e.g. the few
+// very-high-degree variables of a power-law graph: ONE WORKGROUP per such variable.
+// Boolean: the 256 lanes stride over the variable's records straight from HBM (coalesced
+// 16-byte loads, weights gathered per lane), accumulate partial potentials, and an LDS
+// tree reduction hands the totals to lane 0, which draws; then all lanes scatter the
+// gradient.  (The partial sums re-associate the f64 additions, so a potential can differ
+// from the sequential sum in its last bits; a decision flips only if r*(1+e^x) is within
+// ~1e-16 of 1.)  Categorical: lane 0 walks the rows sequentially.
+DWX_DEV double block_sum(double v, double *scratch) {
+  const uint32_t t = threadIdx.x;
+  scratch[t] = v;
+  __syncthreads();
+  for (uint32_t s = BLOCK_THREADS / 2; s > 0; s >>= 1) {
+    if (t < s) scratch[t] += scratch[t + s];
+    __syncthreads();
+  }
+  const double r = scratch[0];
+  __syncthreads();
+  return r;
+}
+
 template <bool LEARN>
-__global__ void __launch_bounds__(64) giant_kernel(const KernelParams P, const uint32_t *giant_tiles,
-                                                   uint32_t n) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const TileDesc d = P.tiles[giant_tiles[i]];
+__global__ void __launch_bounds__(BLOCK_THREADS) giant_kernel(const KernelParams P, const uint32_t *giant_tiles,
+                                                              uint32_t n) {
+  __shared__ double s_red[BLOCK_THREADS];
+  __shared__ uint32_t s_pick[2];
+  const uint32_t t = threadIdx.x;
+  if (blockIdx.x >= n) return;
+  const TileDesc d = P.tiles[giant_tiles[blockIdx.x]];
   TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr, nullptr};
-  for (uint32_t p = d.v0; p < d.v0 + d.nv; ++p) {
+  for (uint32_t p = d.v0; p < d.v0 + d.nv; ++p) {   // nv == 1 by construction
     const VarPre vp = load_var_pre<LEARN>(P, p);
     double A, B;
     philox_uniforms(P.seed, P.vid_offset + vp.orig, P.sweep, A, B);
-    process_variable<LEARN, W_GLOBAL, false>(P, T, p, vp, A, B);
+    if (vp.meta & VM_CATEGORICAL) {
+      if (t == 0) process_variable<LEARN, W_GLOBAL, false>(P, T, p, vp, A, B);
+      continue;
+    }
+    const bool is_evid = vp.meta & VM_EVIDENCE;
+    if (!LEARN && is_evid && !(P.flags & OPT_SAMPLE_EVIDENCE)) continue;
+    const bool noise_aware = P.flags & OPT_NOISE_AWARE;
+    const uint32_t es = P.row_ptr[vp.row0], ee = P.row_ptr[vp.row0 + 1];
+    // partial potentials of this lane: chain c = 0 free (learning) / evid (inference),
+    // c = 1 evidence chain while learning
+    double pp0 = 0.0, pn0 = 0.0, pp1 = 0.0, pn1 = 0.0;
+    const bool draw_evid = LEARN && (noise_aware || !is_evid);
+    for (uint32_t e = es + t; e < ee; e += BLOCK_THREADS) {
+      const EdgeRec er = P.edges[e];
+      const double w = (double)P.w32[er.wid];
+      const uint32_t *a0 = LEARN ? P.assign_free : P.assign_evid;
+      pp0 += w * edge_term<false>(P, er, e, a0, p, 1u, true);
+      pn0 += w * edge_term<false>(P, er, e, a0, p, 0u, false);
+      if (draw_evid) {
+        pp1 += w * edge_term<false>(P, er, e, P.assign_evid, p, 1u, true);
+        pn1 += w * edge_term<false>(P, er, e, P.assign_evid, p, 0u, false);
+      }
+    }
+    pp0 = block_sum(pp0, s_red); pn0 = block_sum(pn0, s_red);
+    if (draw_evid) { pp1 = block_sum(pp1, s_red); pn1 = block_sum(pn1, s_red); }
+    if (!LEARN) {
+      if (t == 0) {
+        const uint32_t prop = bool_draw(A, pp0, pn0);
+        if (prop) atomicAdd(&P.tally[vp.row0], 1u);
+        P.assign_evid[p] = prop;
+      }
+      continue;
+    }
+    if (t == 0) {
+      const uint32_t p_free = bool_draw(A, pp0, pn0);
+      const uint32_t p_evid = draw_evid ? bool_draw(B, pp1, pn1) : vp.init;
+      P.assign_free[p] = p_free;
+      P.assign_evid[p] = p_evid;
+      s_pick[0] = p_free;
+    }
+    __syncthreads();
+    const uint32_t p_free = s_pick[0];
+    __syncthreads();
+    if (!(P.flags & OPT_LEARN_NON_EVIDENCE) && (noise_aware || !is_evid)) continue;
+    // sgd_on_variable (src/factor_graph.cc:265-273); the boolean update counts are static.
+    // edge_term reads the owner's own value only through `proposal`, so the freshly
+    // written assignments need not be visible to the other lanes.
+    const uint32_t evid_value = vp.init;
+    for (uint32_t e = es + t; e < ee; e += BLOCK_THREADS) {
+      const EdgeRec er = P.edges[e];
+      if (er.packed & EDGE_FIXED_FLAG) continue;
+      const double pot_evid = edge_term<false>(P, er, e, P.assign_evid, p, evid_value, evid_value == 1u);
+      const double pot_free = edge_term<false>(P, er, e, P.assign_free, p, p_free, p_free == 1u);
+      const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
+      if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
+    }
   }
 }
 

@@ -67,3 +67,34 @@ def random_graph(seed, V=60, F=200, W=12, p_cat=0.4, with_domains=True, truthy=F
                     np.array(eeq, np.uint64), w_init, w_fixed,
                     np.array(dom_vid, np.uint64), np.array(dom_off, np.uint64),
                     np.array(dom_val, np.uint64), np.array(dom_tr, np.float64))
+
+
+def hub_graph(seed, V=400, hub_degree=5000, W=50):
+    """Power-law-ish: variables 0 and 1 (one evidence, one query) each sit in `hub_degree`
+    factors (unary ISTRUE and binary EQUAL/OR/IMPLY to random others); everybody else has a
+    few unary factors.  The hubs exceed any LDS tile and take the block-cooperative path."""
+    rng = np.random.default_rng(seed)
+    func, off, wid, fval, evid, eeq = [], [0], [], [], [], []
+
+    def add(fn, vs, eqs):
+        func.append(fn); evid.extend(vs); eeq.extend(eqs); off.append(len(evid))
+        wid.append(int(rng.integers(0, W))); fval.append(float(rng.choice([1.0, -1.0, 0.5, 2.0])))
+
+    for hub in (0, 1):
+        for _ in range(hub_degree):
+            if rng.random() < 0.5:
+                add(4, [hub], [int(rng.integers(0, 2))])
+            else:
+                o = int(rng.integers(2, V))
+                pair = [hub, o] if rng.random() < 0.5 else [o, hub]
+                add(int(rng.choice([3, 1, 0, 2])), pair, [int(rng.integers(0, 2)), int(rng.integers(0, 2))])
+    for v in range(2, V):
+        for _ in range(3):
+            add(4, [v], [1])
+    role = (rng.random(V) < 0.4).astype(np.uint8)
+    role[0], role[1] = 1, 0
+    init = (rng.random(V) < 0.6).astype(np.uint64) * role
+    return RawGraph(role, init, np.zeros(V, np.uint16), np.full(V, 2, np.uint64),
+                    np.array(func, np.uint16), np.array(off, np.uint64), np.array(wid, np.uint64),
+                    np.array(fval), np.array(evid, np.uint64), np.array(eeq, np.uint64),
+                    rng.normal(0, 0.02, W), np.zeros(W, np.uint8))

@@ -224,3 +224,11 @@ def test_binary_factor_tiles_all_functions(lib, seed):
     raw = random_graph(100 + seed, V=3000, F=15000, W=40, p_cat=0.0, max_arity=2, exact_fvals=True)
     run_parity(lib, raw, n_learn=3, n_infer=6, stepsize=0.05, sample_evidence=bool(seed % 2),
                learn_non_evidence=seed >= 1)
+
+
+def test_high_degree_hub_variables(lib):
+    from randgraph import hub_graph
+    s, _ = run_parity(lib, hub_graph(3, V=4000, hub_degree=200_000), n_learn=3, n_infer=4,
+                      stepsize=0.0001, learn_non_evidence=True)
+    assert s.graph.info.num_giant_tiles == 2
+    run_parity(lib, hub_graph(4, W=2000), n_learn=3, n_infer=3, stepsize=0.001, sample_evidence=True)

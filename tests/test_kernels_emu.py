@@ -143,3 +143,13 @@ def test_binary_factor_tiles_all_functions(lib, seed):
     raw = random_graph(100 + seed, V=300, F=1500, W=20, p_cat=0.0, max_arity=2, exact_fvals=True)
     run_parity(lib, raw, n_learn=3, n_infer=8, stepsize=0.05, sample_evidence=bool(seed % 2),
                learn_non_evidence=seed >= 2)
+
+
+def test_high_degree_hub_variables(lib):
+    """Variables whose records exceed any tile: one workgroup per variable, lane-strided
+    partial sums + LDS reduction (giant_kernel)."""
+    from randgraph import hub_graph
+    raw = hub_graph(3)
+    s, _ = run_parity(lib, raw, n_learn=4, n_infer=6, stepsize=0.001, learn_non_evidence=True)
+    assert s.graph.info.num_giant_tiles == 2
+    run_parity(lib, hub_graph(4, W=2000), n_learn=3, n_infer=3, stepsize=0.001, sample_evidence=True)
