@@ -103,8 +103,12 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the dwx sampler has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # DWX_BENCH_FORCE_DIST=1 runs the multi-GPU code path (process group, RCCL
+    # all-reduces, barriers) even at world size 1 -- a self-check for single-GPU boxes
+    use_dist = world > 1 or os.environ.get("DWX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -123,6 +127,9 @@ def main():
     del raw
     engine = HipEngine(sampler)
     drv = ShardedDimmWitted(engine, 0, 0, stepsize, decay)
+    if use_dist and not drv.distributed:      # forced self-check at world size 1
+        drv.distributed = True
+        engine.allreduce_static_counts()
 
     def step(cur):
         drv.learn_epoch(cur)      # sample_sgd (+ RCCL all-reduce of the gradient vector)
@@ -131,7 +138,7 @@ def main():
     def fence():
         engine.wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
@@ -149,7 +156,7 @@ def main():
     ms_l, nl_l, ns_l = sampler.kernel_time("learn")
     ms_p, nl_p, ns_p = sampler.kernel_time("pull")
     sampler.kernel_time_reset(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -211,7 +218,7 @@ def main():
                                        "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     sampler.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

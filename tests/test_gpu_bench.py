@@ -1,0 +1,47 @@
+"""bench.py contract on the GPU box: one JSON line with the required keys; the launch
+path the driver uses for N > 1 (python -m torch.distributed.run ... bench.py) works and
+the RCCL code path (forced at world size 1) gives the same kind of line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+        "scaling", "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def _check(out, n_gpus):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"]
+    assert "workload" in d["config"]
+    return d
+
+
+@pytest.mark.gpu
+def test_bench_single_process_small():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                        "--vars-per-gpu", "200000", "--cpu-sample-vars", "20000"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _check(r.stdout, 1)
+    assert d["cpu_baseline"]["value"] and d["cpu_baseline"]["kind"] in ("reference", "port")
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_with_rccl_path():
+    env = dict(os.environ, DWX_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--vars-per-gpu", "200000", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    _check(r.stdout, 1)
