@@ -70,18 +70,43 @@ CmdLine parse_cmdline(int argc, const char *const argv[]) {
   CmdLine a;
   std::ostringstream err;
   a.app_name = argc > 1 ? argv[1] : "";
-  if (a.app_name != "gibbs") {
-    ++a.num_errors;
-    if (a.app_name == "text2bin" || a.app_name == "bin2text")
-      err << a.app_name << ": not part of this build (SURVEY.md §8f rank 4); use the reference's converter\n";
-    else {
-      err << "DimmWitted (MI355X-native build)\nUsage: " << (argc ? argv[0] : "dw") << " MODE [ARG...]\n  "
-          << (argc ? argv[0] : "dw") << " gibbs\n";
-      if (argc > 1) err << a.app_name << ": Unrecognized MODE\n";
+  if (a.app_name == "text2bin") {
+    // dw text2bin MODE input output count_output [func_id arity var_is_positive...]
+    // (positional, src/cmd_parser.cc:168-212)
+    std::vector<std::string> pos(argv + 2, argv + argc);
+    if (pos.size() < 4) {
+      ++a.num_errors;
+      err << "PARSE ERROR:\n             Required arguments missing: mode, input, output, count_output\n";
+    } else {
+      a.text2bin_mode = pos[0]; a.text2bin_input = pos[1]; a.text2bin_output = pos[2];
+      a.text2bin_count_output = pos[3];
+      if (a.text2bin_mode == "factor") {
+        uint64_t u = 0;
+        if (pos.size() < 7 || !to_u64(pos[4], u)) {
+          ++a.num_errors;
+          err << "PARSE ERROR:\n             factor needs: func_id arity var_is_positive...\n";
+        } else {
+          a.text2bin_factor_func_id = (int)u;
+          if (!to_u64(pos[5], a.text2bin_factor_arity)) ++a.num_errors;
+          for (size_t i = 6; i < pos.size(); ++i) {
+            if (!to_u64(pos[i], u)) { ++a.num_errors; break; }
+            a.text2bin_factor_variables_should_equal_to.push_back(u);
+          }
+        }
+      }
     }
     a.error_text = err.str();
     return a;
   }
+  if (a.app_name != "gibbs" && a.app_name != "bin2text") {
+    ++a.num_errors;
+    err << "DimmWitted (MI355X-native build)\nUsage: " << (argc ? argv[0] : "dw") << " MODE [ARG...]\n";
+    for (const char *m : {"bin2text", "gibbs", "text2bin"}) err << "  " << (argc ? argv[0] : "dw") << " " << m << "\n";
+    if (argc > 1) err << a.app_name << ": Unrecognized MODE\n";
+    a.error_text = err.str();
+    return a;
+  }
+  const bool is_gibbs = a.app_name == "gibbs";
   bool have_l = false, have_i = false;
   for (int i = 2; i < argc; ++i) {
     std::string tok = argv[i], val;
@@ -144,9 +169,9 @@ CmdLine parse_cmdline(int argc, const char *const argv[]) {
     else if (n == "seed") { if (need_u()) a.seed = u; }
     else if (n == "step_cap") { if (need_d()) a.step_cap = d; }
   }
-  // -l and -i are required (src/cmd_parser.cc:75-80)
-  if (!have_l) { ++a.num_errors; err << "PARSE ERROR:\n             Required argument missing: n_learning_epoch\n"; }
-  if (!have_i) { ++a.num_errors; err << "PARSE ERROR:\n             Required argument missing: n_inference_epoch\n"; }
+  // -l and -i are required for gibbs (src/cmd_parser.cc:75-80)
+  if (is_gibbs && !have_l) { ++a.num_errors; err << "PARSE ERROR:\n             Required argument missing: n_learning_epoch\n"; }
+  if (is_gibbs && !have_i) { ++a.num_errors; err << "PARSE ERROR:\n             Required argument missing: n_inference_epoch\n"; }
   // XXX hack of the reference to support two step-size flags (src/cmd_parser.cc:158-160)
   if (a.stepsize == 0.01) a.stepsize = a.stepsize2;
   // n_datacopy / n_threads describe CPU replicas and threads; one GPU sampler replaces
@@ -541,12 +566,178 @@ int gibbs(const CmdLine &args) {
   return exit_code;
 }
 
+// ------------------------------------------------------------------ text2bin / bin2text
+namespace {
+void put_be64(std::ostream &o, uint64_t v) { v = htobe64(v); o.write((const char *)&v, 8); }
+void put_be16(std::ostream &o, uint16_t v) { v = htobe16(v); o.write((const char *)&v, 2); }
+void put_bef64(std::ostream &o, double d) { uint64_t v; memcpy(&v, &d, 8); put_be64(o, v); }
+
+std::vector<std::string> split_tabs(const std::string &line) {
+  std::vector<std::string> out;
+  size_t b = 0;
+  for (;;) {
+    size_t e = line.find('\t', b);
+    out.push_back(line.substr(b, e == std::string::npos ? std::string::npos : e - b));
+    if (e == std::string::npos) break;
+    b = e + 1;
+  }
+  return out;
+}
+
+// "{a,b,c}" -> elements (parse_pgarray, src/text2bin.cc:75-97)
+std::vector<std::string> parse_pgarray(const std::string &s) {
+  if (s.size() < 2 || s.front() != '{' || s.back() != '}')
+    throw std::runtime_error("Expected an array '{...}' but found: " + s);
+  std::vector<std::string> out;
+  std::string body = s.substr(1, s.size() - 2), el;
+  std::istringstream ss(body);
+  while (getline(ss, el, ',')) out.push_back(el);
+  return out;
+}
+}  // namespace
+
+int text2bin(const CmdLine &a) {
+  try {
+    std::ifstream fin(a.text2bin_input);
+    if (!fin) throw std::runtime_error("cannot open " + a.text2bin_input);
+    std::ofstream fout(a.text2bin_output, std::ios::binary);
+    if (!fout) throw std::runtime_error("cannot write " + a.text2bin_output);
+    std::ofstream fcount(a.text2bin_count_output);
+    uint64_t count = 0;
+    std::string line;
+    if (a.text2bin_mode == "variable") {          // src/text2bin.cc:19-47
+      while (getline(fin, line)) {
+        std::istringstream ss(line);
+        uint64_t vid, role, init, type, card;
+        if (!(ss >> vid >> role >> init >> type >> card)) throw std::runtime_error("bad variable line: " + line);
+        put_be64(fout, vid); fout.put((char)(uint8_t)role); put_be64(fout, init);
+        put_be16(fout, (uint16_t)type); put_be64(fout, card);
+        ++count;
+      }
+    } else if (a.text2bin_mode == "weight") {     // :50-71
+      while (getline(fin, line)) {
+        std::istringstream ss(line);
+        uint64_t wid, fixed; double val;
+        if (!(ss >> wid >> fixed >> val)) throw std::runtime_error("bad weight line: " + line);
+        put_be64(fout, wid); fout.put((char)(uint8_t)fixed); put_bef64(fout, val);
+        ++count;
+      }
+    } else if (a.text2bin_mode == "factor") {     // :115-185; count = total edges
+      const uint64_t ar = a.text2bin_factor_arity;
+      const bool cat = a.text2bin_factor_func_id == 12;   // FUNC_AND_CATEGORICAL
+      while (getline(fin, line)) {
+        std::vector<std::string> f = split_tabs(line);
+        const size_t need = ar + (cat ? ar : 0) + 2;
+        if (f.size() < need) throw std::runtime_error("bad factor line: " + line);
+        put_be16(fout, (uint16_t)a.text2bin_factor_func_id);
+        put_be64(fout, ar);
+        for (uint64_t i = 0; i < ar; ++i) {
+          put_be64(fout, (uint64_t)atol(f[i].c_str()));
+          uint64_t eq = cat ? (uint64_t)atol(f[ar + i].c_str())
+                            : a.text2bin_factor_variables_should_equal_to.at(i);
+          put_be64(fout, eq);
+        }
+        put_be64(fout, (uint64_t)atol(f[need - 2].c_str()));
+        put_bef64(fout, atof(f[need - 1].c_str()));
+        count += ar;
+      }
+    } else if (a.text2bin_mode == "domain") {     // :188-243
+      while (getline(fin, line)) {
+        std::istringstream ss(line);
+        uint64_t vid, card; std::string dom, truthy;
+        if (!(ss >> vid >> card >> dom >> truthy)) throw std::runtime_error("bad domain line: " + line);
+        std::vector<std::string> dv = parse_pgarray(dom), tv = parse_pgarray(truthy);
+        if (dv.size() != card || tv.size() != card) throw std::runtime_error("domain size != cardinality: " + line);
+        put_be64(fout, vid); put_be64(fout, card);
+        for (uint64_t i = 0; i < card; ++i) { put_be64(fout, (uint64_t)atol(dv[i].c_str())); put_bef64(fout, atof(tv[i].c_str())); }
+        ++count;
+      }
+    } else {
+      std::cerr << "Unsupported type" << std::endl;
+      return 1;
+    }
+    fcount << count << std::endl;
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << "dw text2bin: " << e.what() << std::endl;
+    return 1;
+  }
+}
+
+int bin2text(const CmdLine &a) {
+  try {
+    LoadedGraph g;
+    read_meta(a.fg_file, g);
+    load_variables(a.variable_file, g);
+    load_weights(a.weight_file, g);
+    load_domains(a.domain_file, g);
+    load_factors(a.factor_file, g);
+    const std::string dir = a.output_folder;
+    // per-variable domain (file order = dense order); implicit 0..card-1 without a block
+    std::vector<int64_t> dom_of(g.n_variables, -1);
+    for (size_t b = 0; b < g.dom_vid.size(); ++b) if (g.dom_vid[b] < g.n_variables) dom_of[g.dom_vid[b]] = (int64_t)b;
+    auto sparse_value = [&](uint64_t vid, uint64_t dense) -> uint64_t {
+      return dom_of[vid] >= 0 ? g.dom_value[g.dom_offset[dom_of[vid]] + dense] : dense;
+    };
+    auto dense_index = [&](uint64_t vid, uint64_t sparse) -> uint64_t {
+      if (dom_of[vid] < 0) return sparse;
+      for (uint64_t i = g.dom_offset[dom_of[vid]]; i < g.dom_offset[dom_of[vid] + 1]; ++i)
+        if (g.dom_value[i] == sparse) return i - g.dom_offset[dom_of[vid]];
+      throw std::runtime_error("value not in domain");
+    };
+    {   // dump_variables (src/bin2text.cc:23-50): prints assignment_dense
+      std::ofstream f(dir + "/variables.tsv");
+      for (uint64_t v = 0; v < g.n_variables; ++v) {
+        const bool ev = g.var_role[v] >= 1;
+        uint64_t val = ev ? g.var_init_value[v] : 0;
+        if (val && dom_of[v] >= 0) val = dense_index(v, val);
+        f << v << '\t' << (ev ? "1" : "0") << '\t' << val << '\t' << g.var_dtype[v] << '\t'
+          << g.var_cardinality[v] << std::endl;
+      }
+    }
+    {   // dump_domains (:52-69)
+      std::ofstream f(dir + "/domains.tsv");
+      for (uint64_t v = 0; v < g.n_variables; ++v) {
+        if (g.var_dtype[v] == 0) continue;
+        f << v << '\t' << g.var_cardinality[v] << '\t' << "{";
+        for (uint64_t j = 0; j < g.var_cardinality[v]; ++j) f << (j ? "," : "") << sparse_value(v, j);
+        f << "}" << std::endl;
+      }
+    }
+    {   // dump_factors (:71-98)
+      std::ofstream f(dir + "/factors.tsv");
+      for (uint64_t i = 0; i < g.n_factors; ++i) {
+        const uint64_t lo = g.fac_edge_offset[i], hi = g.fac_edge_offset[i + 1];
+        for (uint64_t e = lo; e < hi; ++e) f << g.edge_vid[e] << '\t';
+        if (g.fac_func[i] == 12) for (uint64_t e = lo; e < hi; ++e) f << g.edge_equal_to[e] << '\t';
+        f << g.fac_weight_id[i] << '\t' << g.fac_feature_value[i] << std::endl;
+      }
+    }
+    {   // dump_weights (:100-112)
+      std::ofstream f(dir + "/weights.tsv");
+      for (uint64_t w = 0; w < g.n_weights; ++w)
+        f << w << '\t' << (int)g.w_is_fixed[w] << '\t' << g.w_initial_value[w] << std::endl;
+    }
+    {   // dump_meta (:114-129)
+      std::ofstream f(dir + "/graph.meta");
+      f << g.n_weights << "," << g.n_variables << "," << g.n_factors << "," << g.n_edges
+        << ",graph.weights,graph.variables,graph.factors" << std::endl;
+    }
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << "dw bin2text: " << e.what() << std::endl;
+    return 1;
+  }
+}
+
 int dw_main(int argc, const char *const argv[]) {
   CmdLine a = parse_cmdline(argc, argv);
   if (a.num_errors > 0) {
     std::cerr << a.error_text;
     return a.num_errors;
   }
+  if (a.app_name == "text2bin") return text2bin(a);
+  if (a.app_name == "bin2text") return bin2text(a);
   return gibbs(a);
 }
 

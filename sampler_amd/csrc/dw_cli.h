@@ -29,6 +29,11 @@ struct CmdLine {
   bool regularization_l1 = false;
   bool should_be_quiet = false, should_sample_evidence = false, should_learn_non_evidence = false,
        is_noise_aware = false;
+  // text2bin (src/cmd_parser.cc:168-212)
+  std::string text2bin_mode, text2bin_input, text2bin_output, text2bin_count_output;
+  int text2bin_factor_func_id = 0;
+  uint64_t text2bin_factor_arity = 1;
+  std::vector<uint64_t> text2bin_factor_variables_should_equal_to;
   // additions of this build
   int device = 0;
   uint64_t seed = 0x5eed5eedULL;
@@ -77,6 +82,9 @@ void dump_marginals_in_text(std::ostream &o, const LoadedGraph &g, bool sample_e
 
 // the `dw gibbs` mode (src/dimmwitted.cc:37-95); returns the process exit code
 int gibbs(const CmdLine &args);
+// `dw text2bin` (src/text2bin.cc:19-260) and `dw bin2text` (src/bin2text.cc:23-151)
+int text2bin(const CmdLine &args);
+int bin2text(const CmdLine &args);
 // entry point (src/dimmwitted.cc:20-35)
 int dw_main(int argc, const char *const argv[]);
 

@@ -87,6 +87,13 @@ def convert_fixture(name):
                 with open(os.path.join(dst, "graph." + what + "s"), "wb") as f:
                     for p in parts:
                         f.write(open(p, "rb").read())
+    # the fixture's TSV inputs and text2bin arguments (test DATA of the reference), so the
+    # `dw text2bin` of this build can be checked against the converted binaries
+    tsv_dir = os.path.join(dst, "tsv")
+    os.makedirs(tsv_dir, exist_ok=True)
+    for f in sorted(glob.glob(os.path.join(src, "*.tsv")) + glob.glob(os.path.join(src, "*.text2bin-args"))):
+        shutil.copy(f, os.path.join(tsv_dir, os.path.basename(f)))
+        os.chmod(os.path.join(tsv_dir, os.path.basename(f)), 0o644)
     shutil.copy(os.path.join(src, "graph.meta"), os.path.join(dst, "graph.meta"))
     shutil.copy(os.path.join(src, "dw-args"), os.path.join(dst, "dw-args"))
     os.chmod(os.path.join(dst, "graph.meta"), 0o644)
@@ -159,6 +166,17 @@ def synth_goldens():
               sort_keys=True)
 
 
+def codec_goldens():
+    """The reference's text2bin codec fixtures (test/text2bin/: TSV inputs and xxd dumps of
+    the expected big-endian bytes) -- data files of the reference's tests."""
+    src = os.path.join(REF, "test", "text2bin")
+    dst = os.path.join(HERE, "text2bin")
+    os.makedirs(dst, exist_ok=True)
+    for f in sorted(os.listdir(src)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+        os.chmod(os.path.join(dst, f), 0o644)
+
+
 if __name__ == "__main__":
     if not os.path.exists(DW):
         sys.exit("oracle/_ref/dw missing: run oracle/build_ref.sh first")
@@ -167,6 +185,9 @@ if __name__ == "__main__":
         for fx in FIXTURES:
             convert_fixture(fx)
             print("golden:", fx)
+    if "fixtures" in which:
+        codec_goldens()
+        print("golden: text2bin codec fixtures")
     if "synth" in which:
         synth_goldens()
         print("golden: synthetic")

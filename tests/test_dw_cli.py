@@ -93,8 +93,6 @@ def test_dw_argument_errors(dw_emu):
     assert r.returncode != 0 and "Usage" in r.stderr
     r = subprocess.run([dw_emu, "frobnicate"], capture_output=True, text=True)
     assert r.returncode != 0 and "Unrecognized MODE" in r.stderr
-    r = subprocess.run([dw_emu, "text2bin", "variable", "a", "b", "c"], capture_output=True, text=True)
-    assert r.returncode != 0 and "not part of this build" in r.stderr
     with tempfile.TemporaryDirectory() as out:
         r = run_dw(dw_emu, "biased_coin", out, args=["-i", "3"])         # -l is required
         assert r.returncode != 0 and "n_learning_epoch" in r.stderr
