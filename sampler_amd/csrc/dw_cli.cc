@@ -396,7 +396,7 @@ dwx_graph_desc LoadedGraph::desc() const {
 // ------------------------------------------------------------------ dumps
 // src/inference_result.cc:101-105
 void dump_weights_in_text(std::ostream &o, const std::vector<double> &w) {
-  for (size_t j = 0; j < w.size(); ++j) o << j << " " << w[j] << std::endl;
+  for (size_t j = 0; j < w.size(); ++j) o << j << " " << w[j] << '\n';   // (no per-line flush)
 }
 
 // src/inference_result.cc:211-243
@@ -409,10 +409,10 @@ void dump_marginals_in_text(std::ostream &o, const LoadedGraph &g, bool sample_e
     if (g.var_role[v] >= 1 && !sample_evidence) continue;
     const uint64_t b = var_val_base[v];
     if (g.var_dtype[v] == 0) {
-      o << v << " " << 1 << " " << 1.0 * tallies[b] / nsamples[v] << std::endl;
+      o << v << " " << 1 << " " << 1.0 * tallies[b] / nsamples[v] << '\n';
     } else {
       for (uint64_t j = 0; j < g.var_cardinality[v]; ++j)
-        o << v << " " << value_sparse[b + j] << " " << 1.0 * tallies[b + j] / nsamples[v] << std::endl;
+        o << v << " " << value_sparse[b + j] << " " << 1.0 * tallies[b + j] / nsamples[v] << '\n';
     }
   }
 }
