@@ -40,6 +40,10 @@ class HipEngine:
         dev = torch.device("cuda", sampler.opts.device)
         self._holder = _CudaArray(ptr, nbytes, "<i8", 8)
         self.grad = torch.as_tensor(self._holder, device=dev)
+        # [G | T]: dynamic update counts T only exist for categorical variables (boolean
+        # counts are static, t_static), so an all-boolean graph reduces the G half only
+        W = sampler.W
+        self.grad_reduced = self.grad if sampler.graph.info.has_categorical else self.grad[:W]
         tp, tn = sampler.device_buffer(dwx.BUF_TSTATIC)
         self._tholder = _CudaArray(tp, tn, "<i8", 8)
         self.t_static = torch.as_tensor(self._tholder, device=dev)
@@ -64,7 +68,7 @@ class HipEngine:
 
     def allreduce_grad(self, group=None):
         with torch.cuda.stream(self.stream):
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(self.grad_reduced, op=dist.ReduceOp.SUM, group=group)
 
     # ---- halo exchange support ----
     def assign_tensor(self, chain):
