@@ -258,28 +258,78 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
   }
 }
 
-// src/gibbs_sampler.h:204-214
+// f32 exp for the guarded fast paths below (v_exp_f32; error ~1e-6 relative for |x| < 30)
+#ifndef DWX_FAST_EXPF
+#define DWX_FAST_EXPF(x) __expf(x)
+#endif
+constexpr double DRAW_GUARD = 1e-4;   // >> every f32 error bound below
+
+// src/gibbs_sampler.h:204-214: proposal 1 iff r * (1 + exp(pn - pp)) < 1.
+// Fast path: the same quantity with an f32 exp (relative error < 1e-5 for |x| < 30); its
+// verdict is taken only when it clears 1 by DRAW_GUARD, otherwise -- about one draw in
+// 10^4 -- the exact f64 expression decides.  The result therefore ALWAYS equals the exact
+// expression's; only the f64 exp is skipped.
 DWX_DEV uint32_t bool_draw(double r, double pp, double pn) {
-  return (r * (1.0 + exp(pn - pp)) < 1.0) ? 1u : 0u;
+  const double x = pn - pp;
+  if (x > -30.0 && x < 30.0) {
+    const double q = r * (1.0 + (double)DWX_FAST_EXPF((float)x));
+    if (q < 1.0 - DRAW_GUARD) return 1u;
+    if (q > 1.0 + DRAW_GUARD) return 0u;
+  }
+  return (r * (1.0 + exp(x)) < 1.0) ? 1u : 0u;
 }
 
-// categorical draw, src/gibbs_sampler.h:217-246 (inverse CDF with ONE uniform)
+// categorical draw, src/gibbs_sampler.h:217-246 (inverse CDF with ONE uniform):
+//   sum = logadd over d of pot_d;  first d with  r - sum_{j<=d} exp(pot_j - sum) <= 0.
+// Fast path (potentials buffered in LDS): normalise with max-subtracted f32 exps and pick
+// the first d whose cumulative mass reaches r; accepted only if r is at least DRAW_GUARD
+// away from both cumulative boundaries of that d (f32 error of a boundary < 1e-5, the
+// reference's own logadd cut-off shifts it by < 1e-8); otherwise the exact sequence runs.
 template <int WMODE, bool SIMPLE>
 DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row0, uint32_t card,
                           const uint32_t *assign, uint32_t me, double r) {
-  double sum = -100000.0;
-  for (uint32_t d = 0; d < card; ++d) {
-    const double pot = row_potential<WMODE, SIMPLE>(P, T, row0 + d, assign, me, d);
-    if (T.pot) T.pot[row0 + d - T.row_bias] = pot;
-    sum = logadd(sum, pot);
+  if (T.pot) {
+    double *pot = T.pot + (row0 - T.row_bias);
+    double m = -1e300;
+    for (uint32_t d = 0; d < card; ++d) {
+      const double v = row_potential<WMODE, SIMPLE>(P, T, row0 + d, assign, me, d);
+      pot[d] = v;
+      m = v > m ? v : m;
+    }
+    float S = 0.f;
+    for (uint32_t d = 0; d < card; ++d) {
+      const double z = pot[d] - m;
+      S += z > -30.0 ? DWX_FAST_EXPF((float)z) : 0.f;
+    }
+    const double target = r * (double)S, guard = DRAW_GUARD * (double)S;
+    float c = 0.f;
+    for (uint32_t d = 0; d < card; ++d) {
+      const double z = pot[d] - m;
+      const float lo = c;
+      c += z > -30.0 ? DWX_FAST_EXPF((float)z) : 0.f;
+      if ((double)c >= target) {
+        if (target - (double)lo > guard && (double)c - target > guard) return d;
+        break;   // too close to a boundary: let the exact sequence decide
+      }
+    }
+    // exact: the reference's sequence on the buffered potentials
+    double sum = -100000.0;
+    for (uint32_t d = 0; d < card; ++d) sum = logadd(sum, pot[d]);
+    for (uint32_t d = 0; d < card; ++d) {
+      r -= exp(pot[d] - sum);
+      if (r <= 0) return d;
+    }
+    return card - 1;  // the reference asserts here (:243); rounding can leave r > 0
   }
+  // no scratch (oversized variable): recompute potentials instead of buffering them
+  double sum = -100000.0;
+  for (uint32_t d = 0; d < card; ++d)
+    sum = logadd(sum, row_potential<WMODE, SIMPLE>(P, T, row0 + d, assign, me, d));
   for (uint32_t d = 0; d < card; ++d) {
-    const double pot = T.pot ? T.pot[row0 + d - T.row_bias]
-                             : row_potential<WMODE, SIMPLE>(P, T, row0 + d, assign, me, d);
-    r -= exp(pot - sum);
+    r -= exp(row_potential<WMODE, SIMPLE>(P, T, row0 + d, assign, me, d) - sum);
     if (r <= 0) return d;
   }
-  return card - 1;  // the reference asserts here (:243); rounding can leave r > 0
+  return card - 1;
 }
 
 // sgd_on_factor (src/factor_graph.cc:243-260), gradient accumulated in fixed point:

@@ -44,6 +44,7 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::functi
 #define DWX_DEV inline
 #define DWX_DYN_LDS(name) unsigned char *name = ::emu::g_lds
 #define DWX_HOST_EMU 1
+#define DWX_FAST_EXPF(x) expf(x)
 #define __shared__ static
 #define DWX_BALLOT(pred) (::emu::ballot(pred))
 #define DWX_UNIFORM(x) (x)
@@ -63,6 +64,7 @@ inline unsigned atomicAdd(unsigned *p, unsigned v) {
 }
 
 using std::exp;
+
 using std::log1p;
 using std::log2;
 using std::pow;
