@@ -605,7 +605,9 @@ DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t
 // WIDE (learning only): the graph has TILE_TERMS2 tiles; their records are staged as
 // 32-byte LearnRec (LDS doubles, one workgroup per CU, so registers are plentiful).
 template <bool LEARN, int K, bool WIDE = false>
-__global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : 3) sweep_kernel(const KernelParams P) {
+// (the learning kernel's LDS footprint admits 2 workgroups per CU at K = 12: give the
+// register allocator the matching budget instead of spilling at the 3-per-CU limit)
+__global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) sweep_kernel(const KernelParams P) {
   DWX_DYN_LDS(dyn_lds);
   uint32_t *s_rowptr = (uint32_t *)dyn_lds;
   double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
