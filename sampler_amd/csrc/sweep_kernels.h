@@ -215,11 +215,11 @@ DWX_DEV double edge_weight(const KernelParams &P, const TileView &T, const EdgeR
 }
 
 // FactorGraph::potential for one value row (src/factor_graph.h:127-145):
-// pot = sum_i weight[wid_i] * (sign_i * feature_value_i), in row order.
+// pot = sum_i weight[wid_i] * (sign_i * feature_value_i), in row order; [es, ee) is the
+// row's record range.
 template <int WMODE, bool SIMPLE>
-DWX_DEV double row_potential(const KernelParams &P, const TileView &T, uint32_t row,
-                             const uint32_t *assign, uint32_t me, uint32_t proposal) {
-  const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
+DWX_DEV double range_potential(const KernelParams &P, const TileView &T, uint32_t es, uint32_t ee,
+                               const uint32_t *assign, uint32_t me, uint32_t proposal) {
   double pot = 0.0;
   if (WMODE == W_TERMS) {
     const EdgeTerms *terms = (const EdgeTerms *)T.edges;
@@ -232,6 +232,13 @@ DWX_DEV double row_potential(const KernelParams &P, const TileView &T, uint32_t 
     pot += w * edge_term<SIMPLE>(P, er, e, assign, me, proposal, true);
   }
   return pot;
+}
+
+template <int WMODE, bool SIMPLE>
+DWX_DEV double row_potential(const KernelParams &P, const TileView &T, uint32_t row,
+                             const uint32_t *assign, uint32_t me, uint32_t proposal) {
+  return range_potential<WMODE, SIMPLE>(P, T, T.rowptr[row - T.row_bias], T.rowptr[row + 1 - T.row_bias],
+                                        assign, me, proposal);
 }
 
 // boolean variable: both proposals in one pass over the row (same sums, same order
@@ -263,6 +270,7 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
 #define DWX_FAST_EXPF(x) __expf(x)
 #endif
 constexpr double DRAW_GUARD = 1e-4;   // >> every f32 error bound below
+constexpr uint32_t SMALL_CARD = 8;    // domains up to this size are drawn out of registers
 
 // src/gibbs_sampler.h:204-214: proposal 1 iff r * (1 + exp(pn - pp)) < 1.
 // Fast path: the same quantity with an f32 exp (relative error < 1e-5 for |x| < 30); its
@@ -288,6 +296,59 @@ DWX_DEV uint32_t bool_draw(double r, double pp, double pn) {
 template <int WMODE, bool SIMPLE>
 DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row0, uint32_t card,
                           const uint32_t *assign, uint32_t me, double r) {
+  if (card <= SMALL_CARD) {
+    // Small domains (the usual case): potentials live in registers (fully unrolled, no
+    // dynamic indexing), each row pointer is read once -- no LDS scratch traffic.
+    double pot[SMALL_CARD];
+    uint32_t es = T.rowptr[row0 - T.row_bias];
+    double m = -1e300;
+#pragma unroll
+    for (uint32_t d = 0; d < SMALL_CARD; ++d) {
+      pot[d] = -1e300;
+      if (d < card) {
+        const uint32_t ee = T.rowptr[row0 + d + 1 - T.row_bias];
+        pot[d] = range_potential<WMODE, SIMPLE>(P, T, es, ee, assign, me, d);
+        es = ee;
+        m = pot[d] > m ? pot[d] : m;
+      }
+    }
+    float ex[SMALL_CARD];
+    float S = 0.f;
+#pragma unroll
+    for (uint32_t d = 0; d < SMALL_CARD; ++d) {
+      const double z = pot[d] - m;
+      ex[d] = (d < card && z > -30.0) ? DWX_FAST_EXPF((float)z) : 0.f;
+      S += ex[d];
+    }
+    const double target = r * (double)S, guard = DRAW_GUARD * (double)S;
+    float c = 0.f;
+    bool decided = false, near = false;
+    uint32_t pick = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < SMALL_CARD; ++d) {
+      const float lo = c;
+      c += ex[d];
+      if (!decided && !near && d < card && (double)c >= target) {
+        if (target - (double)lo > guard && (double)c - target > guard) { decided = true; pick = d; }
+        else near = true;
+      }
+    }
+    if (decided) return pick;
+    // exact: the reference's sequence
+    double sum = -100000.0;
+#pragma unroll
+    for (uint32_t d = 0; d < SMALL_CARD; ++d) if (d < card) sum = logadd(sum, pot[d]);
+    uint32_t res = card - 1;   // the reference asserts here (:243); rounding can leave r > 0
+    bool found = false;
+#pragma unroll
+    for (uint32_t d = 0; d < SMALL_CARD; ++d) {
+      if (d < card && !found) {
+        r -= exp(pot[d] - sum);
+        if (r <= 0) { res = d; found = true; }
+      }
+    }
+    return res;
+  }
   if (T.pot) {
     double *pot = T.pot + (row0 - T.row_bias);
     double m = -1e300;
