@@ -119,7 +119,6 @@ struct KernelParams {
   uint32_t *assign_evid;      // [V]
   uint32_t *tally;            // [R]
   const float *w32;           // [W] sampling copy of the weights, rounded to f32 (fits L2)
-  const uint8_t *w_fixed;     // [W]
   long long *grad;            // [2W]: G then T (fixed point)
   unsigned long long *delta;  // [n_tiles*4*2] per wave: {chains disagree, free < evid} ballots
   // launch

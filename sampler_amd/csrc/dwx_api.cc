@@ -403,7 +403,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     P.row_ptr = s->d_row_ptr; P.row_truth = s->d_row_truth; P.edges = s->d_edges;
     P.edge_fval64 = s->d_edge_fval64; P.vifs = s->d_vifs; P.tiles = s->d_tiles;
     P.assign_free = s->d_assign_free; P.assign_evid = s->d_assign_evid; P.tally = s->d_tally;
-    P.w32 = s->d_w32; P.w_fixed = s->d_w_fixed; P.grad = s->d_grad; P.delta = s->d_delta;
+    P.w32 = s->d_w32; P.grad = s->d_grad; P.delta = s->d_delta;
     P.seed = opts->seed; P.sweep = 0; P.vid_offset = opts->var_id_offset; P.tile_begin = 0; P.num_weights = (uint32_t)c.W;
     P.flags = (opts->sample_evidence ? OPT_SAMPLE_EVIDENCE : 0) |
               (opts->learn_non_evidence ? OPT_LEARN_NON_EVIDENCE : 0) |

@@ -501,7 +501,6 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
 
     g.w_init.assign(d.w_initial_value, d.w_initial_value + W);
     g.w_fixed.assign(d.w_is_fixed, d.w_is_fixed + W);
-    g.ref_row_has.clear();
   } catch (const LimitError &) {
     *limit = true;
     throw;

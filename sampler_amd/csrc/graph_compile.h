@@ -36,7 +36,6 @@ struct CompiledGraph {
   std::vector<uint64_t> value_sparse;      // [R]   values[].value
   std::vector<uint64_t> ref_row_ptr;       // [R+1] into ref_fidx
   std::vector<uint32_t> ref_fidx;          // [NIdx] factor ids, reference order
-  std::vector<uint8_t> ref_row_has;        // [R] whether the row has any factor
 
   // ---- device order ----
   std::vector<uint32_t> perm;      // [V] position -> original variable id

@@ -586,15 +586,7 @@ DWX_DEV void learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr
 // traffic), and the K loads differ only in their scalar offset, so they cost no
 // per-load address VALU.  "nt": the stream is read once per sweep and must not evict
 // the re-used f32 weight table from the XCD's L2.
-#ifdef DWX_HOST_EMU
-template <int K>
-DWX_DEV void load_tile_records(const EdgeRec *base, uint32_t nedges, uint32_t t, EdgeRec (&rec)[K]) {
-  for (int k = 0; k < K; ++k) {
-    const uint32_t i = t + k * BLOCK_THREADS;
-    rec[k] = i < nedges ? base[i] : EdgeRec{0u, 0u, 0u, 0.0f};
-  }
-}
-#else
+#ifndef DWX_LOAD_TILE_RECORDS
 typedef uint32_t dwx_u32x4 __attribute__((ext_vector_type(4)));
 template <int K>
 DWX_DEV void load_tile_records(const EdgeRec *base, uint32_t nedges, uint32_t t, EdgeRec (&rec)[K]) {
@@ -607,6 +599,7 @@ DWX_DEV void load_tile_records(const EdgeRec *base, uint32_t nedges, uint32_t t,
     rec[k].wid = v.x; rec[k].aux = v.y; rec[k].packed = v.z; rec[k].fval = bits_to_float(v.w);
   }
 }
+#define DWX_LOAD_TILE_RECORDS(K, base, nedges, t, rec) load_tile_records<K>(base, nedges, t, rec)
 #endif
 
 // Everything a lane holds in registers for the tile it will stage next.
@@ -649,7 +642,7 @@ DWX_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 template <bool LEARN, int K>
 DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t t,
                               TilePrefetch<K> &f) {
-  load_tile_records<K>(P.edges + d.e0, d.nedges, t, f.rec);
+  DWX_LOAD_TILE_RECORDS(K, P.edges + d.e0, d.nedges, t, f.rec);
 #pragma unroll
   for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k)
     f.rp[k] = P.row_ptr[d.r0 + umin(t + k * BLOCK_THREADS, d.nrows)];

@@ -43,7 +43,6 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::functi
 #define __launch_bounds__(...)
 #define DWX_DEV inline
 #define DWX_DYN_LDS(name) unsigned char *name = ::emu::g_lds
-#define DWX_HOST_EMU 1
 #define DWX_FAST_EXPF(x) expf(x)
 #define __shared__ static
 #define DWX_BALLOT(pred) (::emu::ballot(pred))
@@ -69,5 +68,18 @@ using std::log1p;
 using std::log2;
 using std::pow;
 using std::llrint;
+
+// host stand-in for the buffer-descriptor record stream (zero-fills past the end, like
+// the hardware bounds check)
+#include "device_types.h"
+template <int K>
+inline void emu_load_tile_records(const dwx::EdgeRec *base, uint32_t nedges, uint32_t t,
+                                  dwx::EdgeRec (&rec)[K]) {
+  for (int k = 0; k < K; ++k) {
+    const uint32_t i = t + k * dwx::BLOCK_THREADS;
+    rec[k] = i < nedges ? base[i] : dwx::EdgeRec{0u, 0u, 0u, 0.0f};
+  }
+}
+#define DWX_LOAD_TILE_RECORDS(K, base, nedges, t, rec) emu_load_tile_records<K>(base, nedges, t, rec)
 
 #endif
