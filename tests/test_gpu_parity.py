@@ -232,3 +232,46 @@ def test_high_degree_hub_variables(lib):
                       stepsize=0.0001, learn_non_evidence=True)
     assert s.graph.info.num_giant_tiles == 2
     run_parity(lib, hub_graph(4, W=2000), n_learn=3, n_infer=3, stepsize=0.001, sample_evidence=True)
+
+
+def test_full_pipeline_learn_infer_vs_reference_live(lib):
+    """Config-3 shape at 300k variables, the WHOLE pipeline on both sides (the real
+    reference binary vs this build's `dw` drop-in, same files, same flags): learned
+    weights must agree as noisy estimates of the same optimum, marginals within
+    Monte-Carlo tolerance."""
+    import subprocess
+    from oracle import binding as orc
+    if not orc.have_reference():
+        pytest.skip("oracle/_ref/dw not present")
+    V, N = 300_000, 200
+    raw = synthetic.cfg3(V, n_weights=3000, seed=2024)
+    args = ["-l", "40", "-i", str(N), "--alpha", "0.01", "--diminish", "0.95", "--reg_param", "0.01"]
+    dw = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sampler_amd", "csrc", "dw")
+    with tempfile.TemporaryDirectory() as d:
+        binary_format.write_graph(raw, d)
+        ref_out, my_out = os.path.join(d, "ref"), os.path.join(d, "mine")
+        os.makedirs(ref_out); os.makedirs(my_out)
+        orc.run_reference_dw(d, args, ref_out)
+        r = subprocess.run([dw, "gibbs", "-m", d + "/graph.meta", "-v", d + "/graph.variables",
+                            "-w", d + "/graph.weights", "-f", d + "/graph.factors", "-o", my_out, "-q",
+                            "--seed", "5"] + args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        w = [np.array([float(l.split()[1]) for l in open(os.path.join(o, "inference_result.out.weights.text"))])
+             for o in (ref_out, my_out)]
+        p = [_parse_marginals(open(os.path.join(o, "inference_result.out.text")).read(), V)
+             for o in (ref_out, my_out)]
+    # weights: ~100 factors (~50 evidence) per weight, MLE logit(0.7)/2 = 0.42 on average
+    assert abs(w[0].mean() - w[1].mean()) < 0.02 and abs(w[0].std() - w[1].std()) < 0.03
+    assert np.corrcoef(w[0], w[1])[0, 1] > 0.8
+    assert 0.3 < w[1].mean() < 0.55
+    q = raw.var_role == 0
+    assert np.array_equal(np.isnan(p[0]), np.isnan(p[1])) and np.array_equal(~np.isnan(p[0]), q)
+    p_ref, p_gpu = p[0][q], p[1][q]
+    assert abs(p_ref.mean() - p_gpu.mean()) < 0.005
+    z = stats.z_scores_two_sample(p_gpu, N, p_ref, N)
+    pbar = 0.5 * (p_gpu + p_ref)
+    z = z[(pbar > 0.1) & (pbar < 0.9)]
+    # the two sides sample from slightly different learned weights, so var(z) sits a little
+    # above 1; a real sampling bug would shift the mean or blow the variance up
+    assert abs(z.mean()) < 0.05 and 0.9 < z.var() < 1.6
+    assert stats.ks_two_sample(p_gpu, p_ref) > 0.001
