@@ -104,8 +104,8 @@ typedef struct dwx_options {
   int32_t regularization;      /* 0 = l1, 1 = l2 (reference enum order)                */
   int32_t reserved;
   double reg_param;            /* -b / --reg_param                                     */
-  double step_cap;             /* cap on stepsize x (updates of one weight per sweep);
-                                  <= 0 disables; default via dwx_default_options: 1.0  */
+  double step_cap;             /* bound on stepsize x R of one SGD mini-batch (see
+                                  dwx_sgd_plan); <= 0: never split a sweep; default 1.0 */
   uint64_t seed;               /* Philox key                                           */
   uint64_t var_id_offset;      /* added to local variable ids in the Philox counter: the
                                   global id of this shard's variable 0 (multi-GPU)     */
@@ -150,16 +150,36 @@ void dwx_sampler_destroy(dwx_sampler *s);
 /* GibbsSampler::sample(i_epoch) (src/gibbs_sampler.cc:20-25): one inference sweep. */
 int dwx_sample_async(dwx_sampler *s);
 /* GibbsSampler::sample_sgd(stepsize) (src/gibbs_sampler.cc:27-33): one learning
- * sweep = dwx_sgd_accumulate_async + dwx_sgd_apply_async. */
+ * sweep = dwx_sgd_plan + (accumulate, apply)* + dwx_sgd_finish. */
 int dwx_sample_sgd_async(dwx_sampler *s, double stepsize);
 /* GibbsSampler::wait() (src/gibbs_sampler.cc:35-38). */
 int dwx_wait(dwx_sampler *s);
 
-/* The two halves of a learning sweep, split so that a multi-GPU driver can
- * all-reduce the gradient buffer in between (replaces the dormant
- * InferenceResult::merge_gradients_from, src/inference_result.cc:57-62). */
-int dwx_sgd_accumulate_async(dwx_sampler *s);
-int dwx_sgd_apply_async(dwx_sampler *s, double stepsize);
+/* A learning sweep in pieces, for drivers that put a collective between accumulation and
+ * update (multi-GPU: all-reduce DWX_BUF_GRAD; replaces the dormant
+ * InferenceResult::merge_gradients_from, src/inference_result.cc:57-62).
+ *
+ * The reference applies every factor's SGD update immediately; the device accumulates a
+ * mini-batch and applies it in one step.  dwx_sgd_plan sizes the mini-batches for the
+ * given step size: with R = the (estimated) largest eigenvalue of a batch's curvature in
+ * weight space (how strongly all updates of one batch interact), a sweep is split into
+ * `batches` = the smallest power of two with stepsize * R(batches) <= step_cap, i.e. as
+ * many pieces as keep one batched step inside the region where it tracks the
+ * sequential updates (1 for configs 2-5 of BASELINE.json; dozens for heavily tied
+ * weights with a large step).  force_batches != 0 overrides (all ranks of a multi-GPU run
+ * must use the same value).  A plan is a list of chunks (consecutive device-order runs
+ * of variables, never crossing a colour); with batches == 1 the update is applied once
+ * after the last chunk, otherwise after every chunk.
+ *   dwx_sgd_plan -> n_chunks;  for c in chunks: dwx_sgd_accumulate_async(c) [+ collective,
+ *   + dwx_sgd_apply_async where due];  dwx_sgd_finish. */
+int dwx_sgd_plan(dwx_sampler *s, double stepsize, uint32_t force_batches, uint32_t *batches,
+                 uint32_t *n_chunks, double *effective_stepsize);
+/* chunk_off[n_chunks+1]: chunk c covers positions [chunk_off[c], chunk_off[c+1]) of the
+ * schedule order (dwx_graph_get_schedule). */
+int dwx_sgd_get_chunks(dwx_sampler *s, uint64_t *chunk_off);
+int dwx_sgd_accumulate_async(dwx_sampler *s, uint32_t chunk);
+int dwx_sgd_apply_async(dwx_sampler *s);
+int dwx_sgd_finish(dwx_sampler *s);
 
 /* infrs.weight_values access (src/dimmwitted.cc:209-216 merge/average, :245-258 dump) */
 int dwx_get_weights(dwx_sampler *s, double *out);

@@ -87,6 +87,11 @@ constexpr uint32_t OPT_LEARN_NON_EVIDENCE = 1u << 1;
 constexpr uint32_t OPT_NOISE_AWARE = 1u << 2;
 constexpr uint32_t OPT_HAS_F64_FVAL = 1u << 3;
 constexpr uint32_t OPT_HAS_TRUTHINESS = 1u << 4;
+// A learning sweep split into several mini-batches: per-batch update
+// counts are not static any more (count them with atomics) and the whole-sweep pull-based
+// gradient does not apply (scatter the gradient instead).
+constexpr uint32_t OPT_DYNAMIC_T = 1u << 5;
+constexpr uint32_t OPT_NO_PULL = 1u << 6;
 
 constexpr double FIX_SCALE = 1073741824.0;  // 2^30: gradient fixed-point scale
 constexpr double LINEAR_ZERO_THRESHOLD = 0.000001;  // src/common.h:15

@@ -37,7 +37,7 @@ struct CmdLine {
   // additions of this build
   int device = 0;
   uint64_t seed = 0x5eed5eedULL;
-  double step_cap = 1.0;
+  double step_cap = 1.5;
   int num_errors = 0;
   std::string error_text;
 };

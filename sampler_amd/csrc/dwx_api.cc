@@ -6,7 +6,10 @@
 #include "../../include/dwx.h"
 
 #include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <new>
 #include <stdexcept>
@@ -80,6 +83,13 @@ struct dwx_sampler {
   TileDesc *d_tiles = nullptr;
   uint32_t *d_giant = nullptr;
   int stage_k = 12;
+  // learning-sweep plan (dwx_sgd_plan)
+  struct Chunk { uint32_t launch, t0, t1; };
+  std::vector<Chunk> plan_chunks;
+  uint32_t plan_batches = 1;
+  double plan_eta = 0.0;
+  bool plan_valid = false;
+  std::map<uint32_t, double> row_sum_cache;   // batches -> R
   bool wide_learn = false;   // the graph has TILE_TERMS2 tiles: 32-byte staged records when learning
   unsigned persistent_blocks[2] = {1, 1};
   double *d_row_truth = nullptr, *d_edge_fval64 = nullptr;
@@ -118,72 +128,222 @@ struct dwx_sampler {
 };
 
 namespace {
+// launch the sweep kernel (+ the oversized-variable kernel) over tiles [t0, t1) of launch l
 template <bool LEARN>
-void enqueue_sweep(dwx_sampler *s) {
+uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, uint32_t t1) {
+  const CompiledGraph &c = *s->cg;
+  if (t1 <= t0) return 0;
+  uint32_t launches = 0;
+  P.tile_begin = t0;
+  P.tile_end = t1;
+  // persistent grid: as many workgroups as stay resident, each striding over tiles
+  const unsigned grid = std::min<unsigned>(t1 - t0, s->persistent_blocks[LEARN ? 1 : 0]);
+  const size_t lds = s->lds_bytes[LEARN ? 1 : 0];
+  if (LEARN && s->wide_learn) {
+    switch (s->stage_k) {
+      case 3: rt::launch(sweep_kernel<LEARN, 3, LEARN>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      case 6: rt::launch(sweep_kernel<LEARN, 6, LEARN>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      default: rt::launch(sweep_kernel<LEARN, 12, LEARN>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+    }
+  } else {
+    switch (s->stage_k) {
+      case 3: rt::launch(sweep_kernel<LEARN, 3>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      case 6: rt::launch(sweep_kernel<LEARN, 6>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      default: rt::launch(sweep_kernel<LEARN, 12>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+    }
+  }
+  ++launches;
+  // oversized variables among these tiles (giant_tiles is sorted by tile index)
+  const uint32_t *gb = c.giant_tiles.data() + c.launch_giant[l], *ge = c.giant_tiles.data() + c.launch_giant[l + 1];
+  const uint32_t g0 = (uint32_t)(std::lower_bound(gb, ge, t0) - c.giant_tiles.data());
+  const uint32_t g1 = (uint32_t)(std::lower_bound(gb, ge, t1) - c.giant_tiles.data());
+  if (g1 > g0) {
+    rt::launch(giant_kernel<LEARN>, g1 - g0, BLOCK_THREADS, 0, s->stream, P,
+               (const uint32_t *)(s->d_giant + g0), g1 - g0);
+    ++launches;
+  }
+  return launches;
+}
+
+// one inference sweep (GibbsSampler::sample)
+void enqueue_inference(dwx_sampler *s) {
   const CompiledGraph &c = *s->cg;
   rt::set_device(s->device);
   KernelParams P = s->base;
   P.sweep = s->sweep;
   TimedSpan sp{};
   if (s->timing) {
-    sp.a = rt::event_create(); sp.b = rt::event_create(); sp.kind = LEARN ? 1 : 0;
+    sp.a = rt::event_create(); sp.b = rt::event_create(); sp.c = rt::event_create(); sp.kind = 0;
     rt::event_record(sp.a, s->stream);
   }
-  const size_t nl = c.launch_off.size() - 1;
   uint32_t launches = 0;
-  for (size_t l = 0; l < nl; ++l) {
-    // an inference sweep only visits the query variables' tiles unless
-    // --sample_evidence (src/gibbs_sampler.h:157); a learning sweep visits all
-    const bool all = LEARN || s->opts.sample_evidence;
-    const uint32_t t0 = c.launch_tile[l];
-    const uint32_t t1 = all ? c.launch_tile[l + 1] : c.launch_query_tile_end[l];
-    if (t1 == t0) continue;
-    P.tile_begin = t0;
-    P.tile_end = t1;
-    // persistent grid: as many workgroups as stay resident, each striding over tiles
-    const unsigned grid = std::min<unsigned>(t1 - t0, s->persistent_blocks[LEARN ? 1 : 0]);
-    const size_t lds = s->lds_bytes[LEARN ? 1 : 0];
-    if (LEARN && s->wide_learn) {
-      switch (s->stage_k) {
-        case 3: rt::launch(sweep_kernel<LEARN, 3, LEARN>, grid, BLOCK_THREADS, lds, s->stream, P); break;
-        case 6: rt::launch(sweep_kernel<LEARN, 6, LEARN>, grid, BLOCK_THREADS, lds, s->stream, P); break;
-        default: rt::launch(sweep_kernel<LEARN, 12, LEARN>, grid, BLOCK_THREADS, lds, s->stream, P); break;
-      }
-    } else {
-      switch (s->stage_k) {
-        case 3: rt::launch(sweep_kernel<LEARN, 3>, grid, BLOCK_THREADS, lds, s->stream, P); break;
-        case 6: rt::launch(sweep_kernel<LEARN, 6>, grid, BLOCK_THREADS, lds, s->stream, P); break;
-        default: rt::launch(sweep_kernel<LEARN, 12>, grid, BLOCK_THREADS, lds, s->stream, P); break;
-      }
+  for (size_t l = 0; l + 1 < c.launch_off.size(); ++l) {
+    // only the query variables' tiles unless --sample_evidence (src/gibbs_sampler.h:157)
+    const uint32_t t1 = s->opts.sample_evidence ? c.launch_tile[l + 1] : c.launch_query_tile_end[l];
+    launches += launch_tiles<false>(s, P, l, c.launch_tile[l], t1);
+  }
+  if (s->timing) {
+    rt::event_record(sp.b, s->stream);
+    rt::event_record(sp.c, s->stream);
+    sp.launches = launches; sp.has_pull = false;
+    s->spans.push_back(sp);
+  }
+  ++s->sweep;
+}
+
+// Curvature of one SGD mini-batch in weight space, when every colour launch is cut into
+// `batches` runs of tiles.  A variable v that triggers SGD contributes kappa_v d_v d_v^T to
+// the batch Hessian bound, d_v[w] = sum of |d_r| over its non-fixed records with weight w,
+// d_r = the change of the record's potential between proposals (|sign(hit) f - sign(miss) f|
+// for pre-signed records, a 2|f|(arity-1) bound otherwise), kappa = 1/4 (logistic) for
+// boolean, 1/2 for categorical variables.  The largest eigenvalue lambda of that matrix
+// decides whether ONE batched step tracks the reference's sequential updates
+// (stepsize * lambda < 2).  Estimated per chunk by two power iterations from the all-ones
+// vector (the matrix is entrywise non-negative: the iteration converges from below to its
+// Perron value) combined with the largest diagonal entry (exact for a batch dominated by
+// one heavily tied weight), times a safety factor; the result is the max over chunks.
+double row_sum_bound(dwx_sampler *s, uint32_t batches) {
+  auto it = s->row_sum_cache.find(batches);
+  if (it != s->row_sum_cache.end()) return it->second;
+  const CompiledGraph &c = *s->cg;
+  std::vector<double> x(c.W, 0.0), y(c.W, 0.0), diag(c.W, 0.0);
+  std::vector<uint8_t> seen(c.W, 0);
+  std::vector<uint32_t> touched;
+  double lam_max = 0.0;
+  auto rec_d = [&](uint32_t e) -> double {
+    const EdgeRec &r = c.edges[e];
+    if (r.packed & EDGE_FIXED_FLAG) return 0.0;
+    if (r.packed & EDGE_PRESIGNED) {
+      float miss;
+      std::memcpy(&miss, &r.aux, 4);
+      return std::fabs((double)r.fval - (double)miss);
     }
-    ++launches;
-    // oversized variables of this launch, if any
-    const uint32_t g0 = c.launch_giant[l];
-    const uint32_t g1 = all ? c.launch_giant[l + 1] : c.launch_giant_query_end[l];
-    if (g1 > g0) {
-      rt::launch(giant_kernel<LEARN>, g1 - g0, BLOCK_THREADS, 0, s->stream, P,
-                 (const uint32_t *)(s->d_giant + g0), g1 - g0);
-      ++launches;
+    const double f = (r.packed & EDGE_F64_FLAG) ? c.edge_fval64[e] : (double)r.fval;
+    const uint32_t ar = (r.packed >> EDGE_ARITY_SHIFT) & EDGE_ARITY_MASK;
+    return 2.0 * std::fabs(f) * std::max(1u, ar - 1);
+  };
+  auto triggers = [&](uint32_t m) {
+    return s->opts.learn_non_evidence || (!s->opts.noise_aware && (m & VM_EVIDENCE)) ||
+           (s->opts.noise_aware && (m & VM_TRUTHINESS));
+  };
+  for (size_t l = 0; l + 1 < c.launch_off.size(); ++l) {
+    const uint32_t t0 = c.launch_tile[l], n = c.launch_tile[l + 1] - t0;
+    const uint32_t nb = std::min(batches, n);
+    for (uint32_t b = 0; b < nb; ++b) {
+      const uint32_t ta = t0 + (uint32_t)((uint64_t)n * b / nb), tb = t0 + (uint32_t)((uint64_t)n * (b + 1) / nb);
+      const uint32_t p0 = c.tile_v[ta], p1 = c.tile_v[tb];
+      // y = H x, three times: x0 = 1 (y = row sums), then two normalised power steps
+      double lam = 0.0, dmax = 0.0;
+      for (int iter = 0; iter < 3; ++iter) {
+        for (uint32_t p = p0; p < p1; ++p) {
+          const uint32_t m = c.v_meta[p];
+          if (!triggers(m)) continue;
+          const uint32_t e0 = c.row_ptr[c.v_row[p]], e1 = c.row_ptr[c.v_row[p + 1]];
+          const double kappa = (m & VM_CATEGORICAL) ? 0.5 : 0.25;
+          double dot = 0.0;
+          for (uint32_t e = e0; e < e1; ++e) {
+            const double d = rec_d(e);
+            if (d == 0.0) continue;
+            const uint32_t w = c.edges[e].wid;
+            if (!seen[w]) { seen[w] = 1; touched.push_back(w); x[w] = 1.0; }
+            dot += d * x[w];
+          }
+          for (uint32_t e = e0; e < e1; ++e) {
+            const double d = rec_d(e);
+            if (d == 0.0) continue;
+            y[c.edges[e].wid] += kappa * d * dot;
+            if (iter == 0) diag[c.edges[e].wid] += kappa * d * d;   // (lower bound of H_ww)
+          }
+        }
+        double xy = 0.0, xx = 0.0, yy = 0.0;
+        for (uint32_t w : touched) { xy += x[w] * y[w]; xx += x[w] * x[w]; yy += y[w] * y[w]; }
+        if (xx > 0) lam = std::max(lam, xy / xx);
+        const double norm = yy > 0 ? 1.0 / std::sqrt(yy) : 0.0;
+        for (uint32_t w : touched) { x[w] = y[w] * norm; y[w] = 0.0; }
+      }
+      for (uint32_t w : touched) { dmax = std::max(dmax, diag[w]); diag[w] = 0.0; seen[w] = 0; x[w] = 0.0; }
+      touched.clear();
+      lam_max = std::max(lam_max, 1.1 * std::max(lam, dmax));
     }
   }
+  s->row_sum_cache[batches] = lam_max;
+  return lam_max;
+}
+
+void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
+  const CompiledGraph &c = *s->cg;
+  uint32_t max_tiles = 1;
+  for (size_t l = 0; l + 1 < c.launch_off.size(); ++l)
+    max_tiles = std::max(max_tiles, c.launch_tile[l + 1] - c.launch_tile[l]);
+  const double cap = s->opts.step_cap;
+  uint32_t B = 1;
+  double eta = stepsize;
+  if (force_batches) {
+    B = std::min(force_batches, max_tiles);
+  } else if (cap > 0 && stepsize > 0) {
+    while (B < max_tiles && stepsize * row_sum_bound(s, B) > cap) B *= 2;
+    B = std::min(B, max_tiles);
+  }
+  if (cap > 0 && stepsize > 0) {
+    // even one tile per batch is too coarse for this step: shrink the step instead
+    const double R = row_sum_bound(s, B);
+    if (stepsize * R > cap && (force_batches == 0 || B >= max_tiles)) eta = cap / R;
+  }
+  s->plan_batches = B;
+  s->plan_eta = eta;
+  s->plan_chunks.clear();
+  for (size_t l = 0; l + 1 < c.launch_off.size(); ++l) {
+    const uint32_t t0 = c.launch_tile[l], n = c.launch_tile[l + 1] - t0;
+    const uint32_t nb = std::min(B, n);
+    for (uint32_t b = 0; b < nb; ++b)
+      s->plan_chunks.push_back({(uint32_t)l, t0 + (uint32_t)((uint64_t)n * b / nb),
+                                t0 + (uint32_t)((uint64_t)n * (b + 1) / nb)});
+  }
+  s->plan_valid = true;
+}
+
+// accumulate the gradient of one chunk of the plan (sampling both chains on the way)
+void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
+  rt::set_device(s->device);
+  if (chunk >= s->plan_chunks.size()) return;   // ranks with fewer chunks idle through the rest
+  const dwx_sampler::Chunk &ch = s->plan_chunks[chunk];
+  KernelParams P = s->base;
+  P.sweep = s->sweep;
+  const bool split = s->plan_batches > 1;
+  if (split) P.flags |= OPT_DYNAMIC_T | OPT_NO_PULL;
+  TimedSpan sp{};
+  if (s->timing) {
+    sp.a = rt::event_create(); sp.b = rt::event_create(); sp.c = rt::event_create(); sp.kind = 1;
+    rt::event_record(sp.a, s->stream);
+  }
+  const uint32_t launches = launch_tiles<true>(s, P, ch.launch, ch.t0, ch.t1);
   if (s->timing) rt::event_record(sp.b, s->stream);
   bool pulled = false;
-  if (LEARN && s->n_inc) {
-    const unsigned chunk = BLOCK_THREADS * PULL_RUN;
-    const unsigned grid = std::min<unsigned>((s->n_inc + chunk - 1) / chunk, 256u * 16u);
+  if (!split && chunk + 1 == s->plan_chunks.size() && s->n_inc) {
+    // un-split sweep: the pull-based gradient of all TILE_PULL tiles, once, at the end
+    const unsigned chunk_sz = BLOCK_THREADS * PULL_RUN;
+    const unsigned grid = std::min<unsigned>((s->n_inc + chunk_sz - 1) / chunk_sz, 256u * 16u);
     rt::launch(pull_grad_kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)s->d_inc_wid,
                (const uint32_t *)s->d_inc_slot, (const float *)s->d_inc_d, s->n_inc,
                (const unsigned long long *)s->d_delta, s->d_grad);
     pulled = true;
   }
   if (s->timing) {
-    sp.c = rt::event_create();
     rt::event_record(sp.c, s->stream);
-    sp.launches = launches;
-    sp.has_pull = pulled;
+    sp.launches = launches; sp.has_pull = pulled;
     s->spans.push_back(sp);
   }
-  ++s->sweep;
+}
+
+void enqueue_apply(dwx_sampler *s) {
+  rt::set_device(s->device);
+  const uint32_t W = (uint32_t)s->cg->W;
+  if (!W) return;
+  const unsigned grid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 2048u);
+  const long long *ts = s->plan_batches > 1 ? nullptr : (const long long *)s->d_t_static;
+  rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
+             (const uint8_t *)s->d_w_fixed, s->d_grad, ts, W, s->plan_eta, s->opts.reg_param,
+             (int)(s->opts.regularization == 1));
 }
 
 void drain_spans(dwx_sampler *s) {
@@ -192,7 +352,7 @@ void drain_spans(dwx_sampler *s) {
   for (auto &sp : s->spans) {
     s->t_ms[sp.kind] += rt::event_elapsed_ms(sp.a, sp.b);
     s->t_launches[sp.kind] += sp.launches;
-    s->t_sweeps[sp.kind] += 1;
+    s->t_sweeps[sp.kind] += 1;   // (a learning sweep split into chunks counts once per chunk)
     if (sp.has_pull) {
       s->t_ms[2] += rt::event_elapsed_ms(sp.b, sp.c);
       s->t_launches[2] += 1;
@@ -213,7 +373,7 @@ void dwx_default_options(dwx_options *o) {
   std::memset(o, 0, sizeof *o);
   o->regularization = 1;  // l2 (src/cmd_parser.cc:163-166)
   o->reg_param = 0.01;    // src/cmd_parser.cc:162
-  o->step_cap = 1.0;
+  o->step_cap = 1.5;   // stepsize * lambda of one SGD mini-batch (the hard limit is 2)
   o->seed = 0x5eed5eedULL;
 }
 
@@ -454,6 +614,9 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       }
     }
     rt::stream_sync(st);
+    // the un-split sweep's curvature estimate is needed by the first dwx_sgd_plan: pay
+    // for it here (one host pass over the records), not inside the first learning sweep
+    if (opts->step_cap > 0) (void)row_sum_bound(s.get(), 1);
   });
   if (rc != DWX_OK) return rc;
   *out = s.release();
@@ -474,33 +637,63 @@ void dwx_sampler_destroy(dwx_sampler *s) {
 int dwx_sample_async(dwx_sampler *s) {
   if (!s) return fail(DWX_E_INVALID, "null sampler");
   return guarded([&]() {
-    enqueue_sweep<false>(s);
+    enqueue_inference(s);
     ++s->infer_sweeps;
   });
 }
 
-int dwx_sgd_accumulate_async(dwx_sampler *s) {
-  if (!s) return fail(DWX_E_INVALID, "null sampler");
-  return guarded([&]() { enqueue_sweep<true>(s); });
-}
-
-int dwx_sgd_apply_async(dwx_sampler *s, double stepsize) {
+int dwx_sgd_plan(dwx_sampler *s, double stepsize, uint32_t force_batches, uint32_t *batches,
+                 uint32_t *n_chunks, double *effective_stepsize) {
   if (!s) return fail(DWX_E_INVALID, "null sampler");
   return guarded([&]() {
-    rt::set_device(s->device);
-    const uint32_t W = (uint32_t)s->cg->W;
-    if (!W) return;
-    const unsigned grid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 2048u);
-    rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
-               (const uint8_t *)s->d_w_fixed, s->d_grad, (const long long *)s->d_t_static, W,
-               stepsize, s->opts.step_cap, s->opts.reg_param, (int)(s->opts.regularization == 1));
+    make_plan(s, stepsize, force_batches);
+    if (batches) *batches = s->plan_batches;
+    if (n_chunks) *n_chunks = (uint32_t)s->plan_chunks.size();
+    if (effective_stepsize) *effective_stepsize = s->plan_eta;
   });
 }
 
+int dwx_sgd_get_chunks(dwx_sampler *s, uint64_t *chunk_off) {
+  if (!s || !chunk_off) return fail(DWX_E_INVALID, "null argument");
+  if (!s->plan_valid) return fail(DWX_E_INVALID, "no plan: call dwx_sgd_plan first");
+  const CompiledGraph &c = *s->cg;
+  size_t i = 0;
+  for (const auto &ch : s->plan_chunks) chunk_off[i++] = c.tile_v[ch.t0];
+  chunk_off[i] = s->plan_chunks.empty() ? 0 : c.tile_v[s->plan_chunks.back().t1];
+  return DWX_OK;
+}
+
+int dwx_sgd_accumulate_async(dwx_sampler *s, uint32_t chunk) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  if (!s->plan_valid) return fail(DWX_E_INVALID, "no plan: call dwx_sgd_plan first");
+  return guarded([&]() { enqueue_learn_chunk(s, chunk); });
+}
+
+int dwx_sgd_apply_async(dwx_sampler *s) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  if (!s->plan_valid) return fail(DWX_E_INVALID, "no plan: call dwx_sgd_plan first");
+  return guarded([&]() { enqueue_apply(s); });
+}
+
+int dwx_sgd_finish(dwx_sampler *s) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  ++s->sweep;
+  s->plan_valid = false;
+  return DWX_OK;
+}
+
 int dwx_sample_sgd_async(dwx_sampler *s, double stepsize) {
-  int rc = dwx_sgd_accumulate_async(s);
-  if (rc != DWX_OK) return rc;
-  return dwx_sgd_apply_async(s, stepsize);
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  return guarded([&]() {
+    make_plan(s, stepsize, 0);
+    const size_t n = s->plan_chunks.size();
+    for (size_t c = 0; c < n; ++c) {
+      enqueue_learn_chunk(s, (uint32_t)c);
+      if (s->plan_batches > 1 || c + 1 == n) enqueue_apply(s);
+    }
+    ++s->sweep;
+    s->plan_valid = false;
+  });
 }
 
 int dwx_wait(dwx_sampler *s) {

@@ -395,13 +395,14 @@ DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row
 
 // sgd_on_factor (src/factor_graph.cc:243-260), gradient accumulated in fixed point:
 // G[wid] += round(2^30 * t * (pot_free - pot_evid)),  T[wid] += round(2^30 * t).
-// COUNT_T = false for boolean variables: their update counts are static and were
-// folded into T_static on the host (dwx_sampler_create).
+// count_t = false for boolean variables of an un-split sweep: their update counts are
+// static and were folded into T_static on the host (dwx_sampler_create).
 // hit_value: the proposal that "hits" a pre-signed record of this row (1 for a boolean
 // variable, the row's value for a categorical one).
-template <bool COUNT_T, bool SIMPLE>
+template <bool SIMPLE>
 DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uint32_t me,
-                     uint32_t evid_value, uint32_t free_value, uint32_t hit_value, double t) {
+                     uint32_t evid_value, uint32_t free_value, uint32_t hit_value, double t,
+                     const bool count_t) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
@@ -410,13 +411,13 @@ DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uin
     const double pot_free = edge_term<SIMPLE>(P, er, e, P.assign_free, me, free_value, free_value == hit_value);
     const double g = pot_free - pot_evid;
     const long long gi = llrint(FIX_SCALE * (t * g));
-    const long long ti = COUNT_T ? llrint(FIX_SCALE * t) : 0;
+    const long long ti = count_t ? llrint(FIX_SCALE * t) : 0;
     if (T.agg) {   // workgroup-local accumulation in LDS (few, heavily shared weights)
       if (gi) atomicAdd((unsigned long long *)&T.agg[er.wid], (unsigned long long)gi);
-      if (COUNT_T) atomicAdd((unsigned long long *)&T.agg[P.num_weights + er.wid], (unsigned long long)ti);
+      if (count_t) atomicAdd((unsigned long long *)&T.agg[P.num_weights + er.wid], (unsigned long long)ti);
     } else {
       if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
-      if (COUNT_T) atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)ti);
+      if (count_t) atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)ti);
     }
   }
 }
@@ -510,9 +511,10 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
   if (!is_cat) {
     // a pre-signed record's gradient is (free hits ? A : B) - (evid hits ? A : B): zero
     // for the whole row when both chains agree (update counts are static, T_static)
-    if (SIMPLE && p_free == evid_value) return;
+    const bool dyn_t = P.flags & OPT_DYNAMIC_T;
+    if (SIMPLE && !dyn_t && p_free == evid_value) return;
     if (SIMPLE && delta) { *delta = (int)p_free - (int)evid_value; return; }
-    sgd_row<false, SIMPLE>(P, T, row0, p, evid_value, p_free, 1u, 1.0);
+    sgd_row<SIMPLE>(P, T, row0, p, evid_value, p_free, 1u, 1.0, dyn_t);
     return;
   }
   for (uint32_t val = 0; val < card; ++val) {
@@ -522,9 +524,9 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
       t = P.row_truth ? P.row_truth[row0 + val] : 0.0;
       if (is_linear_zero(t)) continue;
     }
-    sgd_row<true, SIMPLE>(P, T, row0 + val, p, val, p_free, val, t);
+    sgd_row<SIMPLE>(P, T, row0 + val, p, val, p_free, val, t, true);
     if (val == p_free) continue;
-    sgd_row<true, SIMPLE>(P, T, row0 + p_free, p, val, p_free, p_free, t);
+    sgd_row<SIMPLE>(P, T, row0 + p_free, p, val, p_free, p_free, t, true);
   }
 }
 
@@ -568,9 +570,10 @@ DWX_DEV void learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr
     const double pot_free = (double)(p_free ? r.sf1 : r.sf0);
     const double pot_evid = (double)(evid_value ? r.se1 : r.se0);
     const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
-    if (!gi) continue;
-    if (agg) atomicAdd((unsigned long long *)&agg[r.wid], (unsigned long long)gi);
-    else atomicAdd((unsigned long long *)&P.grad[r.wid], (unsigned long long)gi);
+    long long *dst = agg ? agg : P.grad;
+    if (gi) atomicAdd((unsigned long long *)&dst[r.wid], (unsigned long long)gi);
+    if (P.flags & OPT_DYNAMIC_T)
+      atomicAdd((unsigned long long *)&dst[P.num_weights + r.wid], (unsigned long long)(long long)FIX_SCALE);
   }
 }
 
@@ -824,7 +827,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
     if (!has_next) { dl.nedges = 0; dl.nrows = 0; dl.nv = 1; }
     issue_tile_loads<LEARN, K>(P, dl, t, f);
     // process the current tile out of LDS
-    const bool pull = LEARN && fits && (d.flags & TILE_PULL);   // workgroup-uniform
+    const bool pull = LEARN && fits && (d.flags & TILE_PULL) && !(P.flags & OPT_NO_PULL);   // uniform
     int delta = 0;
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
@@ -949,6 +952,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) giant_kernel(const KernelParams
       const double pot_free = edge_term<false>(P, er, e, P.assign_free, p, p_free, p_free == 1u);
       const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
       if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
+      if (P.flags & OPT_DYNAMIC_T)
+        atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)(long long)FIX_SCALE);
     }
   }
 }
@@ -1015,27 +1020,25 @@ pull_grad_kernel(const uint32_t *inc_wid, const uint32_t *inc_slot, const float 
 }
 
 // Batched InferenceResult::update_weight (src/inference_result.h:66-85): apply one
-// sweep's accumulated gradient to every non-fixed weight that received updates,
-// then clear the accumulators.  T = dynamic counts (categorical variables, atomics)
-// + static counts (boolean variables, precomputed).  Also refreshes the f32 sampling
-// copy of each weight it changes.
+// mini-batch's accumulated gradient to every non-fixed weight that received updates,
+// then clear the accumulators.  T = dynamic counts (atomics) + static counts (boolean
+// variables of an un-split sweep, precomputed; null when the sweep is split).  `stepsize`
+// is the plan's effective step (dwx_sgd_plan).  Also refreshes the f32 sampling copy of
+// each weight it changes.
 __global__ void __launch_bounds__(BLOCK_THREADS)
 apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *grad,
-             const long long *t_static, uint32_t W, double stepsize, double step_cap,
-             double reg_param, int l2) {
+             const long long *t_static, uint32_t W, double stepsize, double reg_param, int l2) {
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride) {
     const long long G = grad[i], Td = grad[W + i];
     if (G != 0 || Td != 0) { grad[i] = 0; grad[W + i] = 0; }
-    const long long Tn = Td + t_static[i];
+    const long long Tn = Td + (t_static ? t_static[i] : 0);
     if (w_fixed[i] || Tn == 0) continue;
     const double Tt = (double)Tn / FIX_SCALE, Gg = (double)G / FIX_SCALE;
-    double eta = stepsize;
-    if (step_cap > 0 && eta * Tt > step_cap) eta = step_cap / Tt;
     double x = weights[i];
-    if (l2) x *= pow(1.0 / (1.0 + reg_param * eta), Tt);
+    if (l2) x *= pow(1.0 / (1.0 + reg_param * stepsize), Tt);
     else x += reg_param * Tt * (x < 0 ? 1.0 : 0.0);
-    x -= eta * Gg;
+    x -= stepsize * Gg;
     weights[i] = x;
     w32[i] = (float)x;
   }

@@ -54,11 +54,17 @@ class HipEngine:
         with torch.cuda.stream(self.stream):
             dist.all_reduce(self.t_static, op=dist.ReduceOp.SUM, group=group)
 
-    def sgd_accumulate(self):
-        self.s.sgd_accumulate()
+    def sgd_plan(self, stepsize, force_batches=0):
+        return self.s.sgd_plan(stepsize, force_batches)
 
-    def sgd_apply(self, stepsize):
-        self.s.sgd_apply(stepsize)
+    def sgd_accumulate(self, chunk):
+        self.s.sgd_accumulate(chunk)
+
+    def sgd_apply(self):
+        self.s.sgd_apply()
+
+    def sgd_finish(self):
+        self.s.sgd_finish()
 
     def sample(self):
         self.s.sample()
@@ -159,10 +165,30 @@ class ShardedDimmWitted:
             self.halo.exchange(("free", "evid"))   # ghosts start from their owners' state
 
     def learn_epoch(self, stepsize):
-        self.e.sgd_accumulate()
+        """One learning sweep: plan the mini-batches (every rank must cut its block into the
+        same number of pieces, because every piece ends in a collective), then per chunk
+        accumulate -> all-reduce -> apply (un-split sweeps apply once, after the last chunk)."""
+        world = dist.get_world_size(self.group) if self.distributed else 1
+        # a weight's row sum adds up over shards: plan for the whole graph's step
+        batches, n_chunks, _ = self.e.sgd_plan(stepsize * world)
         if self.distributed:
-            self.e.allreduce_grad(self.group)
-        self.e.sgd_apply(stepsize)
+            t = torch.tensor([batches, n_chunks], dtype=torch.int64, device=self.e.grad.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            batches, n_chunks_all = int(t[0]), int(t[1])
+            # re-plan with the agreed batch count and this rank's true step
+            _, n_mine, _ = self.e.sgd_plan(stepsize, batches)
+            t = torch.tensor([n_mine], dtype=torch.int64, device=self.e.grad.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            n_chunks = int(t[0])
+        else:
+            _, n_chunks, _ = self.e.sgd_plan(stepsize, batches)
+        for c in range(n_chunks):
+            self.e.sgd_accumulate(c)          # ranks with fewer chunks idle through the rest
+            if batches > 1 or c + 1 == n_chunks:
+                if self.distributed:
+                    self.e.allreduce_grad(self.group)
+                self.e.sgd_apply()
+        self.e.sgd_finish()
         if self.halo is not None:
             self.halo.exchange(("free", "evid"))
 

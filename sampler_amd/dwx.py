@@ -24,7 +24,8 @@ SYMBOLS = [
     "dwx_graph_create", "dwx_graph_destroy", "dwx_graph_get_info", "dwx_graph_get_schedule",
     "dwx_graph_get_values", "dwx_graph_get_positions", "dwx_graph_get_index",
     "dwx_sampler_create", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
-    "dwx_wait", "dwx_sgd_accumulate_async", "dwx_sgd_apply_async",
+    "dwx_wait", "dwx_sgd_plan", "dwx_sgd_get_chunks", "dwx_sgd_accumulate_async",
+    "dwx_sgd_apply_async", "dwx_sgd_finish",
     "dwx_get_weights", "dwx_set_weights", "dwx_clear_tallies", "dwx_get_tallies",
     "dwx_get_assignments", "dwx_set_assignments", "dwx_get_sweep", "dwx_set_sweep",
     "dwx_device_buffer", "dwx_stream", "dwx_kernel_time", "dwx_kernel_time_reset",
@@ -87,8 +88,11 @@ class Library:
         L.dwx_sample_async.argtypes = [vp]
         L.dwx_sample_sgd_async.argtypes = [vp, dbl]
         L.dwx_wait.argtypes = [vp]
-        L.dwx_sgd_accumulate_async.argtypes = [vp]
-        L.dwx_sgd_apply_async.argtypes = [vp, dbl]
+        L.dwx_sgd_plan.argtypes = [vp, dbl, C.c_uint32, vp, vp, vp]
+        L.dwx_sgd_get_chunks.argtypes = [vp, vp]
+        L.dwx_sgd_accumulate_async.argtypes = [vp, C.c_uint32]
+        L.dwx_sgd_apply_async.argtypes = [vp]
+        L.dwx_sgd_finish.argtypes = [vp]
         L.dwx_get_weights.argtypes = [vp, vp]; L.dwx_set_weights.argtypes = [vp, vp]
         L.dwx_clear_tallies.argtypes = [vp]
         L.dwx_get_tallies.argtypes = [vp, vp, vp]
@@ -175,7 +179,7 @@ class GibbsSampler:
 
     def __init__(self, graph: Graph, device=0, sample_evidence=False, learn_non_evidence=False,
                  noise_aware=False, regularization="l2", reg_param=0.01, seed=0x5eed5eed,
-                 step_cap=1.0, var_id_offset=0):
+                 step_cap=1.5, var_id_offset=0):
         self.lib = graph.lib
         self.graph = graph
         o = Options()
@@ -215,12 +219,27 @@ class GibbsSampler:
     def wait(self):
         self.lib.check(self.lib.L.dwx_wait(self.h))
 
-    # ---- split learning sweep (multi-GPU) ----
-    def sgd_accumulate(self):
-        self.lib.check(self.lib.L.dwx_sgd_accumulate_async(self.h))
+    # ---- a learning sweep in pieces (multi-GPU drivers, parity tests) ----
+    def sgd_plan(self, stepsize, force_batches=0):
+        """-> (batches, n_chunks, effective_stepsize); see dwx_sgd_plan in include/dwx.h."""
+        b, n, e = C.c_uint32(), C.c_uint32(), C.c_double()
+        self.lib.check(self.lib.L.dwx_sgd_plan(self.h, stepsize, force_batches, C.byref(b), C.byref(n),
+                                               C.byref(e)))
+        return b.value, n.value, e.value
 
-    def sgd_apply(self, stepsize):
-        self.lib.check(self.lib.L.dwx_sgd_apply_async(self.h, stepsize))
+    def sgd_chunks(self, n_chunks):
+        off = np.zeros(n_chunks + 1, np.uint64)
+        self.lib.check(self.lib.L.dwx_sgd_get_chunks(self.h, off.ctypes.data))
+        return off
+
+    def sgd_accumulate(self, chunk):
+        self.lib.check(self.lib.L.dwx_sgd_accumulate_async(self.h, chunk))
+
+    def sgd_apply(self):
+        self.lib.check(self.lib.L.dwx_sgd_apply_async(self.h))
+
+    def sgd_finish(self):
+        self.lib.check(self.lib.L.dwx_sgd_finish(self.h))
 
     # ---- InferenceResult state ----
     @property

@@ -32,15 +32,21 @@ class OracleEngine:
     def allreduce_static_counts(self, group=None):
         self.static_reduced = True                     # the oracle counts T dynamically
 
-    def sgd_accumulate(self):
+    def sgd_plan(self, stepsize, force_batches=0):
+        self.eta = stepsize          # the driver's last call carries this rank's true step
+        return 1, 1, stepsize
+
+    def sgd_accumulate(self, chunk):
         self.o.sched_accumulate(self.order, self.off, self.seed, self.sweep)
+
+    def sgd_finish(self):
         self.sweep += 1
 
     def allreduce_grad(self, group=None):
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
-    def sgd_apply(self, stepsize):
-        self.o.sched_apply(stepsize, 1.0)
+    def sgd_apply(self):
+        self.o.sched_apply(self.eta, 0.0)
 
     def sample(self):
         self.o.sched_sample(self.order, self.off, self.seed, self.sweep)

@@ -45,16 +45,22 @@ class OracleShardEngine:
     def allreduce_static_counts(self, group=None):
         pass
 
-    def sgd_accumulate(self):
+    def sgd_plan(self, stepsize, force_batches=0):
+        self.eta = stepsize
+        return 1, 1, stepsize
+
+    def sgd_accumulate(self, chunk):
         self._prep()
         self.o.sched_accumulate(self.order_local, self.off, SEED, self.sweep)
+
+    def sgd_finish(self):
         self.sweep += 1
 
     def allreduce_grad(self, group=None):
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
-    def sgd_apply(self, stepsize):
-        self.o.sched_apply(stepsize, 1.0)
+    def sgd_apply(self):
+        self.o.sched_apply(self.eta, 0.0)
 
     def sample(self):
         self._prep()

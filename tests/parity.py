@@ -38,6 +38,21 @@ def check_index_parity(graph: dwx.Graph, oracle: orc.Oracle):
             assert np.array_equal(fi[int(ib[r]):int(ib[r]) + n], of[int(ob[r]):int(ob[r]) + n])
 
 
+def learn_sweep_both(s, o, order, seed, sweep, stepsize):
+    """One learning sweep on the device and, mirrored, on the oracle: the device cuts a
+    sweep into mini-batches (dwx_sgd_plan); the oracle follows the same chunk boundaries --
+    accumulate over each chunk's variables, apply where the device applies."""
+    batches, n_chunks, eta = s.sgd_plan(stepsize)
+    chunk_off = s.sgd_chunks(n_chunks)
+    s.sample_sgd(stepsize); s.wait()
+    for c in range(n_chunks):
+        sl = order[int(chunk_off[c]):int(chunk_off[c + 1])]
+        o.sched_accumulate(sl, np.array([0, len(sl)], np.uint64), seed, sweep)
+        if batches > 1 or c + 1 == n_chunks:
+            o.sched_apply(eta, 0.0)
+    return batches
+
+
 def run_parity(lib, raw, n_learn=3, n_infer=5, stepsize=0.05, decay=0.9, seed=77,
                sample_evidence=False, learn_non_evidence=False, noise_aware=False,
                regularization="l2", reg_param=0.01, step_cap=1.0, compile_opts=None,
@@ -59,8 +74,7 @@ def run_parity(lib, raw, n_learn=3, n_infer=5, stepsize=0.05, decay=0.9, seed=77
     sweep = 0
     cur = stepsize
     for _ in range(n_learn):
-        s.sample_sgd(cur); s.wait()
-        o.sched_sample_sgd(order, off, seed, sweep, cur, step_cap)
+        learn_sweep_both(s, o, order, seed, sweep, cur)
         sweep += 1
         cur *= decay
         assert np.array_equal(s.assignments("free"), o.assignments("free")), "free chain differs"

@@ -68,7 +68,7 @@ def test_two_rank_sharded_learning_equals_single_process():
     off = np.array([0, union.num_variables], np.uint64)
     sweep, cur = 0, 0.05
     for _ in range(6):
-        o.sched_sample_sgd(order, off, 4242, sweep, cur, 1.0); sweep += 1; cur *= 0.9
+        o.sched_sample_sgd(order, off, 4242, sweep, cur, 0.0); sweep += 1; cur *= 0.9
     o.clear_tallies()
     for _ in range(4):
         o.sched_sample(order, off, 4242, sweep); sweep += 1

@@ -71,11 +71,13 @@ def _lockstep(total, world):
     cur = hw.STEP
     for _ in range(hw.N_LEARN):
         for e in engines:
-            e.sgd_accumulate()
+            e.sgd_plan(cur)
+            e.sgd_accumulate(0)
         total_grad = sum(e.o.grad.copy() for e in engines)
         for e in engines:
             e.o.grad[:] = total_grad
-            e.sgd_apply(cur)
+            e.sgd_apply()
+            e.sgd_finish()
         exchange(("free", "evid"))
         cur *= hw.DECAY
     for e in engines:

@@ -108,8 +108,8 @@ def test_ghost_variables_parity(lib):
             s.set_assignments(chain, a)
             o.assignments(chain)[:] = a
         if it % 2 == 0:
-            s.sample_sgd(0.05); s.wait()
-            o.sched_sample_sgd(order, off, 77, sweep, 0.05, 1.0)
+            from parity import learn_sweep_both
+            learn_sweep_both(s, o, order, 77, sweep, 0.05)
         else:
             s.sample(); s.wait()
             o.sched_sample(order, off, 77, sweep)
@@ -153,3 +153,31 @@ def test_high_degree_hub_variables(lib):
     s, _ = run_parity(lib, raw, n_learn=4, n_infer=6, stepsize=0.001, learn_non_evidence=True)
     assert s.graph.info.num_giant_tiles == 2
     run_parity(lib, hub_graph(4, W=2000), n_learn=3, n_infer=3, stepsize=0.001, sample_evidence=True)
+
+
+def test_split_sweep_parity_and_heavy_tying_learns_like_the_reference(lib):
+    """Heavily tied weights (hundreds of SGD updates per weight and sweep, every variable
+    couples 10 weights) with a large step: one batched update per sweep would be outside
+    its stability region (it learns mean weight 0.3 where the reference learns 0.04).  The
+    plan must split the sweep into mini-batches; the split sweep must (a) match the oracle
+    exactly when the oracle follows the same chunks and (b) learn what the REFERENCE
+    semantics (sequential in-place updates, oracle reference mode) learn."""
+    from oracle import binding as orc
+    from sampler_amd import dwx
+    raw = synthetic.cfg3(20_000, n_weights=200, seed=2024)
+    s, o = run_parity(lib, raw, n_learn=3, n_infer=1, stepsize=0.01, decay=0.95)
+    g = dwx.Graph(raw, lib=lib)
+    s = dwx.GibbsSampler(g, seed=5, reg_param=0.01)
+    batches, n_chunks, eta = s.sgd_plan(0.01)
+    assert batches >= 8 and n_chunks == batches and 0.005 < eta <= 0.01
+    assert s.sgd_plan(1e-5)[0] == 1                      # tiny step: no split
+    dwx.DimmWitted(s, 30, 0, 0.01, 0.95).learn()
+    ref = orc.Oracle(raw, reg_param=0.01)
+    ref.set_workers(1)
+    ref.learn(30, 0.01, 0.95)
+    w, wr = s.weights, ref.weights
+    assert abs(w.mean() - wr.mean()) < 0.01 and abs(w.std() - wr.std()) < 0.015, (w.mean(), wr.mean())
+    assert np.corrcoef(w, wr)[0, 1] > 0.6
+    # with splitting disabled (step_cap <= 0) the same run drifts far away
+    s1 = dwx.GibbsSampler(g, seed=5, reg_param=0.01, step_cap=0.0)
+    assert s1.sgd_plan(0.01)[0] == 1
