@@ -296,9 +296,11 @@ DWX_DEV uint32_t bool_draw(double r, double pp, double pn) {
 template <int WMODE, bool SIMPLE>
 DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row0, uint32_t card,
                           const uint32_t *assign, uint32_t me, double r) {
-  if (card <= SMALL_CARD) {
-    // Small domains (the usual case): potentials live in registers (fully unrolled, no
-    // dynamic indexing), each row pointer is read once -- no LDS scratch traffic.
+  if (SIMPLE && card <= SMALL_CARD) {
+    // Small domains, all-unary tile (the usual case): potentials live in registers (fully
+    // unrolled, no dynamic indexing), each row pointer is read once -- no LDS scratch
+    // traffic.  (Not instantiated for the generic factor code: 8 inlined copies of it
+    // would bloat the kernel far beyond the instruction cache.)
     double pot[SMALL_CARD];
     uint32_t es = T.rowptr[row0 - T.row_bias];
     double m = -1e300;
@@ -440,11 +442,11 @@ DWX_DEV VarPre load_var_pre(const KernelParams &P, uint32_t p) {
   return v;
 }
 
-// `delta` (learning, TILE_PULL tiles only): receives hit(free) - hit(evid) in {-1,0,+1} for
-// a variable that triggers SGD, instead of the gradient atomics.
+// want_delta (learning, TILE_PULL tiles only): instead of scattering gradient atomics,
+// return hit(free) - hit(evid) in {-1,0,+1} for a variable that triggers SGD (0 otherwise).
 template <bool LEARN, int WMODE, bool SIMPLE>
-DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t p,
-                              const VarPre pre, double A, double B, int *delta = nullptr) {
+DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t p,
+                             const VarPre pre, double A, double B, const bool want_delta = false) {
   const uint32_t meta = pre.meta;
   const bool is_cat = meta & VM_CATEGORICAL;
   const bool is_evid = meta & VM_EVIDENCE;
@@ -452,7 +454,7 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
   const uint32_t row0 = pre.row0;
   if (!LEARN) {
     // sample_single_variable (src/gibbs_sampler.h:151-169)
-    if (is_evid && !(P.flags & OPT_SAMPLE_EVIDENCE)) return;
+    if (is_evid && !(P.flags & OPT_SAMPLE_EVIDENCE)) return 0;
     uint32_t prop;
     if (!is_cat) {
       double pp, pn;
@@ -466,7 +468,7 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
       atomicAdd(&P.tally[row0 + prop], 1u);
     }
     P.assign_evid[p] = prop;
-    return;
+    return 0;
   }
   // sample_sgd_single_variable (src/gibbs_sampler.h:127-149)
   const bool noise_aware = P.flags & OPT_NOISE_AWARE;
@@ -506,16 +508,16 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
   // src/gibbs_sampler.h:144-146
   if (!(P.flags & OPT_LEARN_NON_EVIDENCE) &&
       ((!noise_aware && !is_evid) || (noise_aware && !has_truth)))
-    return;
+    return 0;
   // sgd_on_variable (src/factor_graph.cc:262-314)
   if (!is_cat) {
     // a pre-signed record's gradient is (free hits ? A : B) - (evid hits ? A : B): zero
     // for the whole row when both chains agree (update counts are static, T_static)
     const bool dyn_t = P.flags & OPT_DYNAMIC_T;
-    if (SIMPLE && !dyn_t && p_free == evid_value) return;
-    if (SIMPLE && delta) { *delta = (int)p_free - (int)evid_value; return; }
+    if (SIMPLE && !dyn_t && p_free == evid_value) return 0;
+    if (SIMPLE && want_delta) return (int)p_free - (int)evid_value;
     sgd_row<SIMPLE>(P, T, row0, p, evid_value, p_free, 1u, 1.0, dyn_t);
-    return;
+    return 0;
   }
   for (uint32_t val = 0; val < card; ++val) {
     if (!noise_aware && val != evid_value) continue;
@@ -528,6 +530,7 @@ DWX_DEV void process_variable(const KernelParams &P, const TileView &T, uint32_t
     if (val == p_free) continue;
     sgd_row<SIMPLE>(P, T, row0 + p_free, p, val, p_free, p_free, t, true);
   }
+  return 0;
 }
 
 // ---------------------------------------------------------------- learning, TILE_TERMS2
@@ -834,8 +837,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
       if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2))
         learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B);
       else if ((d.flags & TILE_SIMPLE) || (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)))
-        process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B,
-                                                                  pull ? &delta : nullptr);
+        delta = process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B, pull);
       else
         process_variable<LEARN, WMODE, false>(P, T, d.v0 + t, pre, A, B);
     }
