@@ -162,6 +162,8 @@ def main():
         elapsed = float(t.item())
     w = sampler.weights
     assert np.isfinite(w).all()
+    # mini-batch plan at the LARGEST step of the run: 1 = un-split sweeps
+    plan_batches, _, plan_eta = sampler.sgd_plan(stepsize * n_gpus)
 
     if rank == 0:
         total_vars = 2.0 * V * n_gpus * args.steps
@@ -197,6 +199,7 @@ def main():
                 "parallelism": "variable-block shards x%d, int64 gradient all-reduce per "
                                "learning sweep" % n_gpus if n_gpus > 1 else "single GPU",
                 "stepsize": stepsize, "diminish": decay, "reg_param": reg,
+                "sgd_batches_per_sweep": plan_batches, "effective_stepsize": plan_eta / n_gpus,
             },
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

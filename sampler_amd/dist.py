@@ -158,6 +158,8 @@ class ShardedDimmWitted:
         self.decay = decay
         self.group = group
         self.halo = halo          # HaloExchange or None (no cross-shard factors)
+        self._unsplit_upto = None  # largest step all ranks agreed to run as one batch ...
+        self._unsplit_chunks = 1   # ... and the (step-independent) launch count of that plan
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         if self.distributed:
             self.e.allreduce_static_counts(group)
@@ -169,6 +171,26 @@ class ShardedDimmWitted:
         same number of pieces, because every piece ends in a collective), then per chunk
         accumulate -> all-reduce -> apply (un-split sweeps apply once, after the last chunk)."""
         world = dist.get_world_size(self.group) if self.distributed else 1
+        if self.distributed and self._unsplit_upto is not None and stepsize <= self._unsplit_upto:
+            # the batch count is monotone in the step: once every rank agreed on an un-split
+            # sweep at some step, smaller steps need no agreement round (and no host sync)
+            batches, n_chunks = 1, self._unsplit_chunks
+            self.e.sgd_plan(stepsize, 1)
+        else:
+            batches, n_chunks = self._agree_plan(stepsize, world)
+            if self.distributed and batches == 1:
+                self._unsplit_upto, self._unsplit_chunks = stepsize, n_chunks
+        for c in range(n_chunks):
+            self.e.sgd_accumulate(c)          # ranks with fewer chunks idle through the rest
+            if batches > 1 or c + 1 == n_chunks:
+                if self.distributed:
+                    self.e.allreduce_grad(self.group)
+                self.e.sgd_apply()
+        self.e.sgd_finish()
+        if self.halo is not None:
+            self.halo.exchange(("free", "evid"))
+
+    def _agree_plan(self, stepsize, world):
         # a weight's row sum adds up over shards: plan for the whole graph's step
         batches, n_chunks, _ = self.e.sgd_plan(stepsize * world)
         if self.distributed:
@@ -182,15 +204,7 @@ class ShardedDimmWitted:
             n_chunks = int(t[0])
         else:
             _, n_chunks, _ = self.e.sgd_plan(stepsize, batches)
-        for c in range(n_chunks):
-            self.e.sgd_accumulate(c)          # ranks with fewer chunks idle through the rest
-            if batches > 1 or c + 1 == n_chunks:
-                if self.distributed:
-                    self.e.allreduce_grad(self.group)
-                self.e.sgd_apply()
-        self.e.sgd_finish()
-        if self.halo is not None:
-            self.halo.exchange(("free", "evid"))
+        return batches, n_chunks
 
     def learn(self):
         cur = self.stepsize

@@ -19,7 +19,13 @@ from sampler_amd.dist import ShardedDimmWitted, shard_range  # noqa: E402
 class OracleEngine:
     """Same interface as HipEngine, state in the CPU oracle (schedule mode)."""
 
-    def __init__(self, raw, seed, var_id_offset, reg_param):
+    def __init__(self, raw, seed, var_id_offset, reg_param, split_above=None, max_chunks=1):
+        # split_above: steps larger than this are cut into 4 mini-batches (a stand-in for
+        # the curvature plan of dwx_sgd_plan); max_chunks: this rank's tile count, so that
+        # ranks can end up with different chunk counts
+        self.split_above, self.max_chunks = split_above, max_chunks
+        self.n_chunks = 1
+        self.plans = []
         self.o = orc.Oracle(raw, reg_param=reg_param)
         self.o.set_var_id_offset(var_id_offset)
         self.order = np.arange(raw.num_variables, dtype=np.uint64)
@@ -34,10 +40,20 @@ class OracleEngine:
 
     def sgd_plan(self, stepsize, force_batches=0):
         self.eta = stepsize          # the driver's last call carries this rank's true step
-        return 1, 1, stepsize
+        batches = force_batches or (4 if self.split_above is not None and stepsize > self.split_above else 1)
+        self.n_chunks = min(batches, self.max_chunks)
+        self.plans.append((stepsize, force_batches, batches))
+        return batches, self.n_chunks, stepsize
+
+    def chunk_vars(self, chunk, n_chunks=None):
+        n, V = n_chunks or self.n_chunks, len(self.order)
+        return self.order[V * chunk // n:V * (chunk + 1) // n]
 
     def sgd_accumulate(self, chunk):
-        self.o.sched_accumulate(self.order, self.off, self.seed, self.sweep)
+        if chunk >= self.n_chunks:
+            return                   # fewer chunks than the slowest rank: idle
+        sl = self.chunk_vars(chunk)
+        self.o.sched_accumulate(sl, np.array([0, len(sl)], np.uint64), self.seed, self.sweep)
 
     def sgd_finish(self):
         self.sweep += 1
@@ -67,14 +83,17 @@ def main():
     total, W, seed = int(sys.argv[2]), int(sys.argv[3]), 4242
     dist.init_process_group("gloo", rank=rank, world_size=world)
     raw, begin = shard_graph(total, W, rank, world, 1234)
-    eng = OracleEngine(raw, seed, begin, 0.01)
+    split = os.environ.get("DWX_TEST_SPLIT_ABOVE")
+    eng = OracleEngine(raw, seed, begin, 0.01, split_above=float(split) if split else None,
+                       max_chunks=(4, 3)[rank % 2] if split else 1)
     drv = ShardedDimmWitted(eng, n_learning_epoch=6, n_inference_epoch=4, stepsize=0.05, decay=0.9)
     assert drv.distributed and eng.static_reduced
     drv.learn()
     eng.o.clear_tallies()
     drv.inference()
     np.savez(os.path.join(out, "rank%d.npz" % rank), weights=eng.o.weights, tallies=eng.o.tallies,
-             free=eng.o.assignments("free"), evid=eng.o.assignments("evid"), begin=begin)
+             free=eng.o.assignments("free"), evid=eng.o.assignments("evid"), begin=begin,
+             plans=np.array(eng.plans, np.float64))
     dist.barrier()
     dist.destroy_process_group()
 

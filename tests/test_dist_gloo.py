@@ -88,3 +88,61 @@ def test_shard_range_covers_everything():
             r = [shard_range(total, k, world) for k in range(world)]
             assert r[0][0] == 0 and r[-1][1] == total
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+
+
+def test_two_rank_split_sweeps_agree_on_the_plan_and_match_single_process():
+    """Mini-batched learning across ranks: steps above a threshold are cut into 4 batches,
+    rank 1 can only cut into 3 (fewer tiles) and idles through the 4th collective; once the
+    step has decayed below the threshold the sweep is un-split and the driver stops
+    negotiating.  Result = one process running the same chunk sequence on the union graph."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import shard_graph
+    total, W, world, thr = 1200, 40, 2, 0.07
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as out:
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), LOCAL_RANK=str(r), DWX_TEST_SPLIT_ABOVE=str(thr))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"),
+                                           out, str(total), str(W)], env=env))
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        res = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
+    assert np.array_equal(res[0]["weights"], res[1]["weights"])
+    shards = [shard_graph(total, W, r, world, 1234)[0] for r in range(world)]
+    union = _concat(shards)
+    o = orc.Oracle(union, reg_param=0.01)
+    nv = [g.num_variables for g in shards]
+    base = [0, nv[0]]
+    max_chunks = (4, 3)
+    order = np.arange(union.num_variables, dtype=np.uint64)
+    sweep, cur, n_split = 0, 0.05, 0
+    for _ in range(6):
+        split = cur * world > thr          # the driver plans for the whole graph's step
+        n_split += split
+        n_chunks = 4 if split else 1
+        for c in range(n_chunks):
+            parts = []
+            for r in range(world):
+                n_r = min(4 if split else 1, max_chunks[r])
+                if c < n_r:
+                    parts.append(order[base[r] + nv[r] * c // n_r:base[r] + nv[r] * (c + 1) // n_r])
+            sl = np.concatenate(parts)
+            o.sched_accumulate(sl, np.array([0, len(sl)], np.uint64), 4242, sweep)
+            if split or c + 1 == n_chunks:
+                o.sched_apply(cur, 0.0)
+        sweep += 1; cur *= 0.9
+    assert 0 < n_split < 6                 # both regimes and the transition were exercised
+    o.clear_tallies()
+    all_order, off = order, np.array([0, union.num_variables], np.uint64)
+    for _ in range(4):
+        o.sched_sample(all_order, off, 4242, sweep); sweep += 1
+    assert np.array_equal(res[0]["weights"], o.weights)
+    for r in range(world):
+        b = int(res[r]["begin"]); n = len(res[r]["free"])
+        assert np.array_equal(res[r]["free"], o.assignments("free")[b:b + n])
+        assert np.array_equal(res[r]["evid"], o.assignments("evid")[b:b + n])
+    # negotiation stops once an un-split plan was agreed: the last sweep only re-plans locally
+    plans = res[0]["plans"]
+    assert plans[-1][1] == 1 and plans[-2][1] == 1 and plans[0][1] == 0
