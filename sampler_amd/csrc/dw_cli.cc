@@ -1,12 +1,15 @@
 // dw_cli.cc -- see dw_cli.h.  Plain C++17; talks to the sampler only through the C ABI.
 #include "dw_cli.h"
 
+#include "host_parallel.h"
+
 #include <endian.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -343,38 +346,110 @@ void load_domains(const std::vector<std::string> &files, LoadedGraph &g) {
   }
 }
 
-// src/binary_format.cc:128-190; factor ids are assigned in read order
+// src/binary_format.cc:128-190; factor ids are assigned in read order.
+// Records have variable length, so a file is first cut at record boundaries -- for free
+// when every record has the arity of the first one (what text2bin writes: one arity per
+// file), which the parse itself verifies; otherwise by a hop over the arity fields -- and
+// the pieces are decoded in parallel straight into the columns.
+namespace {
+struct Piece { size_t off; uint64_t n_rec, f0, e0; size_t end; };
+
+// decode one piece; returns false if its records do not end where the cut said
+bool parse_piece(const Mapped &m, const std::string &path, const Piece &pc, LoadedGraph &g,
+                 bool speculative) {
+  size_t off = pc.off;
+  uint64_t f = pc.f0, e = pc.e0;
+  for (uint64_t r = 0; r < pc.n_rec; ++r, ++f) {
+    if (off + 10 > m.n) {
+      if (speculative) return false;
+      throw std::runtime_error(path + ": truncated factor record");
+    }
+    const uint16_t func = be16(m.p + off);
+    const uint64_t arity = be64(m.p + off + 2);
+    off += 10;
+    if (arity > (m.n - off) / 16 || off + 16 * arity + 16 > m.n) {
+      if (speculative) return false;
+      throw std::runtime_error(path + ": truncated factor record");
+    }
+    if (f >= g.n_factors || arity > g.n_edges - e) return false;   // more than the meta file announced
+    g.fac_func[f] = func;
+    g.fac_edge_offset[f] = e;
+    for (uint64_t i = 0; i < arity; ++i, off += 16, ++e) {
+      g.edge_vid[e] = be64(m.p + off);
+      g.edge_equal_to[e] = be64(m.p + off + 8);
+    }
+    g.fac_weight_id[f] = be64(m.p + off);
+    g.fac_feature_value[f] = bef64(m.p + off + 8);
+    off += 16;
+  }
+  return off == pc.end;
+}
+}  // namespace
+
 void load_factors(const std::vector<std::string> &files, LoadedGraph &g) {
-  g.fac_func.clear(); g.fac_edge_offset.assign(1, 0); g.fac_weight_id.clear();
-  g.fac_feature_value.clear(); g.edge_vid.clear(); g.edge_equal_to.clear();
-  g.fac_func.reserve(g.n_factors); g.fac_weight_id.reserve(g.n_factors);
-  g.fac_feature_value.reserve(g.n_factors); g.fac_edge_offset.reserve(g.n_factors + 1);
-  g.edge_vid.reserve(g.n_edges); g.edge_equal_to.reserve(g.n_edges);
+  g.fac_func.reset(g.n_factors); g.fac_edge_offset.reset(g.n_factors + 1);
+  g.fac_weight_id.reset(g.n_factors); g.fac_feature_value.reset(g.n_factors);
+  g.edge_vid.reset(g.n_edges); g.edge_equal_to.reset(g.n_edges);
+  const uint32_t nth = dwx::host_threads();
+  const uint64_t kPiece = 1 << 16;   // records per piece
+  uint64_t f_base = 0, e_base = 0;
   for (const auto &path : files) {
     Mapped m(path);
-    size_t off = 0;
-    while (off < m.n) {
-      if (off + 10 > m.n) throw std::runtime_error(path + ": truncated factor record");
-      uint16_t func = be16(m.p + off);
-      uint64_t arity = be64(m.p + off + 2);
-      off += 10;
-      if (arity > (m.n - off) / 16 || off + 16 * arity + 16 > m.n)
-        throw std::runtime_error(path + ": truncated factor record");
-      g.fac_func.push_back(func);
-      for (uint64_t i = 0; i < arity; ++i, off += 16) {
-        g.edge_vid.push_back(be64(m.p + off));
-        g.edge_equal_to.push_back(be64(m.p + off + 8));
+    if (m.n == 0) continue;
+    if (m.n < 10) throw std::runtime_error(path + ": truncated factor record");
+    std::vector<Piece> pieces;
+    bool done = false;
+    // (1) optimistic: fixed stride of the first record
+    const uint64_t a0 = be64(m.p + 2);
+    if (a0 <= (m.n - 10) / 16) {
+      const size_t rs = 26 + 16 * a0;
+      if (m.n % rs == 0) {
+        const uint64_t n = m.n / rs;
+        for (uint64_t r = 0; r < n; r += kPiece) {
+          const uint64_t k = std::min(kPiece, n - r);
+          pieces.push_back({(size_t)(r * rs), k, f_base + r, e_base + r * a0, (size_t)((r + k) * rs)});
+        }
+        std::atomic<bool> ok{n <= g.n_factors - f_base};
+        if (ok)
+          dwx::parallel_ranges(pieces.size(), nth, [&](uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e && ok; ++i)
+              if (!parse_piece(m, path, pieces[i], g, true)) ok = false;
+          });
+        if (ok) { f_base += n; e_base += n * a0; done = true; }
       }
-      g.fac_edge_offset.push_back(g.edge_vid.size());
-      g.fac_weight_id.push_back(be64(m.p + off));
-      g.fac_feature_value.push_back(bef64(m.p + off + 8));
-      off += 16;
+    }
+    if (!done) {
+      // (2) general: hop from record to record reading only the arity, cut every kPiece
+      pieces.clear();
+      size_t off = 0;
+      uint64_t f = f_base, e = e_base;
+      Piece cur{0, 0, f, e, 0};
+      while (off < m.n) {
+        if (off + 10 > m.n) throw std::runtime_error(path + ": truncated factor record");
+        const uint64_t arity = be64(m.p + off + 2);
+        if (arity > (m.n - off - 10) / 16 || off + 26 + 16 * arity > m.n)
+          throw std::runtime_error(path + ": truncated factor record");
+        off += 26 + 16 * arity;
+        ++f; e += arity;
+        if (++cur.n_rec == kPiece) { cur.end = off; pieces.push_back(cur); cur = Piece{off, 0, f, e, 0}; }
+      }
+      if (cur.n_rec) { cur.end = off; pieces.push_back(cur); }
+      if (f > g.n_factors)
+        throw std::runtime_error("factor count " + std::to_string(f) + " != meta " + std::to_string(g.n_factors));
+      if (e > g.n_edges)
+        throw std::runtime_error("edge count " + std::to_string(e) + " != meta " + std::to_string(g.n_edges));
+      dwx::parallel_ranges(pieces.size(), nth, [&](uint64_t b, uint64_t pe) {
+        for (uint64_t i = b; i < pe; ++i)
+          if (!parse_piece(m, path, pieces[i], g, false)) throw std::runtime_error(path + ": inconsistent factor records");
+      });
+      f_base = f; e_base = e;
     }
   }
-  if (g.fac_func.size() != g.n_factors)
-    throw std::runtime_error("factor count " + std::to_string(g.fac_func.size()) + " != meta " + std::to_string(g.n_factors));
-  if (g.edge_vid.size() != g.n_edges)
-    throw std::runtime_error("edge count " + std::to_string(g.edge_vid.size()) + " != meta " + std::to_string(g.n_edges));
+  if (f_base != g.n_factors)
+    throw std::runtime_error("factor count " + std::to_string(f_base) + " != meta " + std::to_string(g.n_factors));
+  if (e_base != g.n_edges)
+    throw std::runtime_error("edge count " + std::to_string(e_base) + " != meta " + std::to_string(g.n_edges));
+  g.fac_edge_offset[g.n_factors] = g.n_edges;
 }
 
 dwx_graph_desc LoadedGraph::desc() const {
@@ -394,9 +469,34 @@ dwx_graph_desc LoadedGraph::desc() const {
 }
 
 // ------------------------------------------------------------------ dumps
+// Both dumps format variable ranges in parallel into per-thread buffers and write them
+// out in order.  "%g" is what `ostream << double` prints at the default precision 6, so the
+// bytes equal the reference's (tests/test_dw_cli.py, tests/test_end_to_end.py).
+namespace {
+template <class LineFn>
+void dump_parallel(std::ostream &o, uint64_t n, LineFn &&line) {
+  const uint32_t nth = dwx::host_threads();
+  std::vector<std::string> bufs(nth);
+  dwx::parallel_parts(n, nth, [&](uint32_t t, uint64_t b, uint64_t e) {
+    std::string &s = bufs[t];
+    s.reserve((e - b) * 24);
+    for (uint64_t i = b; i < e; ++i) line(i, s);
+  });
+  for (const std::string &s : bufs) o.write(s.data(), (std::streamsize)s.size());
+}
+inline void append_line(std::string &s, uint64_t a, double x) {
+  char tmp[64];
+  s.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "%llu %g\n", (unsigned long long)a, x));
+}
+inline void append_line(std::string &s, uint64_t a, uint64_t b, double x) {
+  char tmp[96];
+  s.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "%llu %llu %g\n", (unsigned long long)a, (unsigned long long)b, x));
+}
+}  // namespace
+
 // src/inference_result.cc:101-105
 void dump_weights_in_text(std::ostream &o, const std::vector<double> &w) {
-  for (size_t j = 0; j < w.size(); ++j) o << j << " " << w[j] << '\n';   // (no per-line flush)
+  dump_parallel(o, w.size(), [&](uint64_t j, std::string &s) { append_line(s, j, w[j]); });
 }
 
 // src/inference_result.cc:211-243
@@ -405,16 +505,16 @@ void dump_marginals_in_text(std::ostream &o, const LoadedGraph &g, bool sample_e
                             const std::vector<uint64_t> &value_sparse,
                             const std::vector<uint64_t> &tallies,
                             const std::vector<uint64_t> &nsamples) {
-  for (uint64_t v = 0; v < g.n_variables; ++v) {
-    if (g.var_role[v] >= 1 && !sample_evidence) continue;
+  dump_parallel(o, g.n_variables, [&](uint64_t v, std::string &s) {
+    if (g.var_role[v] >= 1 && !sample_evidence) return;
     const uint64_t b = var_val_base[v];
     if (g.var_dtype[v] == 0) {
-      o << v << " " << 1 << " " << 1.0 * tallies[b] / nsamples[v] << '\n';
+      append_line(s, v, (uint64_t)1, 1.0 * tallies[b] / nsamples[v]);
     } else {
       for (uint64_t j = 0; j < g.var_cardinality[v]; ++j)
-        o << v << " " << value_sparse[b + j] << " " << 1.0 * tallies[b + j] / nsamples[v] << '\n';
+        append_line(s, v, value_sparse[b + j], 1.0 * tallies[b + j] / nsamples[v]);
     }
-  }
+  });
 }
 
 // ------------------------------------------------------------------ driver
@@ -443,6 +543,14 @@ int gibbs(const CmdLine &args) {
       std::cout << std::endl;
       std::cout << args << std::endl;
     }
+    // DWX_TIMING=1: wall time of every host phase on stderr
+    const bool timing = getenv("DWX_TIMING") != nullptr;
+    double t_phase = now();
+    auto phase = [&](const char *what) {
+      const double t = now();
+      if (timing) std::cerr << "[dw timing] " << what << ": " << t - t_phase << " s" << std::endl;
+      t_phase = t;
+    };
     LoadedGraph lg;
     read_meta(args.fg_file, lg);
     std::cout << "Factor graph to load:\t#V=" << lg.n_variables << " #F=" << lg.n_factors
@@ -453,9 +561,12 @@ int gibbs(const CmdLine &args) {
     load_variables(args.variable_file, lg);
     load_weights(args.weight_file, lg);
     load_domains(args.domain_file, lg);
+    phase("load variables/weights/domains");
     load_factors(args.factor_file, lg);
+    phase("load factors");
     dwx_graph_desc desc = lg.desc();
     ok(dwx_graph_create(&desc, nullptr, &graph));
+    phase("dwx_graph_create (index, colouring, device layout)");
     dwx_graph_info info;
     ok(dwx_graph_get_info(graph, &info));
     auto print_size = [&](const char *what) {
@@ -480,6 +591,7 @@ int gibbs(const CmdLine &args) {
     o.seed = args.seed;
     o.step_cap = args.step_cap;
     ok(dwx_sampler_create(graph, &o, &sampler));
+    phase("dwx_sampler_create (upload, gradient incidence list, curvature estimate)");
 
     const uint64_t V = lg.n_variables, W = lg.n_weights;
     const bool progress = !args.should_be_quiet;
@@ -512,6 +624,7 @@ int gibbs(const CmdLine &args) {
     }
     std::cout << std::setprecision(6) << "TOTAL LEARNING TIME: " << now() - t_total << " sec." << std::endl;
 
+    phase("learning sweeps");
     // ---- dump_weights (src/dimmwitted.cc:245-258): before inference starts
     ok(dwx_get_weights(sampler, weights.data()));
     if (progress) {
@@ -527,6 +640,7 @@ int gibbs(const CmdLine &args) {
       dump_weights_in_text(f, weights);
     }
 
+    phase("dump weights");
     // ---- DimmWitted::inference (src/dimmwitted.cc:121-160)
     t_total = now();
     ok(dwx_clear_tallies(sampler));
@@ -546,6 +660,7 @@ int gibbs(const CmdLine &args) {
     ok(dwx_wait(sampler));
     std::cout << std::setprecision(6) << "TOTAL INFERENCE TIME: " << now() - t_total << " sec." << std::endl;
 
+    phase("inference sweeps");
     // ---- aggregate_results_and_dump (src/dimmwitted.cc:260-277), only if -i > 0
     if (args.n_inference_epoch > 0) {
       std::vector<uint64_t> tallies(info.num_values), nsamples(V), base(V), sparse(info.num_values);
@@ -555,7 +670,10 @@ int gibbs(const CmdLine &args) {
       std::cout << "DUMPING... TEXT    : " << fn << std::endl;
       std::ofstream f(fn);
       if (!f) throw std::runtime_error("cannot write " + fn);
+      phase("dwx_get_tallies");
       dump_marginals_in_text(f, lg, args.should_sample_evidence, base, sparse, tallies, nsamples);
+      f.close();
+      phase("dump marginals");
     }
   } catch (const std::exception &e) {
     std::cerr << "dw: " << e.what() << std::endl;

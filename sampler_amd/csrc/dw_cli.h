@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/dwx.h"
+#include "host_parallel.h"
 
 namespace dw {
 
@@ -56,10 +57,11 @@ struct LoadedGraph {
   std::vector<uint16_t> var_dtype;
   std::vector<uint64_t> dom_vid, dom_offset, dom_value;
   std::vector<double> dom_truthiness;
-  std::vector<uint16_t> fac_func;
-  std::vector<uint64_t> fac_edge_offset, fac_weight_id;
-  std::vector<double> fac_feature_value;
-  std::vector<uint64_t> edge_vid, edge_equal_to;
+  // the big columns are filled by parallel decoders: no serial zero-fill
+  dwx::RawArray<uint16_t> fac_func;
+  dwx::RawArray<uint64_t> fac_edge_offset, fac_weight_id;
+  dwx::RawArray<double> fac_feature_value;
+  dwx::RawArray<uint64_t> edge_vid, edge_equal_to;
   std::vector<double> w_initial_value;
   std::vector<uint8_t> w_is_fixed;
   dwx_graph_desc desc() const;

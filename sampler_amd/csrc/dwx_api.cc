@@ -7,6 +7,9 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -17,6 +20,7 @@
 #include <vector>
 
 #include "graph_compile.h"
+#include "host_parallel.h"
 
 #ifdef DWX_EMU
 #include "rt_emu.h"
@@ -57,6 +61,13 @@ T *upload(const std::vector<T> &v, rt::stream_t s, size_t pad = 0) {
   T *d = (T *)rt::dmalloc((v.size() + pad) * sizeof(T));
   rt::h2d(d, v.data(), v.size() * sizeof(T), s);
   if (pad) rt::dmemset(d + v.size(), 0, pad * sizeof(T), s);
+  return d;
+}
+
+template <class T>
+T *upload_raw(const T *h, size_t n, rt::stream_t s) {
+  T *d = (T *)rt::dmalloc(n * sizeof(T));
+  rt::h2d(d, h, n * sizeof(T), s);
   return d;
 }
 
@@ -234,6 +245,56 @@ double row_sum_bound(dwx_sampler *s, uint32_t batches) {
       const uint32_t p0 = c.tile_v[ta], p1 = c.tile_v[tb];
       // y = H x, three times: x0 = 1 (y = row sums), then two normalised power steps
       double lam = 0.0, dmax = 0.0;
+      if ((uint64_t)(p1 - p0) * 8 >= c.W && p1 - p0 >= 65536) {
+        // a batch that touches a good part of the weight table: variable ranges in
+        // parallel, one private y (and diagonal) per thread, dense passes over the table
+        const uint32_t T = std::min(host_threads(), 16u);
+        std::vector<std::vector<double>> ys(T), ds(T);
+        std::fill(x.begin(), x.end(), 1.0);
+        for (int iter = 0; iter < 3; ++iter) {
+          parallel_parts(p1 - p0, T, [&](uint32_t t, uint64_t b, uint64_t e) {
+            std::vector<double> &yt = ys[t], &dt = ds[t];
+            yt.assign(c.W, 0.0);
+            if (iter == 0) dt.assign(c.W, 0.0);
+            for (uint32_t p = p0 + (uint32_t)b; p < p0 + (uint32_t)e; ++p) {
+              const uint32_t m = c.v_meta[p];
+              if (!triggers(m)) continue;
+              const uint32_t e0 = c.row_ptr[c.v_row[p]], e1 = c.row_ptr[c.v_row[p + 1]];
+              const double kappa = (m & VM_CATEGORICAL) ? 0.5 : 0.25;
+              double dot = 0.0;
+              for (uint32_t e = e0; e < e1; ++e) dot += rec_d(e) * x[c.edges[e].wid];
+              for (uint32_t e = e0; e < e1; ++e) {
+                const double d = rec_d(e);
+                if (d == 0.0) continue;
+                yt[c.edges[e].wid] += kappa * d * dot;
+                if (iter == 0) dt[c.edges[e].wid] += kappa * d * d;
+              }
+            }
+          }, 0);
+          std::vector<double> part(3 * T, 0.0);
+          parallel_parts(c.W, T, [&](uint32_t t, uint64_t b, uint64_t e) {
+            double xy = 0.0, xx = 0.0, yy = 0.0;
+            for (uint64_t w = b; w < e; ++w) {
+              double yw = 0.0;
+              for (uint32_t k = 0; k < T; ++k) if (!ys[k].empty()) yw += ys[k][w];
+              y[w] = yw;
+              xy += x[w] * yw; xx += x[w] * x[w]; yy += yw * yw;
+            }
+            part[3 * t] = xy; part[3 * t + 1] = xx; part[3 * t + 2] = yy;
+          }, 0);
+          double xy = 0.0, xx = 0.0, yy = 0.0;
+          for (uint32_t t = 0; t < T; ++t) { xy += part[3 * t]; xx += part[3 * t + 1]; yy += part[3 * t + 2]; }
+          if (xx > 0) lam = std::max(lam, xy / xx);
+          const double norm = yy > 0 ? 1.0 / std::sqrt(yy) : 0.0;
+          for (uint64_t w = 0; w < c.W; ++w) { x[w] = y[w] * norm; y[w] = 0.0; }
+        }
+        for (uint64_t w = 0; w < c.W; ++w) {
+          double dw = 0.0;
+          for (uint32_t k = 0; k < T; ++k) if (!ds[k].empty()) dw += ds[k][w];
+          dmax = std::max(dmax, dw);
+          x[w] = 0.0;
+        }
+      } else {
       for (int iter = 0; iter < 3; ++iter) {
         for (uint32_t p = p0; p < p1; ++p) {
           const uint32_t m = c.v_meta[p];
@@ -263,9 +324,11 @@ double row_sum_bound(dwx_sampler *s, uint32_t batches) {
       }
       for (uint32_t w : touched) { dmax = std::max(dmax, diag[w]); diag[w] = 0.0; seen[w] = 0; x[w] = 0.0; }
       touched.clear();
+      }
       lam_max = std::max(lam_max, 1.1 * std::max(lam, dmax));
     }
   }
+  if (getenv("DWX_TIMING")) fprintf(stderr, "[dwx curvature] batches=%u lambda=%.6g\n", batches, lam_max);
   s->row_sum_cache[batches] = lam_max;
   return lam_max;
 }
@@ -462,6 +525,15 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     const CompiledGraph &c = *s->cg;
     s->stream = rt::stream_create();
     rt::stream_t st = s->stream;
+    const bool timing = getenv("DWX_TIMING") != nullptr;   // wall time of every phase on stderr
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char *what) {
+      if (!timing) return;
+      rt::stream_sync(st);
+      auto t = std::chrono::steady_clock::now();
+      fprintf(stderr, "[dwx sampler_create] %-24s %.3f s\n", what, std::chrono::duration<double>(t - t_phase).count());
+      t_phase = t;
+    };
     s->d_v_meta = upload(c.v_meta, st, 1);
     s->d_v_orig = upload(c.perm, st, 1);
     s->d_v_row = upload(c.v_row, st);
@@ -488,6 +560,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     s->d_tally = (uint32_t *)rt::dmalloc((c.R + 1) * 4);
     rt::dmemset(s->d_tally, 0, (c.R + 1) * 4, st);
     s->d_weights = upload(c.w_init, st);
+    phase("upload graph");
     {
       std::vector<float> w32(c.W);
       for (uint64_t i = 0; i < c.W; ++i) w32[i] = (float)c.w_init[i];
@@ -507,50 +580,59 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
           if (!c.w_fixed[c.edges[e].wid]) ts[c.edges[e].wid] += one;
       }
       s->d_t_static = upload(ts, st);
+      phase("static update counts");
       // Incidence list of the pull-based gradient: every (SGD-triggering variable of a
       // TILE_PULL tile, non-fixed record) pair, counting-sorted by weight id.
-      std::vector<uint32_t> cnt(c.W + 1, 0);
-      auto for_each_pull_record = [&](auto &&fn) {
-        for (size_t ti = 0; ti < c.tiles.size(); ++ti) {
-          const TileDesc &td = c.tiles[ti];
-          if (!(td.flags & TILE_PULL)) continue;
-          if (td.nrows > c.rcap || td.nedges > c.ecap) continue;   // oversized: giant_kernel, atomics
-          for (uint32_t l = 0; l < td.nv; ++l) {
-            const uint32_t p = td.v0 + l, m = c.v_meta[p];
-            const bool trig = opts->learn_non_evidence || (!opts->noise_aware && (m & VM_EVIDENCE));
-            if (!trig) continue;
-            for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p] + 1]; ++e) {
-              const EdgeRec &r = c.edges[e];
-              if (r.packed & EDGE_FIXED_FLAG) continue;
-              float miss;
-              std::memcpy(&miss, &r.aux, 4);
-              const float dd = r.fval - miss;    // exact: |hit| == |miss| or one of them is 0
-              if (dd == 0.0f) continue;
-              fn(r.wid, (uint32_t)(ti * BLOCK_THREADS + l), dd);
+      struct Inc { uint32_t wid, slot; float d; };
+      const uint32_t nth = host_threads();
+      RawArray<Inc> inc;
+      std::vector<uint64_t> inc_start;
+      parallel_group_by_key<Inc>(
+          c.tiles.size(), nth, c.W, [](const Inc &r) { return (uint64_t)r.wid; },
+          [&](uint64_t tb, uint64_t te, auto &&emit) {
+            for (uint64_t ti = tb; ti < te; ++ti) {
+              const TileDesc &td = c.tiles[ti];
+              if (!(td.flags & TILE_PULL)) continue;
+              if (td.nrows > c.rcap || td.nedges > c.ecap) continue;   // oversized: giant_kernel, atomics
+              for (uint32_t l = 0; l < td.nv; ++l) {
+                const uint32_t p = td.v0 + l, m = c.v_meta[p];
+                const bool trig = opts->learn_non_evidence || (!opts->noise_aware && (m & VM_EVIDENCE));
+                if (!trig) continue;
+                for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p] + 1]; ++e) {
+                  const EdgeRec &r = c.edges[e];
+                  if (r.packed & EDGE_FIXED_FLAG) continue;
+                  float miss;
+                  std::memcpy(&miss, &r.aux, 4);
+                  const float dd = r.fval - miss;    // exact: |hit| == |miss| or one of them is 0
+                  if (dd == 0.0f) continue;
+                  emit(Inc{r.wid, (uint32_t)(ti * BLOCK_THREADS + l), dd});
+                }
+              }
             }
-          }
-        }
-      };
-      for_each_pull_record([&](uint32_t wid, uint32_t, float) { ++cnt[wid + 1]; });
-      for (uint64_t i = 0; i < c.W; ++i) cnt[i + 1] += cnt[i];
-      const uint64_t n_inc = cnt[c.W];
+          },
+          inc, inc_start);
+      const uint64_t n_inc = inc.size();
       if (n_inc >= 0xFFFFFFFFull) throw std::invalid_argument("incidence list exceeds 2^32-1 entries");
       s->n_inc = (uint32_t)n_inc;
       if (n_inc) {
-        std::vector<uint32_t> iw(n_inc), is(n_inc);
-        std::vector<float> id(n_inc);
-        std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
-        for_each_pull_record([&](uint32_t wid, uint32_t slot, float dd) {
-          const uint32_t at = cur[wid]++;
-          iw[at] = wid; is[at] = slot; id[at] = dd;
+        // split into columns, padded to a whole run with neutral entries (same weight as
+        // the last one, zero gradient contribution), so the kernel's 16-byte loads never
+        // leave the arrays
+        const uint64_t padded = (n_inc + PULL_RUN - 1) / PULL_RUN * PULL_RUN;
+        RawArray<uint32_t> iw(padded), is(padded);
+        RawArray<float> id(padded);
+        parallel_ranges(padded, nth, [&](uint64_t b, uint64_t e) {
+          for (uint64_t i = b; i < e; ++i) {
+            const Inc &r = inc[std::min(i, n_inc - 1)];
+            iw[i] = r.wid; is[i] = r.slot; id[i] = i < n_inc ? r.d : 0.0f;
+          }
         });
-        // pad to a whole run with neutral entries (same weight as the last one, zero
-        // gradient contribution), so the kernel's 16-byte loads never leave the arrays
-        while (iw.size() % PULL_RUN) { iw.push_back(iw.back()); is.push_back(is.back()); id.push_back(0.0f); }
-        s->d_inc_wid = upload(iw, st);
-        s->d_inc_slot = upload(is, st);
-        s->d_inc_d = upload(id, st);
+        s->d_inc_wid = upload_raw(iw.data(), padded, st);
+        s->d_inc_slot = upload_raw(is.data(), padded, st);
+        s->d_inc_d = upload_raw(id.data(), padded, st);
+        rt::stream_sync(st);   // the columns die with this scope
       }
+      phase("gradient incidence list");
       s->d_delta = (unsigned long long *)rt::dmalloc((c.tiles.size() * 8 + 2) * 8);
       rt::dmemset(s->d_delta, 0, (c.tiles.size() * 8 + 2) * 8, st);
     }
@@ -616,7 +698,9 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     rt::stream_sync(st);
     // the un-split sweep's curvature estimate is needed by the first dwx_sgd_plan: pay
     // for it here (one host pass over the records), not inside the first learning sweep
+    phase("kernel setup");
     if (opts->step_cap > 0) (void)row_sum_bound(s.get(), 1);
+    phase("curvature estimate");
   });
   if (rc != DWX_OK) return rc;
   *out = s.release();

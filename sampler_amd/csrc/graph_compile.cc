@@ -1,8 +1,13 @@
 // graph_compile.cc -- see graph_compile.h.  Host-only C++17, no HIP.
 #include "graph_compile.h"
 
+#include "host_parallel.h"
+
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -34,33 +39,6 @@ inline bool known_func(uint32_t f) {
   return false;
 }
 
-// run fn(begin, end) over [0, n) split across threads
-void parallel_ranges(uint64_t n, uint32_t n_threads, const std::function<void(uint64_t, uint64_t)> &fn) {
-  if (n_threads <= 1 || n < 65536) {
-    fn(0, n);
-    return;
-  }
-  std::vector<std::thread> th;
-  std::atomic<bool> failed{false};
-  std::exception_ptr eptr = nullptr;
-  std::atomic_flag lock = ATOMIC_FLAG_INIT;
-  uint64_t per = (n + n_threads - 1) / n_threads;
-  for (uint32_t t = 0; t < n_threads; ++t) {
-    uint64_t b = std::min<uint64_t>(n, per * t), e = std::min<uint64_t>(n, per * (t + 1));
-    if (b >= e) break;
-    th.emplace_back([&, b, e]() {
-      try {
-        fn(b, e);
-      } catch (...) {
-        if (!lock.test_and_set()) eptr = std::current_exception();
-        failed = true;
-      }
-    });
-  }
-  for (auto &t : th) t.join();
-  if (failed && eptr) std::rethrow_exception(eptr);
-}
-
 }  // namespace
 
 uint64_t CompiledGraph::device_bytes() const {
@@ -85,11 +63,19 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     g.Vo = Vo;
     if (V >= kUnset || F >= kUnset || W >= kUnset || E >= kUnset)
       throw LimitError("graph exceeds the 32-bit compact layout (V, F, W, E must be < 2^32-1)");
-    uint32_t nth = o.n_threads ? o.n_threads : std::max(1u, std::thread::hardware_concurrency());
-    nth = std::min(nth, 64u);
+    const uint32_t nth = host_threads(o.n_threads);
     g.tile_vars = o.tile_vars ? std::min(o.tile_vars, BLOCK_THREADS) : BLOCK_THREADS;
     const uint32_t arity_cap = o.conflict_arity_cap ? o.conflict_arity_cap : 256;
     if (F && d.fac_edge_offset[F] != E) throw std::runtime_error("fac_edge_offset[F] != num_edges");
+    // DWX_TIMING=1: wall time of every compile phase on stderr
+    const bool timing = getenv("DWX_TIMING") != nullptr;
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char *what) {
+      if (!timing) return;
+      auto t = std::chrono::steady_clock::now();
+      fprintf(stderr, "[dwx compile] %-28s %.3f s\n", what, std::chrono::duration<double>(t - t_phase).count());
+      t_phase = t;
+    };
 
     // ---- variables (src/binary_format.cc:64-126) ----
     std::vector<uint8_t> is_cat(V);
@@ -109,6 +95,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       if (is_cat[v]) { g.has_categorical = true; g.max_card = std::max(g.max_card, card[v]); }
     }
 
+    phase("variables");
     // ---- domains (src/binary_format.cc:192-226): value -> index in file order ----
     // per block: (value, index) sorted by value, last index wins for duplicates
     std::vector<int64_t> dom_of(d.num_domains ? V : 0, -1);
@@ -194,66 +181,62 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
                                  " is outside its domain");
     for (double t : ref_truth) if (t != 0.0) { g.has_truthiness = true; break; }
 
+    phase("domains, value numbering");
     // ---- factors: dense predicates + per-variable back-refs
     //      (src/binary_format.cc:128-190) ----
     std::vector<uint32_t> edge_dense(E);
-    std::vector<uint32_t> cnt(V + 1, 0);
-    for (uint64_t f = 0; f < F; ++f) {
-      uint64_t lo = d.fac_edge_offset[f], hi = d.fac_edge_offset[f + 1];
-      if (hi < lo || hi > E) throw std::runtime_error("fac_edge_offset not monotone");
-      if (hi - lo > MAX_ARITY) throw LimitError("factor arity exceeds 2^24-1");
-      if (!known_func(d.fac_func[f]))
-        throw std::runtime_error("Unsupported FACTOR_FUNCTION_TYPE = " + std::to_string(d.fac_func[f]));
-      if (d.fac_weight_id[f] >= W) throw std::runtime_error("factor references unknown weight");
-    }
-    for (uint64_t e = 0; e < E; ++e) {
-      uint64_t vid = d.edge_vid[e];
-      if (vid >= V) throw std::runtime_error("factor references unknown variable");
-      if (vid < Vo) ++cnt[vid + 1];   // ghosts get no back-references
-    }
-    std::vector<uint64_t> start(V + 1, 0);
-    for (uint64_t v = 0; v < V; ++v) start[v + 1] = start[v] + cnt[v + 1];
-    std::vector<uint32_t> pv(E), pf(E);
-    {
-      std::vector<uint64_t> cur(start.begin(), start.end() - 1);
-      for (uint64_t f = 0; f < F; ++f)
-        for (uint64_t e = d.fac_edge_offset[f]; e < d.fac_edge_offset[f + 1]; ++e) {
-          uint64_t vid = d.edge_vid[e];
-          uint64_t dense = domain_index(vid, d.edge_equal_to[e]);
+    parallel_ranges(F, nth, [&](uint64_t fb, uint64_t fe) {
+      for (uint64_t f = fb; f < fe; ++f) {
+        uint64_t lo = d.fac_edge_offset[f], hi = d.fac_edge_offset[f + 1];
+        if (hi < lo || hi > E) throw std::runtime_error("fac_edge_offset not monotone");
+        if (hi - lo > MAX_ARITY) throw LimitError("factor arity exceeds 2^24-1");
+        if (!known_func(d.fac_func[f]))
+          throw std::runtime_error("Unsupported FACTOR_FUNCTION_TYPE = " + std::to_string(d.fac_func[f]));
+        if (d.fac_weight_id[f] >= W) throw std::runtime_error("factor references unknown weight");
+        for (uint64_t e = lo; e < hi; ++e) {
+          const uint64_t vid = d.edge_vid[e];
+          if (vid >= V) throw std::runtime_error("factor references unknown variable");
+          const uint64_t dense = domain_index(vid, d.edge_equal_to[e]);
           if (dense >= kUnset) throw LimitError("predicate value exceeds 32 bits");
           edge_dense[e] = (uint32_t)dense;
-          if (vid >= Vo) continue;
-          uint64_t slot = cur[vid]++;
-          pv[slot] = is_cat[vid] ? (uint32_t)dense : 0u;   // booleans index under value 0
-          pf[slot] = (uint32_t)f;
         }
-    }
-
+      }
+    });
+    // back-references grouped by variable, in factor order inside a variable (a stable
+    // parallel counting sort; ghosts get none)
+    struct BackRef { uint32_t vid, val, fid; };
+    RawArray<BackRef> br;
+    std::vector<uint64_t> start;
+    parallel_group_by_key<BackRef>(
+        F, nth, V, [](const BackRef &r) { return (uint64_t)r.vid; },
+        [&](uint64_t fb, uint64_t fe, auto &&emit) {
+          for (uint64_t f = fb; f < fe; ++f)
+            for (uint64_t e = d.fac_edge_offset[f]; e < d.fac_edge_offset[f + 1]; ++e) {
+              const uint64_t vid = d.edge_vid[e];
+              if (vid >= Vo) continue;
+              // booleans index under value 0
+              emit(BackRef{(uint32_t)vid, is_cat[vid] ? edge_dense[e] : 0u, (uint32_t)f});
+            }
+        },
+        br, start);
+    phase("back-references");
     // ---- construct_index: sort by (value, fid), dedup (src/factor_graph.cc:177-197) ----
     std::vector<uint32_t> row_len(R, 0);
     std::vector<uint32_t> ucnt(V, 0);
     parallel_ranges(V, nth, [&](uint64_t vb, uint64_t ve) {
-      std::vector<std::pair<uint32_t, uint32_t>> tmp;
+      auto less = [](const BackRef &a, const BackRef &c) { return a.val < c.val || (a.val == c.val && a.fid < c.fid); };
       for (uint64_t v = vb; v < ve; ++v) {
         uint64_t lo = start[v], hi = start[v + 1];
         if (lo == hi) continue;
-        bool sorted = true;
-        for (uint64_t i = lo + 1; i < hi && sorted; ++i)
-          sorted = pv[i - 1] < pv[i] || (pv[i - 1] == pv[i] && pf[i - 1] <= pf[i]);
-        if (!sorted) {
-          tmp.resize(hi - lo);
-          for (uint64_t i = lo; i < hi; ++i) tmp[i - lo] = {pv[i], pf[i]};
-          std::sort(tmp.begin(), tmp.end());
-          for (uint64_t i = lo; i < hi; ++i) { pv[i] = tmp[i - lo].first; pf[i] = tmp[i - lo].second; }
-        }
+        if (!std::is_sorted(br.begin() + lo, br.begin() + hi, less)) std::sort(br.begin() + lo, br.begin() + hi, less);
+        const uint32_t lim = is_cat[v] ? card[v] : 1;
         uint64_t w = lo;
         for (uint64_t i = lo; i < hi; ++i) {
-          if (i > lo && pv[i] == pv[w - 1] && pf[i] == pf[w - 1]) continue;
-          uint32_t lim = is_cat[v] ? card[v] : 1;
-          if (pv[i] >= lim)
+          if (i > lo && br[i].val == br[w - 1].val && br[i].fid == br[w - 1].fid) continue;
+          if (br[i].val >= lim)
             throw std::runtime_error("predicate value outside the domain of variable " + std::to_string(v));
-          pv[w] = pv[i]; pf[w] = pf[i]; ++w;
-          ++row_len[g.ref_var_val_base[v] + pv[i]];
+          br[w] = br[i]; ++w;
+          ++row_len[g.ref_var_val_base[v] + br[i].val];
         }
         ucnt[v] = (uint32_t)(w - lo);
       }
@@ -268,12 +251,11 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
         uint64_t src = start[v], dst = g.ref_row_ptr[g.ref_var_val_base[v]];
         // the variable's unique (value, fid) pairs are sorted by value, so they are
         // exactly its rows back to back
-        for (uint32_t i = 0; i < ucnt[v]; ++i) g.ref_fidx[dst + i] = pf[src + i];
+        for (uint32_t i = 0; i < ucnt[v]; ++i) g.ref_fidx[dst + i] = br[src + i].fid;
       }
     });
-    std::vector<uint32_t>().swap(pv);
-    std::vector<uint32_t>().swap(pf);
-
+    br.clear();
+    phase("construct_index");
     // ---- chromatic partition: greedy colouring of the variable conflict graph
     //      (two variables conflict iff they share a factor of arity 2..cap) ----
     std::vector<uint32_t> color(V, kUnset);
@@ -301,6 +283,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       g.n_colors = Vo ? ncol : 0;
     }
 
+    phase("colouring");
     // ---- device order: colour-major; inside a colour query variables before evidence
     //      variables (an inference sweep launches over the query part only, like the
     //      reference skips evidence, src/gibbs_sampler.h:157), booleans before
@@ -327,6 +310,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     for (uint64_t v = 0; v < Vo; ++v) g.n_query += !g.var_is_evid[v];
     if (g.n_colors == 0) g.launch_off.assign(1, 0);
 
+    phase("device order");
     // ---- device rows ----
     g.v_meta.resize(V); g.v_init.resize(V); g.v_row.resize(V + 1);
     g.v_row[0] = 0;
@@ -351,6 +335,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     }
     for (uint64_t r = 0; r < R; ++r) g.row_ptr[r + 1] += g.row_ptr[r];
 
+    phase("device rows");
     // ---- vifs of factors with arity >= 2 ----
     std::vector<uint32_t> vif_base(F, 0);
     uint64_t nvif = 0;
@@ -370,6 +355,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       }
     });
 
+    phase("vifs");
     // ---- edge records, variable-major in device order ----
     g.edges.resize(g.NIdx);
     std::atomic<bool> need64{false};
@@ -424,6 +410,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       });
     }
 
+    phase("edge records");
     // ---- workgroup tiles: <= tile_vars variables of one type whose value rows and
     //      edge records fit the LDS budget; an oversized variable gets a tile alone ----
     // Default LDS budget per tile: 3072 records (48 KiB) for all-unary graphs; graphs with
@@ -462,8 +449,9 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     g.launch_tile.push_back((uint32_t)g.tile_v.size());
     g.tile_v.push_back((uint32_t)Vo);
     g.tiles.resize(g.tile_v.size() - 1);
-    g.n_terms2_tiles = 0;
-    for (size_t i = 0; i + 1 < g.tile_v.size(); ++i) {
+    std::atomic<uint32_t> n_terms2{0};
+    parallel_ranges(g.tiles.size(), nth, [&](uint64_t ib, uint64_t ie) {
+    for (uint64_t i = ib; i < ie; ++i) {
       const uint32_t v0 = g.tile_v[i], v1 = g.tile_v[i + 1];
       TileDesc t{};
       t.v0 = v0; t.nv = v1 - v0;
@@ -480,13 +468,15 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       t.flags = (simple ? TILE_SIMPLE : 0u) | (cat ? TILE_CATEGORICAL : 0u) |
                 ((simple && !cat && W > LDS_AGG_MAX_W) ? TILE_PULL : 0u) |
                 ((terms2 && !simple && !cat && t.nv <= 256) ? TILE_TERMS2 : 0u);
-      if (t.flags & TILE_TERMS2) ++g.n_terms2_tiles;
+      if (t.flags & TILE_TERMS2) ++n_terms2;
       // every record learns the lane of its owning variable inside the tile
       for (uint32_t l = 0; l < t.nv; ++l)
         for (uint32_t e = g.row_ptr[g.v_row[v0 + l]]; e < g.row_ptr[g.v_row[v0 + l + 1]]; ++e)
           g.edges[e].packed = (g.edges[e].packed & 0x00FFFFFFu) | ((l & 0xFFu) << EDGE_OWNER_SHIFT);
       g.tiles[i] = t;
     }
+    });
+    g.n_terms2_tiles = n_terms2;
     g.giant_tiles.clear(); g.launch_giant.clear(); g.launch_giant_query_end.clear();
     for (uint64_t l = 0; l < nl; ++l) {
       g.launch_giant.push_back((uint32_t)g.giant_tiles.size());
@@ -499,6 +489,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     }
     g.launch_giant.push_back((uint32_t)g.giant_tiles.size());
 
+    phase("tiles");
     g.w_init.assign(d.w_initial_value, d.w_initial_value + W);
     g.w_fixed.assign(d.w_is_fixed, d.w_is_fixed + W);
   } catch (const LimitError &) {

@@ -1,0 +1,149 @@
+// host_parallel.h -- the two host-side parallel primitives of the one-off setup work
+// (graph compile, gradient incidence list, loader, dumps): a range splitter and a stable
+// two-level counting sort.  They replace the reference's per-variable std::sort under
+// mutexes (src/factor_graph.cc:90-199) and its serial loaders; nothing here runs per sweep.
+#ifndef DWX_HOST_PARALLEL_H_
+#define DWX_HOST_PARALLEL_H_
+
+#include <stdint.h>
+
+#include <stdlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <exception>
+#include <new>
+#include <thread>
+#include <vector>
+
+namespace dwx {
+
+inline uint32_t host_threads(uint32_t requested = 0) {
+  uint32_t n = requested ? requested : std::max(1u, std::thread::hardware_concurrency());
+  return std::min(n, 64u);
+}
+
+// Uninitialised array of trivially copyable T: unlike std::vector it does not zero-fill
+// serially, so the first touch (and its page faults) happens inside the parallel loops.
+template <class T>
+class RawArray {
+ public:
+  RawArray() = default;
+  explicit RawArray(size_t n) { reset(n); }
+  RawArray(const RawArray &) = delete;
+  RawArray &operator=(const RawArray &) = delete;
+  ~RawArray() { free(p_); }
+  void reset(size_t n) {
+    free(p_);
+    p_ = nullptr; n_ = n;
+    if (n) {
+      p_ = (T *)malloc(n * sizeof(T));
+      if (!p_) throw std::bad_alloc();
+    }
+  }
+  void clear() { reset(0); }
+  size_t size() const { return n_; }
+  T *data() { return p_; }
+  const T *data() const { return p_; }
+  T *begin() { return p_; }
+  T *end() { return p_ + n_; }
+  T &operator[](size_t i) { return p_[i]; }
+  const T &operator[](size_t i) const { return p_[i]; }
+
+ private:
+  T *p_ = nullptr;
+  size_t n_ = 0;
+};
+
+// fn(part, begin, end) over [0, n) cut into at most n_threads contiguous parts; the first
+// exception thrown by any part is rethrown on the caller's thread.
+template <class Fn>
+void parallel_parts(uint64_t n, uint32_t n_threads, Fn &&fn, uint64_t serial_below = 65536) {
+  if (n_threads <= 1 || n < serial_below) {
+    fn(0u, (uint64_t)0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  std::exception_ptr eptr = nullptr;
+  std::atomic_flag lock = ATOMIC_FLAG_INIT;
+  const uint64_t per = (n + n_threads - 1) / n_threads;
+  for (uint32_t t = 0; t < n_threads; ++t) {
+    const uint64_t b = std::min<uint64_t>(n, per * t), e = std::min<uint64_t>(n, per * (t + 1));
+    if (b >= e) break;
+    th.emplace_back([&, t, b, e]() {
+      try {
+        fn(t, b, e);
+      } catch (...) {
+        if (!lock.test_and_set()) eptr = std::current_exception();
+      }
+    });
+  }
+  for (auto &t : th) t.join();
+  if (eptr) std::rethrow_exception(eptr);
+}
+
+template <class Fn>
+void parallel_ranges(uint64_t n, uint32_t n_threads, Fn &&fn) {
+  parallel_parts(n, n_threads, [&](uint32_t, uint64_t b, uint64_t e) { fn(b, e); });
+}
+
+// Stable parallel counting sort of generated records by an integer key in [0, n_keys).
+//   produce(begin, end, emit): enumerates, in order, the records of the source range
+//     [begin, end) of [0, n_src) calling emit(const Rec &); it runs TWICE per range (count,
+//     then scatter) and must emit the same records both times.
+//   key(rec) -> uint64_t < n_keys.
+// Output: out = all records ordered by key, records of equal key in source order;
+// start[k] .. start[k+1] = the records of key k (start has n_keys + 1 entries).
+// Level 1 partitions by the high key bits into <= 4096 buckets (per-thread histograms,
+// one streaming scatter), level 2 counting-sorts every bucket on its own (cache-sized
+// counters), buckets handed out dynamically.
+template <class Rec, class KeyFn, class Produce>
+void parallel_group_by_key(uint64_t n_src, uint32_t n_threads, uint64_t n_keys, KeyFn &&key,
+                           Produce &&produce, RawArray<Rec> &out, std::vector<uint64_t> &start) {
+  start.assign(n_keys + 1, 0);
+  out.clear();
+  if (n_keys == 0 || n_src == 0) return;
+  uint32_t shift = 0;
+  while ((n_keys >> shift) > 4096) ++shift;
+  const uint64_t nb = ((n_keys - 1) >> shift) + 1;
+  const uint32_t T = (n_threads <= 1 || n_src < 65536) ? 1u : n_threads;
+  std::vector<std::vector<uint64_t>> hist(T, std::vector<uint64_t>(nb, 0));
+  parallel_parts(n_src, T, [&](uint32_t t, uint64_t b, uint64_t e) {
+    std::vector<uint64_t> &h = hist[t];
+    produce(b, e, [&](const Rec &r) { ++h[key(r) >> shift]; });
+  }, 0);
+  // bucket-major, thread-minor offsets keep the scatter stable
+  std::vector<uint64_t> bucket_start(nb + 1, 0);
+  uint64_t total = 0;
+  for (uint64_t b = 0; b < nb; ++b) {
+    bucket_start[b] = total;
+    for (uint32_t t = 0; t < T; ++t) { const uint64_t c = hist[t][b]; hist[t][b] = total; total += c; }
+  }
+  bucket_start[nb] = total;
+  RawArray<Rec> tmp(total);
+  parallel_parts(n_src, T, [&](uint32_t t, uint64_t b, uint64_t e) {
+    std::vector<uint64_t> &h = hist[t];
+    produce(b, e, [&](const Rec &r) { tmp[h[key(r) >> shift]++] = r; });
+  }, 0);
+  out.reset(total);
+  std::atomic<uint64_t> next{0};
+  const uint64_t width = (uint64_t)1 << shift;
+  parallel_parts(T, T, [&](uint32_t, uint64_t, uint64_t) {
+    std::vector<uint64_t> cnt(width + 1);
+    for (;;) {
+      const uint64_t b = next.fetch_add(1);
+      if (b >= nb) break;
+      const uint64_t lo = bucket_start[b], hi = bucket_start[b + 1], k0 = b << shift;
+      const uint64_t kn = std::min<uint64_t>(width, n_keys - k0);
+      std::fill(cnt.begin(), cnt.begin() + kn + 1, 0);
+      for (uint64_t i = lo; i < hi; ++i) ++cnt[key(tmp[i]) - k0 + 1];
+      for (uint64_t k = 0; k < kn; ++k) cnt[k + 1] += cnt[k];
+      for (uint64_t k = 0; k < kn; ++k) start[k0 + k] = lo + cnt[k];
+      for (uint64_t i = lo; i < hi; ++i) out[lo + cnt[key(tmp[i]) - k0]++] = tmp[i];
+    }
+  }, 0);
+  start[n_keys] = total;
+}
+
+}  // namespace dwx
+#endif

@@ -95,3 +95,110 @@ def test_text2bin_errors():
         r = subprocess.run([DW, "text2bin", "nonsense", bad, os.path.join(t, "o"), os.path.join(t, "c")],
                            capture_output=True, text=True)
         assert r.returncode != 0
+
+
+def _factor_bytes(recs):
+    """recs: [(func, [(vid, equal_to), ...], wid, fval)] -> big-endian factor records."""
+    import struct
+    out = bytearray()
+    for func, edges, wid, fval in recs:
+        out += struct.pack(">HQ", func, len(edges))
+        for vid, eq in edges:
+            out += struct.pack(">QQ", vid, eq)
+        out += struct.pack(">Qd", wid, fval)
+    return bytes(out)
+
+
+def _load_through_bin2text(tmp, recs, n_vars=8, n_weights=4, n_factors=None, n_edges=None, raw=None, split=None):
+    """Writes a graph whose factor file(s) hold `recs`, loads it with `dw bin2text` (the
+    native loader) and returns (returncode, stderr, factors.tsv lines)."""
+    import struct
+    n_factors = len(recs) if n_factors is None else n_factors
+    n_edges = sum(len(r[1]) for r in recs) if n_edges is None else n_edges
+    open(os.path.join(tmp, "graph.meta"), "w").write("%d,%d,%d,%d" % (n_weights, n_vars, n_factors, n_edges))
+    open(os.path.join(tmp, "graph.variables"), "wb").write(
+        b"".join(struct.pack(">QBQHQ", v, 0, 0, 0, 2) for v in range(n_vars)))
+    open(os.path.join(tmp, "graph.weights"), "wb").write(
+        b"".join(struct.pack(">QBd", w, 0, 0.0) for w in range(n_weights)))
+    blob = _factor_bytes(recs) if raw is None else raw
+    files = []
+    cuts = [0] + (split or []) + [len(recs)]
+    if raw is not None or not split:
+        open(os.path.join(tmp, "graph.factors"), "wb").write(blob)
+        files = [os.path.join(tmp, "graph.factors")]
+    else:
+        for i in range(len(cuts) - 1):
+            fn = os.path.join(tmp, "graph.factors.%d" % i)
+            open(fn, "wb").write(_factor_bytes(recs[cuts[i]:cuts[i + 1]]))
+            files.append(fn)
+    out = os.path.join(tmp, "txt")
+    os.makedirs(out, exist_ok=True)
+    cmd = [DW, "bin2text", "-m", os.path.join(tmp, "graph.meta"), "-v", os.path.join(tmp, "graph.variables"),
+           "-w", os.path.join(tmp, "graph.weights"), "-o", out]
+    for f in files:
+        cmd += ["-f", f]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    lines = open(os.path.join(out, "factors.tsv")).read().splitlines() if r.returncode == 0 else None
+    return r.returncode, r.stderr, lines
+
+
+def _expected_lines(recs):
+    out = []
+    for func, edges, wid, fval in recs:
+        cols = [str(v) for v, _ in edges] + ([str(e) for _, e in edges] if func == 12 else [])
+        out.append("\t".join(cols + [str(wid), "%g" % fval]))
+    return out
+
+
+def test_factor_loader_cuts_files_at_record_boundaries():
+    """The native loader decodes factor files in parallel pieces (fixed stride when every
+    record has the first one's arity, otherwise a hop over the arity fields): uniform
+    files, mixed arities, the look-alike case where the file size is a multiple of the
+    first record's size, several files, and > 64k records (more than one piece)."""
+    import random
+    rnd = random.Random(5)
+
+    def rec(arity):
+        return (rnd.choice([0, 1, 2, 3, 4]), [(rnd.randrange(8), 1) for _ in range(arity)],
+                rnd.randrange(4), float(rnd.randrange(-3, 4)))
+
+    cases = {
+        "uniform": [rec(2) for _ in range(1000)],
+        "mixed": [rec(rnd.randint(1, 4)) for _ in range(1000)],
+        # first record arity 1 (42 B); arities 3 (74 B) + ... chosen so the size is a multiple of 42
+        "lookalike": [rec(1)] + [rec(3), rec(3), rec(3)] * 7 + [rec(1)] * 20,
+        "many_uniform": [rec(1) for _ in range(150_000)],
+        "many_mixed": [rec(1 + (i % 3 == 0)) for i in range(150_000)],
+    }
+    assert len(_factor_bytes(cases["lookalike"])) % 42 == 0
+    for name, recs in cases.items():
+        with tempfile.TemporaryDirectory() as t:
+            rc, err, lines = _load_through_bin2text(t, recs)
+            assert rc == 0, (name, err)
+            assert lines == _expected_lines(recs), name
+    with tempfile.TemporaryDirectory() as t:      # three files: uniform, mixed, uniform
+        recs = [rec(2) for _ in range(500)] + [rec(rnd.randint(1, 3)) for _ in range(500)] + [rec(1) for _ in range(500)]
+        rc, err, lines = _load_through_bin2text(t, recs, split=[500, 1000])
+        assert rc == 0, err
+        assert lines == _expected_lines(recs)
+
+
+def test_factor_loader_rejects_malformed_files():
+    import random
+    rnd = random.Random(6)
+    recs = [(4, [(rnd.randrange(8), 1)], 0, 1.0) for _ in range(100)]
+    blob = _factor_bytes(recs)
+    with tempfile.TemporaryDirectory() as t:      # cut in the middle of a record
+        rc, err, _ = _load_through_bin2text(t, recs, raw=blob[:-5])
+        assert rc != 0 and "truncated" in err
+    with tempfile.TemporaryDirectory() as t:      # fewer records than graph.meta announces
+        rc, err, _ = _load_through_bin2text(t, recs, n_factors=101, n_edges=101)
+        assert rc != 0 and "factor count" in err
+    with tempfile.TemporaryDirectory() as t:      # more records than graph.meta announces
+        rc, err, _ = _load_through_bin2text(t, recs, n_factors=99, n_edges=99)
+        assert rc != 0 and "count" in err
+    with tempfile.TemporaryDirectory() as t:      # an arity field pointing far past the file
+        bad = bytearray(blob)
+        bad[42 * 50 + 2:42 * 50 + 10] = (1 << 40).to_bytes(8, "big")
+        rc, err, _ = _load_through_bin2text(t, recs, raw=bytes(bad))
+        assert rc != 0 and "truncated" in err

@@ -43,6 +43,9 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
         r = subprocess.run([exe, "gibbs"] + files + ["-o", out] + flags, capture_output=True, text=True)
         res[name + "_wall_s"] = round(time.time() - t0, 2)
         res[name + "_rc"] = r.returncode
+        phases = [l for l in r.stderr.splitlines() if l.startswith("[dw")]   # DWX_TIMING=1
+        if phases:
+            res[name + "_phases"] = phases
         for line in r.stdout.splitlines():
             if line.startswith("TOTAL"):
                 res[name + "_" + line.split(":")[0].replace(" ", "_").lower()] = line.split(":")[1].strip()
