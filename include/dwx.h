@@ -162,14 +162,16 @@ int dwx_wait(dwx_sampler *s);
  * The reference applies every factor's SGD update immediately; the device accumulates a
  * mini-batch and applies it in one step.  dwx_sgd_plan sizes the mini-batches for the
  * given step size: with R = the (estimated) largest eigenvalue of a batch's curvature in
- * weight space (how strongly all updates of one batch interact), a sweep is split into
- * `batches` = the smallest power of two with stepsize * R(batches) <= step_cap, i.e. as
- * many pieces as keep one batched step inside the region where it tracks the
- * sequential updates (1 for configs 2-5 of BASELINE.json; dozens for heavily tied
- * weights with a large step).  force_batches != 0 overrides (all ranks of a multi-GPU run
- * must use the same value).  A plan is a list of chunks (consecutive device-order runs
- * of variables, never crossing a colour); with batches == 1 the update is applied once
- * after the last chunk, otherwise after every chunk.
+ * weight space (how strongly all updates of one batch interact), every colour launch is cut
+ * into `batches` runs of tiles carrying equal SGD work, batches = the first power of two
+ * >= stepsize * R(1) / step_cap with stepsize * R(batches) <= step_cap, i.e. as many
+ * pieces as keep one batched step inside the region where it tracks the sequential
+ * updates (1 for configs 2-5 of BASELINE.json at their quoted step; dozens for heavily
+ * tied weights with a large step).  force_batches != 0 overrides (all ranks of a multi-GPU
+ * run must use the same value).  A plan is a list of chunks (consecutive device-order runs
+ * of variables, never crossing a colour; n_chunks <= batches * colours -- tiles that learn
+ * nothing ride along with a neighbour); with batches == 1 the update is applied once after
+ * the last chunk, otherwise after every chunk.
  *   dwx_sgd_plan -> n_chunks;  for c in chunks: dwx_sgd_accumulate_async(c) [+ collective,
  *   + dwx_sgd_apply_async where due];  dwx_sgd_finish. */
 int dwx_sgd_plan(dwx_sampler *s, double stepsize, uint32_t force_batches, uint32_t *batches,

@@ -414,7 +414,7 @@ void load_factors(const std::vector<std::string> &files, LoadedGraph &g) {
           dwx::parallel_ranges(pieces.size(), nth, [&](uint64_t b, uint64_t e) {
             for (uint64_t i = b; i < e && ok; ++i)
               if (!parse_piece(m, path, pieces[i], g, true)) ok = false;
-          });
+          }, 2);
         if (ok) { f_base += n; e_base += n * a0; done = true; }
       }
     }
@@ -441,7 +441,7 @@ void load_factors(const std::vector<std::string> &files, LoadedGraph &g) {
       dwx::parallel_ranges(pieces.size(), nth, [&](uint64_t b, uint64_t pe) {
         for (uint64_t i = b; i < pe; ++i)
           if (!parse_piece(m, path, pieces[i], g, false)) throw std::runtime_error(path + ": inconsistent factor records");
-      });
+      }, 2);
       f_base = f; e_base = e;
     }
   }

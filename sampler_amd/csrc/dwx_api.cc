@@ -101,6 +101,7 @@ struct dwx_sampler {
   double plan_eta = 0.0;
   bool plan_valid = false;
   std::map<uint32_t, double> row_sum_cache;   // batches -> R
+  std::vector<uint64_t> sgd_work;             // [tiles + 1] prefix sums of SGD-visited records
   bool wide_learn = false;   // the graph has TILE_TERMS2 tiles: 32-byte staged records when learning
   unsigned persistent_blocks[2] = {1, 1};
   double *d_row_truth = nullptr, *d_edge_fval64 = nullptr;
@@ -202,6 +203,33 @@ void enqueue_inference(dwx_sampler *s) {
   ++s->sweep;
 }
 
+// Tile boundaries of colour launch l cut into at most nb runs of (nearly) equal SGD work
+// (records visited by sgd_on_variable; query variables sample but do not learn, so a cut
+// by tile count would put all the learning of an evidence-after-query launch in half of
+// the batches).  Returns strictly increasing boundaries from the launch's first tile to
+// its last.
+std::vector<uint32_t> cut_launch(const dwx_sampler *s, size_t l, uint32_t nb) {
+  const CompiledGraph &c = *s->cg;
+  const uint32_t t0 = c.launch_tile[l], t1 = c.launch_tile[l + 1];
+  std::vector<uint32_t> cut{t0};
+  if (t1 == t0) return cut;
+  nb = std::max(1u, std::min(nb, t1 - t0));
+  const uint64_t w0 = s->sgd_work[t0], total = s->sgd_work[t1] - w0;
+  for (uint32_t b = 1; b < nb; ++b) {
+    uint32_t t;
+    if (total == 0) {
+      t = t0 + (uint32_t)((uint64_t)(t1 - t0) * b / nb);
+    } else {
+      const uint64_t target = w0 + (total / nb) * b + (total % nb) * b / nb;
+      t = (uint32_t)(std::lower_bound(s->sgd_work.begin() + t0, s->sgd_work.begin() + t1, target) -
+                     s->sgd_work.begin());
+    }
+    if (t > cut.back() && t < t1) cut.push_back(t);
+  }
+  cut.push_back(t1);
+  return cut;
+}
+
 // Curvature of one SGD mini-batch in weight space, when every colour launch is cut into
 // `batches` runs of tiles.  A variable v that triggers SGD contributes kappa_v d_v d_v^T to
 // the batch Hessian bound, d_v[w] = sum of |d_r| over its non-fixed records with weight w,
@@ -238,10 +266,10 @@ double row_sum_bound(dwx_sampler *s, uint32_t batches) {
            (s->opts.noise_aware && (m & VM_TRUTHINESS));
   };
   for (size_t l = 0; l + 1 < c.launch_off.size(); ++l) {
-    const uint32_t t0 = c.launch_tile[l], n = c.launch_tile[l + 1] - t0;
-    const uint32_t nb = std::min(batches, n);
-    for (uint32_t b = 0; b < nb; ++b) {
-      const uint32_t ta = t0 + (uint32_t)((uint64_t)n * b / nb), tb = t0 + (uint32_t)((uint64_t)n * (b + 1) / nb);
+    const std::vector<uint32_t> cut = cut_launch(s, l, batches);
+    for (size_t b = 0; b + 1 < cut.size(); ++b) {
+      const uint32_t ta = cut[b], tb = cut[b + 1];
+      if (s->sgd_work[tb] == s->sgd_work[ta]) continue;   // nothing learns in this run
       const uint32_t p0 = c.tile_v[ta], p1 = c.tile_v[tb];
       // y = H x, three times: x0 = 1 (y = row sums), then two normalised power steps
       double lam = 0.0, dmax = 0.0;
@@ -344,6 +372,9 @@ void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
   if (force_batches) {
     B = std::min(force_batches, max_tiles);
   } else if (cap > 0 && stepsize > 0) {
+    // lambda(1) <= B * lambda(B): no split below stepsize * lambda(1) / cap can do
+    const double need = stepsize * row_sum_bound(s, 1) / cap;
+    while (B < max_tiles && (double)B < need) B *= 2;
     while (B < max_tiles && stepsize * row_sum_bound(s, B) > cap) B *= 2;
     B = std::min(B, max_tiles);
   }
@@ -356,11 +387,8 @@ void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
   s->plan_eta = eta;
   s->plan_chunks.clear();
   for (size_t l = 0; l + 1 < c.launch_off.size(); ++l) {
-    const uint32_t t0 = c.launch_tile[l], n = c.launch_tile[l + 1] - t0;
-    const uint32_t nb = std::min(B, n);
-    for (uint32_t b = 0; b < nb; ++b)
-      s->plan_chunks.push_back({(uint32_t)l, t0 + (uint32_t)((uint64_t)n * b / nb),
-                                t0 + (uint32_t)((uint64_t)n * (b + 1) / nb)});
+    const std::vector<uint32_t> cut = cut_launch(s, l, B);
+    for (size_t b = 0; b + 1 < cut.size(); ++b) s->plan_chunks.push_back({(uint32_t)l, cut[b], cut[b + 1]});
   }
   s->plan_valid = true;
 }
@@ -610,7 +638,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
               }
             }
           },
-          inc, inc_start);
+          inc, inc_start, 64);
       const uint64_t n_inc = inc.size();
       if (n_inc >= 0xFFFFFFFFull) throw std::invalid_argument("incidence list exceeds 2^32-1 entries");
       s->n_inc = (uint32_t)n_inc;
@@ -698,6 +726,28 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     rt::stream_sync(st);
     // the un-split sweep's curvature estimate is needed by the first dwx_sgd_plan: pay
     // for it here (one host pass over the records), not inside the first learning sweep
+    {
+      // SGD work per tile (records sgd_on_variable visits, src/factor_graph.cc:262-314):
+      // what the mini-batch plan balances its cuts on
+      std::vector<uint64_t> work(c.tiles.size() + 1, 0);
+      parallel_ranges(c.tiles.size(), host_threads(), [&](uint64_t tb, uint64_t te) {
+        for (uint64_t ti = tb; ti < te; ++ti) {
+          const TileDesc &td = c.tiles[ti];
+          uint64_t n = 0;
+          for (uint32_t p = td.v0; p < td.v0 + td.nv; ++p) {
+            const uint32_t m = c.v_meta[p];
+            const bool trig = opts->learn_non_evidence || (!opts->noise_aware && (m & VM_EVIDENCE)) ||
+                              (opts->noise_aware && (m & VM_TRUTHINESS));
+            if (!trig) continue;
+            for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p + 1]]; ++e)
+              n += !(c.edges[e].packed & EDGE_FIXED_FLAG);
+          }
+          work[ti + 1] = n;
+        }
+      }, 64);
+      for (size_t i = 0; i < c.tiles.size(); ++i) work[i + 1] += work[i];
+      s->sgd_work.swap(work);
+    }
     phase("kernel setup");
     if (opts->step_cap > 0) (void)row_sum_bound(s.get(), 1);
     phase("curvature estimate");

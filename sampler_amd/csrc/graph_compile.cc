@@ -475,7 +475,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
           g.edges[e].packed = (g.edges[e].packed & 0x00FFFFFFu) | ((l & 0xFFu) << EDGE_OWNER_SHIFT);
       g.tiles[i] = t;
     }
-    });
+    }, 64);
     g.n_terms2_tiles = n_terms2;
     g.giant_tiles.clear(); g.launch_giant.clear(); g.launch_giant_query_end.clear();
     for (uint64_t l = 0; l < nl; ++l) {

@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include <stdlib.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
@@ -18,13 +19,21 @@
 
 namespace dwx {
 
+// threads for the host-side setup work: the caller's request, else DWX_HOST_THREADS, else
+// the hardware concurrency capped at 64
 inline uint32_t host_threads(uint32_t requested = 0) {
-  uint32_t n = requested ? requested : std::max(1u, std::thread::hardware_concurrency());
-  return std::min(n, 64u);
+  if (requested) return std::min(requested, 256u);
+  if (const char *e = getenv("DWX_HOST_THREADS")) {
+    const long v = atol(e);
+    if (v > 0) return (uint32_t)std::min(v, 256L);
+  }
+  return std::min(std::max(1u, std::thread::hardware_concurrency()), 64u);
 }
 
 // Uninitialised array of trivially copyable T: unlike std::vector it does not zero-fill
 // serially, so the first touch (and its page faults) happens inside the parallel loops.
+// Large arrays are mapped directly and advised to use transparent huge pages: first touch
+// of multi-GB columns in 4 KiB pages is what the setup phases otherwise spend their time on.
 template <class T>
 class RawArray {
  public:
@@ -32,13 +41,21 @@ class RawArray {
   explicit RawArray(size_t n) { reset(n); }
   RawArray(const RawArray &) = delete;
   RawArray &operator=(const RawArray &) = delete;
-  ~RawArray() { free(p_); }
+  ~RawArray() { release(); }
   void reset(size_t n) {
-    free(p_);
-    p_ = nullptr; n_ = n;
-    if (n) {
-      p_ = (T *)malloc(n * sizeof(T));
-      if (!p_) throw std::bad_alloc();
+    release();
+    n_ = n;
+    if (!n) return;
+    const size_t bytes = n * sizeof(T);
+    if (bytes >= kHuge) {
+      mapped_ = (bytes + kHuge - 1) / kHuge * kHuge;
+      void *m = mmap(nullptr, mapped_, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      if (m == MAP_FAILED) { mapped_ = 0; n_ = 0; throw std::bad_alloc(); }
+      madvise(m, mapped_, MADV_HUGEPAGE);
+      p_ = (T *)m;
+    } else {
+      p_ = (T *)malloc(bytes);
+      if (!p_) { n_ = 0; throw std::bad_alloc(); }
     }
   }
   void clear() { reset(0); }
@@ -51,8 +68,13 @@ class RawArray {
   const T &operator[](size_t i) const { return p_[i]; }
 
  private:
+  static constexpr size_t kHuge = (size_t)2 << 20;
+  void release() {
+    if (mapped_) munmap(p_, mapped_); else free(p_);
+    p_ = nullptr; n_ = 0; mapped_ = 0;
+  }
   T *p_ = nullptr;
-  size_t n_ = 0;
+  size_t n_ = 0, mapped_ = 0;
 };
 
 // fn(part, begin, end) over [0, n) cut into at most n_threads contiguous parts; the first
@@ -82,9 +104,11 @@ void parallel_parts(uint64_t n, uint32_t n_threads, Fn &&fn, uint64_t serial_bel
   if (eptr) std::rethrow_exception(eptr);
 }
 
+// serial_below: item counts under it run on the caller's thread (the default suits
+// per-variable / per-edge items; pass a small value when one item is a lot of work)
 template <class Fn>
-void parallel_ranges(uint64_t n, uint32_t n_threads, Fn &&fn) {
-  parallel_parts(n, n_threads, [&](uint32_t, uint64_t b, uint64_t e) { fn(b, e); });
+void parallel_ranges(uint64_t n, uint32_t n_threads, Fn &&fn, uint64_t serial_below = 65536) {
+  parallel_parts(n, n_threads, [&](uint32_t, uint64_t b, uint64_t e) { fn(b, e); }, serial_below);
 }
 
 // Stable parallel counting sort of generated records by an integer key in [0, n_keys).
@@ -99,14 +123,15 @@ void parallel_ranges(uint64_t n, uint32_t n_threads, Fn &&fn) {
 // counters), buckets handed out dynamically.
 template <class Rec, class KeyFn, class Produce>
 void parallel_group_by_key(uint64_t n_src, uint32_t n_threads, uint64_t n_keys, KeyFn &&key,
-                           Produce &&produce, RawArray<Rec> &out, std::vector<uint64_t> &start) {
+                           Produce &&produce, RawArray<Rec> &out, std::vector<uint64_t> &start,
+                           uint64_t serial_below = 65536) {
   start.assign(n_keys + 1, 0);
   out.clear();
   if (n_keys == 0 || n_src == 0) return;
   uint32_t shift = 0;
   while ((n_keys >> shift) > 4096) ++shift;
   const uint64_t nb = ((n_keys - 1) >> shift) + 1;
-  const uint32_t T = (n_threads <= 1 || n_src < 65536) ? 1u : n_threads;
+  const uint32_t T = (n_threads <= 1 || n_src < serial_below) ? 1u : (uint32_t)std::min<uint64_t>(n_threads, n_src);
   std::vector<std::vector<uint64_t>> hist(T, std::vector<uint64_t>(nb, 0));
   parallel_parts(n_src, T, [&](uint32_t t, uint64_t b, uint64_t e) {
     std::vector<uint64_t> &h = hist[t];

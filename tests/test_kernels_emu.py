@@ -169,7 +169,9 @@ def test_split_sweep_parity_and_heavy_tying_learns_like_the_reference(lib):
     g = dwx.Graph(raw, lib=lib)
     s = dwx.GibbsSampler(g, seed=5, reg_param=0.01)
     batches, n_chunks, eta = s.sgd_plan(0.01)
-    assert batches >= 8 and n_chunks == batches and 0.005 < eta <= 0.01
+    # (cuts balance the SGD work: the query tiles, which learn nothing, ride along with the
+    # first evidence chunk, so there can be fewer chunks than requested batches)
+    assert batches >= 8 and 8 <= n_chunks <= batches and 0.005 < eta <= 0.01
     assert s.sgd_plan(1e-5)[0] == 1                      # tiny step: no split
     dwx.DimmWitted(s, 30, 0, 0.01, 0.95).learn()
     ref = orc.Oracle(raw, reg_param=0.01)
