@@ -186,6 +186,15 @@ int dwx_sgd_finish(dwx_sampler *s);
 /* infrs.weight_values access (src/dimmwitted.cc:209-216 merge/average, :245-258 dump) */
 int dwx_get_weights(dwx_sampler *s, double *out);
 int dwx_set_weights(dwx_sampler *s, const double *in);
+/* Replica averaging, the reference's n_datacopy semantics (DimmWitted::update_weights +
+ * copy_weights_to, src/dimmwitted.cc:209-216,199; InferenceResult::merge_weights_from /
+ * average_weights, src/inference_result.cc:68-79): every replica (one sampler per GPU on
+ * the WHOLE graph, own seed) runs dwx_sample_sgd_async; the driver then sums
+ * DWX_BUF_WEIGHTS over the replicas in place (RCCL all-reduce on dwx_stream) and calls this
+ * on every replica: weights /= n_replicas (fixed weights are restored verbatim), f32
+ * sampling copy refreshed.  Replaces SURVEY.md 8(b)'s dwx_allreduce_weights: the
+ * collective itself stays with the caller's communicator. */
+int dwx_average_weights_async(dwx_sampler *s, uint32_t n_replicas);
 /* InferenceResult::clear_variabletally / sample_tallies + agg_nsamples
  * (src/inference_result.cc:107-127); arrays are in the REFERENCE numbering. */
 int dwx_clear_tallies(dwx_sampler *s);

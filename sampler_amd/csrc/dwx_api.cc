@@ -110,6 +110,7 @@ struct dwx_sampler {
   uint32_t *d_assign_free = nullptr, *d_assign_evid = nullptr, *d_tally = nullptr;
   double *d_weights = nullptr;
   float *d_w32 = nullptr;
+  double *d_w_init = nullptr;   // initial weights, uploaded on the first replica averaging
   long long *d_t_static = nullptr;
   // pull-based gradient (TILE_PULL tiles)
   unsigned long long *d_delta = nullptr;
@@ -133,7 +134,7 @@ struct dwx_sampler {
     rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
     rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
     rt::dfree(d_edges); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
-    rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_t_static); rt::dfree(d_delta); rt::dfree(d_inc_wid);
+    rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_t_static); rt::dfree(d_delta); rt::dfree(d_inc_wid);
     rt::dfree(d_inc_slot); rt::dfree(d_inc_d); rt::dfree(d_w_fixed); rt::dfree(d_grad);
     if (stream) rt::stream_destroy(stream);
   }
@@ -859,6 +860,23 @@ int dwx_set_weights(dwx_sampler *s, const double *in) {
                  (const double *)s->d_weights, s->d_w32, W);
     }
     rt::stream_sync(s->stream);
+  });
+}
+
+int dwx_average_weights_async(dwx_sampler *s, uint32_t n_replicas) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  if (n_replicas == 0) return fail(DWX_E_INVALID, "n_replicas must be >= 1");
+  return guarded([&]() {
+    rt::set_device(s->device);
+    const uint32_t W = (uint32_t)s->cg->W;
+    if (!W) return;
+    if (!s->d_w_init) {
+      s->d_w_init = upload(s->cg->w_init, s->stream);
+      rt::stream_sync(s->stream);
+    }
+    const unsigned grid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 2048u);
+    rt::launch(average_weights_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
+               (const uint8_t *)s->d_w_fixed, (const double *)s->d_w_init, W, (double)n_replicas);
   });
 }
 

@@ -1054,6 +1054,21 @@ refresh_w32_kernel(const double *weights, float *w32, uint32_t W) {
     w32[i] = (float)weights[i];
 }
 
+// Replica averaging (InferenceResult::average_weights + copy_weights_to,
+// src/inference_result.cc:75-86): the caller summed the replicas' weights in place; divide
+// by their number.  Fixed weights are put back verbatim (copy_weights_to skips them; a sum
+// of n equal values divided by n need not round back for n = 3, 5, 6, 7).
+__global__ void __launch_bounds__(BLOCK_THREADS)
+average_weights_kernel(double *weights, float *w32, const uint8_t *w_fixed, const double *w_init,
+                       uint32_t W, double n_replicas) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride) {
+    const double w = w_fixed[i] ? w_init[i] : weights[i] / n_replicas;
+    weights[i] = w;
+    w32[i] = (float)w;
+  }
+}
+
 // test hook: one factor function evaluated on the device (test/factor_test.cc)
 __global__ void test_sign_kernel(uint32_t func, uint32_t arity, const VifRec *vifs,
                                  const uint32_t *assign, double *out) {

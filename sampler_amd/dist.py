@@ -76,6 +76,41 @@ class HipEngine:
         with torch.cuda.stream(self.stream):
             dist.all_reduce(self.grad_reduced, op=dist.ReduceOp.SUM, group=group)
 
+    # ---- replicas (the reference's n_datacopy) ----
+    def sample_sgd(self, stepsize):
+        self.s.sample_sgd(stepsize)
+
+    def clear_tallies(self):
+        self.s.clear_tallies()
+
+    def _wrap(self, which, typestr, itemsize):
+        ptr, nbytes = self.s.device_buffer(which)
+        holder = _CudaArray(ptr, nbytes, typestr, itemsize)
+        self._keep = getattr(self, "_keep", []) + [holder]
+        return torch.as_tensor(holder, device=self.grad.device)
+
+    def average_weights(self, group=None):
+        """update_weights + copy_weights_to (src/dimmwitted.cc:199,209-216): sum the f64
+        master weights over the replicas in place, then divide on every replica."""
+        from . import dwx
+        if not hasattr(self, "_weights"):
+            self._weights = self._wrap(dwx.BUF_WEIGHTS, "<f8", 8)
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(self._weights, op=dist.ReduceOp.SUM, group=group)
+        self.s.average_weights(dist.get_world_size(group))
+
+    def allreduce_tallies(self, group=None):
+        """aggregate_marginals_from (src/inference_result.cc:113-127): sum the replicas'
+        tallies in place (same graph, same device order on every replica)."""
+        from . import dwx
+        if not hasattr(self, "_tallies"):
+            self._tallies = self._wrap(dwx.BUF_TALLIES, "<i4", 4)
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(self._tallies, op=dist.ReduceOp.SUM, group=group)
+
+    def tallies(self):
+        return self.s.tallies()
+
     # ---- halo exchange support ----
     def assign_tensor(self, chain):
         """int32 view of a chain's assignments in DEVICE order (values < 2^31)."""
@@ -219,6 +254,50 @@ class ShardedDimmWitted:
             if self.halo is not None:
                 self.halo.exchange(("evid",))
         self.e.wait()
+
+
+class ReplicatedDimmWitted:
+    """The reference's own multi-copy mode (`-c n_datacopy`, src/dimmwitted.cc:97-119):
+    every rank holds the WHOLE graph and runs its own chains (distinct seeds).  Learning:
+    each replica runs a full sample_sgd sweep on its own weights, then the weights are
+    summed over replicas and averaged (update_weights, :209-216) -- one f64 all-reduce of W
+    values per epoch; n epochs requested = ceil(n / replicas) rounds (compute_n_epochs,
+    :280-282).  Inference: independent sweeps, tallies and sample counts summed at the end
+    (aggregate_marginals_from).  Only valid while the graph fits one GPU."""
+
+    def __init__(self, engine, n_learning_epoch, n_inference_epoch, stepsize=0.01, decay=0.95, group=None):
+        self.e = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.n_learning_rounds = -(-n_learning_epoch // self.world)
+        self.n_inference_rounds = -(-n_inference_epoch // self.world)
+        self.stepsize = stepsize
+        self.decay = decay
+
+    def learn(self):
+        cur = self.stepsize
+        for _ in range(self.n_learning_rounds):
+            self.e.sample_sgd(cur)
+            if self.world > 1:
+                self.e.average_weights(self.group)
+            cur *= self.decay
+        self.e.wait()
+
+    def inference(self):
+        self.e.clear_tallies()
+        self._tallies_summed = False
+        for _ in range(self.n_inference_rounds):
+            self.e.sample()
+        self.e.wait()
+
+    def marginals(self):
+        """-> (tallies, nsamples) summed over replicas, reference numbering, on every rank."""
+        if self.world > 1 and not getattr(self, "_tallies_summed", False):
+            self.e.allreduce_tallies(self.group)
+            self._tallies_summed = True
+        self.e.wait()
+        t, n = self.e.tallies()
+        return t, n * np.uint64(self.world)
 
 
 def shard_range(total, rank, world):

@@ -26,7 +26,8 @@ SYMBOLS = [
     "dwx_sampler_create", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
     "dwx_wait", "dwx_sgd_plan", "dwx_sgd_get_chunks", "dwx_sgd_accumulate_async",
     "dwx_sgd_apply_async", "dwx_sgd_finish",
-    "dwx_get_weights", "dwx_set_weights", "dwx_clear_tallies", "dwx_get_tallies",
+    "dwx_get_weights", "dwx_set_weights", "dwx_average_weights_async",
+    "dwx_clear_tallies", "dwx_get_tallies",
     "dwx_get_assignments", "dwx_set_assignments", "dwx_get_sweep", "dwx_set_sweep",
     "dwx_device_buffer", "dwx_stream", "dwx_kernel_time", "dwx_kernel_time_reset",
     "dwx_test_factor_sign",
@@ -94,6 +95,7 @@ class Library:
         L.dwx_sgd_apply_async.argtypes = [vp]
         L.dwx_sgd_finish.argtypes = [vp]
         L.dwx_get_weights.argtypes = [vp, vp]; L.dwx_set_weights.argtypes = [vp, vp]
+        L.dwx_average_weights_async.argtypes = [vp, C.c_uint32]
         L.dwx_clear_tallies.argtypes = [vp]
         L.dwx_get_tallies.argtypes = [vp, vp, vp]
         L.dwx_get_assignments.argtypes = [vp, i32, vp]
@@ -253,6 +255,10 @@ class GibbsSampler:
         w = np.ascontiguousarray(w, np.float64)
         assert len(w) == self.W
         self.lib.check(self.lib.L.dwx_set_weights(self.h, w.ctypes.data))
+
+    def average_weights(self, n_replicas):
+        """After an in-place sum of BUF_WEIGHTS over replicas: divide, refresh the f32 copy."""
+        self.lib.check(self.lib.L.dwx_average_weights_async(self.h, int(n_replicas)))
 
     def clear_tallies(self):
         self.lib.check(self.lib.L.dwx_clear_tallies(self.h))

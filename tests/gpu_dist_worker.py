@@ -51,6 +51,27 @@ def main():
     ev[pos] = 1 - ev[pos]                       # write through the view = what a halo scatter does
     torch.cuda.synchronize()
     assert np.array_equal(a.assignments("evid")[:10], 1 - b.assignments("evid")[:10])
+    # replica mode at world size 1: the f64 weight all-reduce and the int32 tally all-reduce
+    # run on the sampler's stream over the raw device buffers; averaging over 1 replica
+    # must leave the state of a plain sampler
+    from sampler_amd.dist import ReplicatedDimmWitted
+    c, d = dwx.GibbsSampler(g, seed=77), dwx.GibbsSampler(g, seed=77)
+    rep = ReplicatedDimmWitted(HipEngine(c), 3, 4, 0.05, 0.9)
+    rep.world = 2                                # force the collective path (world size is 1)
+    rep.n_learning_rounds, rep.n_inference_rounds = 3, 4
+    rep.learn()
+    rep.inference()
+    t, n = rep.marginals()
+    cur = 0.05
+    for _ in range(3):
+        d.sample_sgd(cur); cur *= 0.9
+    d.clear_tallies()
+    for _ in range(4):
+        d.sample()
+    d.wait()
+    assert np.array_equal(c.weights, d.weights) and np.abs(c.weights).max() > 0
+    td, nd = d.tallies()
+    assert np.array_equal(t, td) and np.array_equal(n, 2 * nd)
     dist.destroy_process_group()
     print("gpu dist plumbing ok")
 

@@ -146,3 +146,48 @@ def test_two_rank_split_sweeps_agree_on_the_plan_and_match_single_process():
     # negotiation stops once an un-split plan was agreed: the last sweep only re-plans locally
     plans = res[0]["plans"]
     assert plans[-1][1] == 1 and plans[-2][1] == 1 and plans[0][1] == 0
+
+
+def test_two_rank_replicas_average_weights_like_n_datacopy():
+    """Replica mode (the reference's -c n_datacopy): both ranks hold the whole graph and
+    sample with their own seeds; after every learning round the weights are summed and
+    halved (fixed weights untouched); 7 requested epochs = 4 rounds; tallies add up.  Must
+    equal two oracles run in lockstep in one process."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from replica_worker import make_graph
+    world = 2
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as out:
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "replica_worker.py"), out],
+                                          env=env))
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        res = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
+    assert np.array_equal(res[0]["weights"], res[1]["weights"])
+    assert np.array_equal(res[0]["tallies"], res[1]["tallies"])
+    raw = make_graph()
+    os_ = [orc.Oracle(raw, reg_param=0.01) for _ in range(world)]
+    order = np.arange(raw.num_variables, dtype=np.uint64)
+    off = np.array([0, raw.num_variables], np.uint64)
+    fixed = raw.w_is_fixed.astype(bool)
+    sweep, cur = 0, 0.05
+    for _ in range(4):
+        for r, o in enumerate(os_):
+            o.sched_sample_sgd(order, off, 900 + r, sweep, cur, 0.0)
+        avg = np.where(fixed, os_[0].weights, (os_[0].weights + os_[1].weights) / 2)
+        for o in os_:
+            o.weights[:] = avg
+        sweep += 1; cur *= 0.9
+    for o in os_:
+        o.clear_tallies()
+    for _ in range(3):
+        for r, o in enumerate(os_):
+            o.sched_sample(order, off, 900 + r, sweep)
+        sweep += 1
+    assert np.array_equal(res[0]["weights"], os_[0].weights) and np.abs(os_[0].weights).max() > 0
+    assert np.array_equal(res[0]["tallies"], os_[0].tallies + os_[1].tallies)
+    assert np.all(res[0]["nsamples"] == 6)

@@ -218,6 +218,11 @@ def test_ghost_variables_parity(lib):
         else E.test_ghost_variables_parity(lib)
 
 
+def test_replica_weight_averaging(lib):
+    import test_kernels_emu as E
+    E.test_replica_weight_averaging(lib)
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_binary_factor_tiles_all_functions(lib, seed):
     from randgraph import random_graph
@@ -236,9 +241,11 @@ def test_high_degree_hub_variables(lib):
 
 def test_full_pipeline_learn_infer_vs_reference_live(lib):
     """Config-3 shape at 300k variables, the WHOLE pipeline on both sides (the real
-    reference binary vs this build's `dw` drop-in, same files, same flags): learned
-    weights must agree as noisy estimates of the same optimum, marginals within
-    Monte-Carlo tolerance."""
+    reference binary vs this build's `dw` drop-in, same files, same flags).  Learned
+    weights are noisy SGD estimates of the same optimum, so the yardstick is the
+    reference's own run-to-run spread (parity item 4): the reference is run
+    twice (16 and 5 Hogwild threads: different interleavings and seeds), and this build
+    must sit as close to a reference run as the reference runs sit to each other."""
     import subprocess
     from oracle import binding as orc
     if not orc.have_reference():
@@ -247,35 +254,43 @@ def test_full_pipeline_learn_infer_vs_reference_live(lib):
     raw = synthetic.cfg3(V, n_weights=3000, seed=2024)
     args = ["-l", "40", "-i", str(N), "--alpha", "0.01", "--diminish", "0.95", "--reg_param", "0.01"]
     dw = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sampler_amd", "csrc", "dw")
+    q = raw.var_role == 0
+
+    def read(o):
+        w = np.array([float(l.split()[1]) for l in open(os.path.join(o, "inference_result.out.weights.text"))])
+        return w, _parse_marginals(open(os.path.join(o, "inference_result.out.text")).read(), V)
+
     with tempfile.TemporaryDirectory() as d:
         binary_format.write_graph(raw, d)
-        ref_out, my_out = os.path.join(d, "ref"), os.path.join(d, "mine")
-        os.makedirs(ref_out); os.makedirs(my_out)
-        orc.run_reference_dw(d, args, ref_out)
+        outs = [os.path.join(d, n) for n in ("ref_a", "ref_b", "mine")]
+        for o in outs:
+            os.makedirs(o)
+        orc.run_reference_dw(d, args + ["-t", "16", "-c", "1"], outs[0])
+        orc.run_reference_dw(d, args + ["-t", "5", "-c", "1"], outs[1])
         r = subprocess.run([dw, "gibbs", "-m", d + "/graph.meta", "-v", d + "/graph.variables",
-                            "-w", d + "/graph.weights", "-f", d + "/graph.factors", "-o", my_out, "-q",
+                            "-w", d + "/graph.weights", "-f", d + "/graph.factors", "-o", outs[2], "-q",
                             "--seed", "5"] + args, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
-        w = [np.array([float(l.split()[1]) for l in open(os.path.join(o, "inference_result.out.weights.text"))])
-             for o in (ref_out, my_out)]
-        p = [_parse_marginals(open(os.path.join(o, "inference_result.out.text")).read(), V)
-             for o in (ref_out, my_out)]
+        (wa, pa), (wb, pb), (wm, pm) = [read(o) for o in outs]
+
+    def spread(w0, p0, w1, p1):
+        z = stats.z_scores_two_sample(p1[q], N, p0[q], N)
+        pbar = 0.5 * (p1[q] + p0[q])
+        z = z[(pbar > 0.1) & (pbar < 0.9)]
+        return dict(dw_mean=abs(w0.mean() - w1.mean()), dw_std=(w0 - w1).std(),
+                    corr=np.corrcoef(w0, w1)[0, 1], dp_mean=abs(p0[q].mean() - p1[q].mean()),
+                    z_mean=abs(z.mean()), z_var=z.var())
+
+    ref, mine = spread(wa, pa, wb, pb), spread(wa, pa, wm, pm)
+    print("reference vs reference:", ref)
+    print("this build vs reference:", mine)
     # ~1000 factors (~500 evidence) per weight; a variable's 10 weights share the MLE
-    # logit(0.7)/2 = 0.42, i.e. 0.042 per weight on average.  Two noisy SGD runs (the
-    # reference is Hogwild over all host cores) correlate at ~0.75-0.85.
-    assert abs(w[0].mean() - w[1].mean()) < 0.02 and abs(w[0].std() - w[1].std()) < 0.03
-    assert np.corrcoef(w[0], w[1])[0, 1] > 0.6
-    assert 0.02 < w[1].mean() < 0.07
-    q = raw.var_role == 0
-    assert np.array_equal(np.isnan(p[0]), np.isnan(p[1])) and np.array_equal(~np.isnan(p[0]), q)
-    p_ref, p_gpu = p[0][q], p[1][q]
-    assert abs(p_ref.mean() - p_gpu.mean()) < 0.005
-    z = stats.z_scores_two_sample(p_gpu, N, p_ref, N)
-    pbar = 0.5 * (p_gpu + p_ref)
-    z = z[(pbar > 0.1) & (pbar < 0.9)]
-    # the two sides sample from slightly different learned weights, so var(z) sits a little
-    # above 1 and a 0.001 difference in the mean learned weight moves mean(z) by ~0.05; a real
-    # sampling bug would shift the mean by whole units or blow the variance up (inference
-    # with IDENTICAL weights is held to the tight bounds in the synth/end-to-end tests)
-    assert abs(z.mean()) < 0.2 and 0.9 < z.var() < 1.6
-    assert stats.ks_two_sample(p_gpu, p_ref) > 0.001
+    # logit(0.7)/2 = 0.42, i.e. 0.042 per weight on average
+    assert 0.02 < wm.mean() < 0.07 and 0.02 < wa.mean() < 0.07
+    assert np.array_equal(np.isnan(pa), np.isnan(pm)) and np.array_equal(~np.isnan(pm), q)
+    assert mine["dw_mean"] < 1.5 * ref["dw_mean"] + 0.005
+    assert mine["dw_std"] < 1.5 * ref["dw_std"] + 0.01
+    assert mine["corr"] > ref["corr"] - 0.15
+    assert mine["dp_mean"] < 1.5 * ref["dp_mean"] + 0.003
+    assert mine["z_mean"] < 1.5 * ref["z_mean"] + 0.1
+    assert 0.9 < mine["z_var"] < 1.5 * ref["z_var"] + 0.3

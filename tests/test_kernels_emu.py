@@ -183,3 +183,33 @@ def test_split_sweep_parity_and_heavy_tying_learns_like_the_reference(lib):
     # with splitting disabled (step_cap <= 0) the same run drifts far away
     s1 = dwx.GibbsSampler(g, seed=5, reg_param=0.01, step_cap=0.0)
     assert s1.sgd_plan(0.01)[0] == 1
+
+
+def test_replica_weight_averaging(lib):
+    """dwx_average_weights_async: after an in-place sum over n replicas, non-fixed weights
+    are divided by n, fixed weights restored verbatim, and the f32 sampling copy follows
+    (the next sweep draws exactly what a sampler with those weights set draws)."""
+    from sampler_amd import dwx
+    from randgraph import random_graph
+    raw = random_graph(41, V=500, F=2500, W=25, p_cat=0.2, max_arity=2, exact_fvals=True)
+    raw.w_is_fixed[::4] = 1
+    raw.w_initial_value[::4] = 0.1 * np.arange(len(raw.w_initial_value[::4])) + 0.3   # 3*x/3 != x for some
+    g = dwx.Graph(raw, lib=lib)
+    a, b = dwx.GibbsSampler(g, seed=9), dwx.GibbsSampler(g, seed=9)
+    a.sample_sgd(0.05); b.sample_sgd(0.05); a.wait(); b.wait()
+    w = a.weights
+    assert np.array_equal(w, b.weights) and np.abs(w[raw.w_is_fixed == 0]).max() > 0
+    fixed = raw.w_is_fixed.astype(bool)
+    other = w + np.where(fixed, 0.0, 0.25)             # what a second and third replica hold
+    third = w - np.where(fixed, 0.0, 0.125)
+    a.weights = w + other + third                      # stands for the in-place all-reduce(SUM)
+    a.average_weights(3)
+    expect = np.where(fixed, raw.w_initial_value, (w + other + third) / 3)
+    assert np.array_equal(a.weights, expect)
+    assert np.array_equal(a.weights[fixed], raw.w_initial_value[fixed])
+    b.weights = expect
+    for _ in range(3):
+        a.sample(); b.sample()
+    a.wait(); b.wait()
+    assert np.array_equal(a.assignments("evid"), b.assignments("evid"))
+    assert np.array_equal(a.tallies()[0], b.tallies()[0])
