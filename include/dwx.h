@@ -176,6 +176,10 @@ int dwx_wait(dwx_sampler *s);
  *   + dwx_sgd_apply_async where due];  dwx_sgd_finish. */
 int dwx_sgd_plan(dwx_sampler *s, double stepsize, uint32_t force_batches, uint32_t *batches,
                  uint32_t *n_chunks, double *effective_stepsize);
+/* Multi-GPU only: make the current split plan's static-count table n_rows tall (rows
+ * beyond this rank's own chunks are zero), so that all ranks can sum equally sized tables
+ * and every rank can apply the update of a chunk it idles through. */
+int dwx_sgd_plan_rows(dwx_sampler *s, uint32_t n_rows);
 /* chunk_off[n_chunks+1]: chunk c covers positions [chunk_off[c], chunk_off[c+1]) of the
  * schedule order (dwx_graph_get_schedule). */
 int dwx_sgd_get_chunks(dwx_sampler *s, uint64_t *chunk_off);
@@ -215,9 +219,15 @@ enum {
   DWX_BUF_ASSIGN_FREE = 2,  /* uint32[V] in device order                           */
   DWX_BUF_ASSIGN_EVID = 3,  /* uint32[V] in device order                           */
   DWX_BUF_TALLIES = 4,      /* uint32[num_values] in device order                  */
-  DWX_BUF_TSTATIC = 5       /* int64[W]: per-sweep update counts of boolean variables
+  DWX_BUF_TSTATIC = 5,      /* int64[W]: per-sweep update counts of boolean variables
                                (fixed point, static); a multi-GPU driver sums it
                                across shards once after create                     */
+  DWX_BUF_TSTATIC_PLAN = 6  /* int64[rows][W]: the same counts per chunk of the current
+                               SPLIT plan (valid between dwx_sgd_plan and dwx_sgd_finish;
+                               null / 0 bytes when the plan counts dynamically).  A
+                               multi-GPU driver calls dwx_sgd_plan_rows(n_chunks of the
+                               slowest rank) and sums the table across shards ONCE per
+                               batch count (the library caches it per batch count)   */
 };
 int dwx_device_buffer(dwx_sampler *s, int which, void **dev_ptr, uint64_t *nbytes);
 /* The HIP stream (hipStream_t) the sampler enqueues on. */

@@ -111,12 +111,25 @@ struct dwx_sampler {
   double *d_weights = nullptr;
   float *d_w32 = nullptr;
   double *d_w_init = nullptr;   // initial weights, uploaded on the first replica averaging
-  long long *d_t_static = nullptr;
   // pull-based gradient (TILE_PULL tiles)
   unsigned long long *d_delta = nullptr;
-  uint32_t *d_inc_wid = nullptr, *d_inc_slot = nullptr;
-  float *d_inc_d = nullptr;
-  uint32_t n_inc = 0;
+  // One incidence list + static update counts per plan level (number of batches): sorted by
+  // (chunk, weight), every chunk padded to whole runs; t_static holds one row of W counts per
+  // chunk (rows >= chunks: a multi-GPU driver sizes it for the slowest rank).  Level 1 (the
+  // un-split sweep) is built at create, the others when a plan first needs them.
+  struct Level {
+    std::vector<Chunk> chunks;
+    bool fast = false;                 // lists + static counts present (else: atomics, dynamic T)
+    uint32_t *d_inc_wid = nullptr, *d_inc_slot = nullptr;
+    float *d_inc_d = nullptr;
+    std::vector<uint32_t> inc_begin, inc_end;   // per chunk, entries (multiples of PULL_RUN)
+    long long *d_t_static = nullptr;
+    uint32_t rows = 0;
+    ~Level() { rt::dfree(d_inc_wid); rt::dfree(d_inc_slot); rt::dfree(d_inc_d); rt::dfree(d_t_static); }
+  };
+  std::map<uint32_t, std::unique_ptr<Level>> levels;
+  Level *plan_level = nullptr;        // level of the current plan
+  uint32_t cur_chunk = 0;             // last chunk handed to dwx_sgd_accumulate_async
   uint8_t *d_w_fixed = nullptr;
   long long *d_grad = nullptr;
   KernelParams base{};
@@ -134,8 +147,8 @@ struct dwx_sampler {
     rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
     rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
     rt::dfree(d_edges); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
-    rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_t_static); rt::dfree(d_delta); rt::dfree(d_inc_wid);
-    rt::dfree(d_inc_slot); rt::dfree(d_inc_d); rt::dfree(d_w_fixed); rt::dfree(d_grad);
+    rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_delta);
+    rt::dfree(d_w_fixed); rt::dfree(d_grad);
     if (stream) rt::stream_destroy(stream);
   }
 };
@@ -229,6 +242,136 @@ std::vector<uint32_t> cut_launch(const dwx_sampler *s, size_t l, uint32_t nb) {
   }
   cut.push_back(t1);
   return cut;
+}
+
+bool triggers_sgd(const dwx_options &o, uint32_t meta) {
+  return o.learn_non_evidence || (!o.noise_aware && (meta & VM_EVIDENCE)) ||
+         (o.noise_aware && (meta & VM_TRUTHINESS));
+}
+
+// Everything a plan level needs to run its chunks without per-record atomics: per chunk,
+// (a) the static update counts of its boolean variables -- a boolean variable that triggers
+// SGD visits every factor of its row once with t = 1 (src/factor_graph.cc:265-273),
+// independent of the samples drawn -- and (b) the pull-gradient incidence list of its
+// TILE_PULL tiles: every (triggering variable, non-fixed record) pair, sorted by weight
+// (two stable parallel counting sorts: by weight, then by chunk).
+dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
+  auto it = s->levels.find(batches);
+  if (it != s->levels.end()) return it->second.get();
+  rt::set_device(s->device);
+  const CompiledGraph &c = *s->cg;
+  const dwx_options &o = s->opts;
+  const uint32_t nth = host_threads();
+  std::unique_ptr<dwx_sampler::Level> L(new dwx_sampler::Level());
+  for (size_t l = 0; l + 1 < c.launch_off.size(); ++l) {
+    const std::vector<uint32_t> cut = cut_launch(s, l, batches);
+    for (size_t b = 0; b + 1 < cut.size(); ++b) L->chunks.push_back({(uint32_t)l, cut[b], cut[b + 1]});
+  }
+  const uint32_t nc = (uint32_t)L->chunks.size();
+  // beyond this the per-chunk tables cost more than they save: such plans keep the
+  // per-record atomics and dynamic counts
+  L->fast = nc >= 1 && nc <= 64 && (uint64_t)nc * c.W * 8 <= ((uint64_t)2 << 30);
+  if (batches == 1) L->fast = true;
+  if (L->fast && c.W) {
+    // groups of the tables: the chunks of a split sweep (an update follows each of them); ONE
+    // group for an un-split sweep, whatever its number of colour launches (one update at the end)
+    struct Group { uint32_t t0, t1; };
+    std::vector<Group> groups;
+    if (batches == 1) groups.push_back({0u, (uint32_t)c.tiles.size()});
+    else for (const auto &ch : L->chunks) groups.push_back({ch.t0, ch.t1});
+    const uint32_t nc = (uint32_t)groups.size();
+    std::vector<uint32_t> chunk_of(c.tiles.size(), 0);
+    for (uint32_t k = 0; k < nc; ++k)
+      for (uint32_t t = groups[k].t0; t < groups[k].t1; ++t) chunk_of[t] = k;
+    // (a) static counts, one row per group (rows are disjoint: groups in parallel)
+    L->rows = nc;
+    RawArray<long long> ts((size_t)nc * c.W);
+    parallel_ranges((uint64_t)nc * c.W, nth, [&](uint64_t b, uint64_t e) { std::fill(ts.data() + b, ts.data() + e, 0LL); });
+    const long long one = (long long)FIX_SCALE;
+    parallel_ranges(nc, std::min(nth, nc), [&](uint64_t kb, uint64_t ke) {
+      for (uint64_t k = kb; k < ke; ++k) {
+        long long *row = ts.data() + k * c.W;
+        const uint32_t p0 = c.tile_v[groups[k].t0], p1 = c.tile_v[groups[k].t1];
+        for (uint32_t p = p0; p < p1; ++p) {
+          const uint32_t m = c.v_meta[p];
+          if ((m & VM_CATEGORICAL) || !triggers_sgd(o, m)) continue;
+          for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p] + 1]; ++e)
+            if (!c.w_fixed[c.edges[e].wid]) row[c.edges[e].wid] += one;
+        }
+      }
+    }, 2);
+    L->d_t_static = upload_raw(ts.data(), (size_t)nc * c.W, s->stream);
+    // (b) incidence list
+    struct Inc { uint32_t wid, slot; float d; uint32_t chunk; };
+    RawArray<Inc> by_w, by_c;
+    std::vector<uint64_t> w_start, c_start;
+    parallel_group_by_key<Inc>(
+        c.tiles.size(), nth, c.W, [](const Inc &r) { return (uint64_t)r.wid; },
+        [&](uint64_t tb, uint64_t te, auto &&emit) {
+          for (uint64_t ti = tb; ti < te; ++ti) {
+            const TileDesc &td = c.tiles[ti];
+            if (!(td.flags & TILE_PULL)) continue;
+            if (td.nrows > c.rcap || td.nedges > c.ecap) continue;   // oversized: giant_kernel, atomics
+            for (uint32_t l = 0; l < td.nv; ++l) {
+              const uint32_t p = td.v0 + l, m = c.v_meta[p];
+              if (!(o.learn_non_evidence || (!o.noise_aware && (m & VM_EVIDENCE)))) continue;
+              for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p] + 1]; ++e) {
+                const EdgeRec &r = c.edges[e];
+                if (r.packed & EDGE_FIXED_FLAG) continue;
+                float miss;
+                std::memcpy(&miss, &r.aux, 4);
+                const float dd = r.fval - miss;    // exact: |hit| == |miss| or one of them is 0
+                if (dd == 0.0f) continue;
+                emit(Inc{r.wid, (uint32_t)(ti * BLOCK_THREADS + l), dd, chunk_of[ti]});
+              }
+            }
+          }
+        },
+        by_w, w_start, 64);
+    const uint64_t n_inc = by_w.size();
+    if (n_inc + (uint64_t)nc * PULL_RUN >= 0xFFFFFFFFull)
+      throw std::invalid_argument("incidence list exceeds 2^32-1 entries");
+    const RawArray<Inc> *src = &by_w;
+    if (nc > 1) {
+      parallel_group_by_key<Inc>(
+          n_inc, nth, nc, [](const Inc &r) { return (uint64_t)r.chunk; },
+          [&](uint64_t b, uint64_t e, auto &&emit) { for (uint64_t i = b; i < e; ++i) emit(by_w[i]); },
+          by_c, c_start);
+      by_w.clear();
+      src = &by_c;
+    } else {
+      c_start = {0, n_inc};
+    }
+    // columns; every chunk padded to whole runs with neutral entries (its last weight, zero
+    // contribution), so the kernel's 16-byte loads never leave the chunk
+    std::vector<uint64_t> off(nc + 1, 0);
+    for (uint32_t k = 0; k < nc; ++k)
+      off[k + 1] = off[k] + (c_start[k + 1] - c_start[k] + PULL_RUN - 1) / PULL_RUN * PULL_RUN;
+    const uint64_t padded = off[nc];
+    L->inc_begin.resize(nc); L->inc_end.resize(nc);
+    if (padded) {
+      RawArray<uint32_t> iw(padded), is(padded);
+      RawArray<float> id(padded);
+      for (uint32_t k = 0; k < nc; ++k) {
+        L->inc_begin[k] = (uint32_t)off[k]; L->inc_end[k] = (uint32_t)off[k + 1];
+        const uint64_t n = c_start[k + 1] - c_start[k], base = c_start[k];
+        parallel_ranges(off[k + 1] - off[k], nth, [&](uint64_t b, uint64_t e) {
+          for (uint64_t i = b; i < e; ++i) {
+            const Inc &r = (*src)[base + std::min(i, n - 1)];
+            iw[off[k] + i] = r.wid; is[off[k] + i] = r.slot; id[off[k] + i] = i < n ? r.d : 0.0f;
+          }
+        });
+      }
+      L->d_inc_wid = upload_raw(iw.data(), padded, s->stream);
+      L->d_inc_slot = upload_raw(is.data(), padded, s->stream);
+      L->d_inc_d = upload_raw(id.data(), padded, s->stream);
+      rt::stream_sync(s->stream);   // the columns die with this scope
+    }
+    rt::stream_sync(s->stream);
+  }
+  dwx_sampler::Level *out = L.get();
+  s->levels[batches] = std::move(L);
+  return out;
 }
 
 // Curvature of one SGD mini-batch in weight space, when every colour launch is cut into
@@ -386,11 +529,9 @@ void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
   }
   s->plan_batches = B;
   s->plan_eta = eta;
-  s->plan_chunks.clear();
-  for (size_t l = 0; l + 1 < c.launch_off.size(); ++l) {
-    const std::vector<uint32_t> cut = cut_launch(s, l, B);
-    for (size_t b = 0; b + 1 < cut.size(); ++b) s->plan_chunks.push_back({(uint32_t)l, cut[b], cut[b + 1]});
-  }
+  s->plan_level = build_level(s, B);
+  s->plan_chunks = s->plan_level->chunks;
+  s->cur_chunk = 0;
   s->plan_valid = true;
 }
 
@@ -401,8 +542,10 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
   const dwx_sampler::Chunk &ch = s->plan_chunks[chunk];
   KernelParams P = s->base;
   P.sweep = s->sweep;
+  const dwx_sampler::Level &L = *s->plan_level;
   const bool split = s->plan_batches > 1;
-  if (split) P.flags |= OPT_DYNAMIC_T | OPT_NO_PULL;
+  // a split sweep without per-chunk tables falls back to per-record atomics and counts
+  if (split && !L.fast) P.flags |= OPT_DYNAMIC_T | OPT_NO_PULL;
   TimedSpan sp{};
   if (s->timing) {
     sp.a = rt::event_create(); sp.b = rt::event_create(); sp.c = rt::event_create(); sp.kind = 1;
@@ -411,12 +554,19 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
   const uint32_t launches = launch_tiles<true>(s, P, ch.launch, ch.t0, ch.t1);
   if (s->timing) rt::event_record(sp.b, s->stream);
   bool pulled = false;
-  if (!split && chunk + 1 == s->plan_chunks.size() && s->n_inc) {
-    // un-split sweep: the pull-based gradient of all TILE_PULL tiles, once, at the end
+  // the pull-based gradient of the TILE_PULL tiles: un-split sweeps once, after the last
+  // chunk (= colour launch), over the whole list; split sweeps per chunk over its part
+  uint32_t pb = 0, pe = 0;
+  if (L.fast && !L.inc_end.empty()) {
+    if (!split) { if (chunk + 1 == s->plan_chunks.size()) { pb = L.inc_begin.front(); pe = L.inc_end.back(); } }
+    else { pb = L.inc_begin[chunk]; pe = L.inc_end[chunk]; }
+  }
+  if (pe > pb) {
+    const uint32_t n = pe - pb;
     const unsigned chunk_sz = BLOCK_THREADS * PULL_RUN;
-    const unsigned grid = std::min<unsigned>((s->n_inc + chunk_sz - 1) / chunk_sz, 256u * 16u);
-    rt::launch(pull_grad_kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)s->d_inc_wid,
-               (const uint32_t *)s->d_inc_slot, (const float *)s->d_inc_d, s->n_inc,
+    const unsigned grid = std::min<unsigned>((n + chunk_sz - 1) / chunk_sz, 256u * 16u);
+    rt::launch(pull_grad_kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)(L.d_inc_wid + pb),
+               (const uint32_t *)(L.d_inc_slot + pb), (const float *)(L.d_inc_d + pb), n,
                (const unsigned long long *)s->d_delta, s->d_grad);
     pulled = true;
   }
@@ -432,7 +582,14 @@ void enqueue_apply(dwx_sampler *s) {
   const uint32_t W = (uint32_t)s->cg->W;
   if (!W) return;
   const unsigned grid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 2048u);
-  const long long *ts = s->plan_batches > 1 ? nullptr : (const long long *)s->d_t_static;
+  // static update counts of what was just accumulated: row 0 of an un-split sweep, the
+  // chunk's row of a split one (none on the atomics fallback: counts are in the grad buffer)
+  const dwx_sampler::Level *L = s->plan_level;
+  const long long *ts = nullptr;
+  if (L && L->fast && L->d_t_static) {
+    const uint32_t row = s->plan_batches > 1 ? s->cur_chunk : 0u;
+    if (row < L->rows) ts = L->d_t_static + (size_t)row * W;
+  }
   rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
              (const uint8_t *)s->d_w_fixed, s->d_grad, ts, W, s->plan_eta, s->opts.reg_param,
              (int)(s->opts.regularization == 1));
@@ -594,74 +751,6 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       std::vector<float> w32(c.W);
       for (uint64_t i = 0; i < c.W; ++i) w32[i] = (float)c.w_init[i];
       s->d_w32 = upload(w32, st, 1);
-      // static per-sweep update counts: a boolean variable that triggers SGD visits
-      // every factor of its row once per learning sweep with t = 1
-      // (src/factor_graph.cc:265-273), independent of the samples drawn
-      std::vector<long long> ts(c.W, 0);
-      const long long one = (long long)FIX_SCALE;
-      for (uint64_t p = 0; p < c.Vo; ++p) {
-        const uint32_t m = c.v_meta[p];
-        if (m & VM_CATEGORICAL) continue;
-        const bool is_evid = m & VM_EVIDENCE;
-        const bool trig = opts->learn_non_evidence || (!opts->noise_aware && is_evid);
-        if (!trig) continue;
-        for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p] + 1]; ++e)
-          if (!c.w_fixed[c.edges[e].wid]) ts[c.edges[e].wid] += one;
-      }
-      s->d_t_static = upload(ts, st);
-      phase("static update counts");
-      // Incidence list of the pull-based gradient: every (SGD-triggering variable of a
-      // TILE_PULL tile, non-fixed record) pair, counting-sorted by weight id.
-      struct Inc { uint32_t wid, slot; float d; };
-      const uint32_t nth = host_threads();
-      RawArray<Inc> inc;
-      std::vector<uint64_t> inc_start;
-      parallel_group_by_key<Inc>(
-          c.tiles.size(), nth, c.W, [](const Inc &r) { return (uint64_t)r.wid; },
-          [&](uint64_t tb, uint64_t te, auto &&emit) {
-            for (uint64_t ti = tb; ti < te; ++ti) {
-              const TileDesc &td = c.tiles[ti];
-              if (!(td.flags & TILE_PULL)) continue;
-              if (td.nrows > c.rcap || td.nedges > c.ecap) continue;   // oversized: giant_kernel, atomics
-              for (uint32_t l = 0; l < td.nv; ++l) {
-                const uint32_t p = td.v0 + l, m = c.v_meta[p];
-                const bool trig = opts->learn_non_evidence || (!opts->noise_aware && (m & VM_EVIDENCE));
-                if (!trig) continue;
-                for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p] + 1]; ++e) {
-                  const EdgeRec &r = c.edges[e];
-                  if (r.packed & EDGE_FIXED_FLAG) continue;
-                  float miss;
-                  std::memcpy(&miss, &r.aux, 4);
-                  const float dd = r.fval - miss;    // exact: |hit| == |miss| or one of them is 0
-                  if (dd == 0.0f) continue;
-                  emit(Inc{r.wid, (uint32_t)(ti * BLOCK_THREADS + l), dd});
-                }
-              }
-            }
-          },
-          inc, inc_start, 64);
-      const uint64_t n_inc = inc.size();
-      if (n_inc >= 0xFFFFFFFFull) throw std::invalid_argument("incidence list exceeds 2^32-1 entries");
-      s->n_inc = (uint32_t)n_inc;
-      if (n_inc) {
-        // split into columns, padded to a whole run with neutral entries (same weight as
-        // the last one, zero gradient contribution), so the kernel's 16-byte loads never
-        // leave the arrays
-        const uint64_t padded = (n_inc + PULL_RUN - 1) / PULL_RUN * PULL_RUN;
-        RawArray<uint32_t> iw(padded), is(padded);
-        RawArray<float> id(padded);
-        parallel_ranges(padded, nth, [&](uint64_t b, uint64_t e) {
-          for (uint64_t i = b; i < e; ++i) {
-            const Inc &r = inc[std::min(i, n_inc - 1)];
-            iw[i] = r.wid; is[i] = r.slot; id[i] = i < n_inc ? r.d : 0.0f;
-          }
-        });
-        s->d_inc_wid = upload_raw(iw.data(), padded, st);
-        s->d_inc_slot = upload_raw(is.data(), padded, st);
-        s->d_inc_d = upload_raw(id.data(), padded, st);
-        rt::stream_sync(st);   // the columns die with this scope
-      }
-      phase("gradient incidence list");
       s->d_delta = (unsigned long long *)rt::dmalloc((c.tiles.size() * 8 + 2) * 8);
       rt::dmemset(s->d_delta, 0, (c.tiles.size() * 8 + 2) * 8, st);
     }
@@ -750,6 +839,8 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       s->sgd_work.swap(work);
     }
     phase("kernel setup");
+    (void)build_level(s.get(), 1);
+    phase("static counts + gradient incidence list");
     if (opts->step_cap > 0) (void)row_sum_bound(s.get(), 1);
     phase("curvature estimate");
   });
@@ -788,6 +879,24 @@ int dwx_sgd_plan(dwx_sampler *s, double stepsize, uint32_t force_batches, uint32
   });
 }
 
+int dwx_sgd_plan_rows(dwx_sampler *s, uint32_t n_rows) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  if (!s->plan_valid || !s->plan_level) return fail(DWX_E_INVALID, "no plan: call dwx_sgd_plan first");
+  return guarded([&]() {
+    dwx_sampler::Level &L = *s->plan_level;
+    const uint64_t W = s->cg->W;
+    if (!L.fast || s->plan_batches <= 1 || n_rows <= L.rows || !W) return;
+    rt::set_device(s->device);
+    long long *grown = (long long *)rt::dmalloc((size_t)n_rows * W * 8);
+    rt::dmemset(grown, 0, (size_t)n_rows * W * 8, s->stream);
+    rt::d2d(grown, L.d_t_static, (size_t)L.rows * W * 8, s->stream);
+    rt::stream_sync(s->stream);
+    rt::dfree(L.d_t_static);
+    L.d_t_static = grown;
+    L.rows = n_rows;
+  });
+}
+
 int dwx_sgd_get_chunks(dwx_sampler *s, uint64_t *chunk_off) {
   if (!s || !chunk_off) return fail(DWX_E_INVALID, "null argument");
   if (!s->plan_valid) return fail(DWX_E_INVALID, "no plan: call dwx_sgd_plan first");
@@ -801,7 +910,10 @@ int dwx_sgd_get_chunks(dwx_sampler *s, uint64_t *chunk_off) {
 int dwx_sgd_accumulate_async(dwx_sampler *s, uint32_t chunk) {
   if (!s) return fail(DWX_E_INVALID, "null sampler");
   if (!s->plan_valid) return fail(DWX_E_INVALID, "no plan: call dwx_sgd_plan first");
-  return guarded([&]() { enqueue_learn_chunk(s, chunk); });
+  return guarded([&]() {
+    s->cur_chunk = chunk;
+    enqueue_learn_chunk(s, chunk);
+  });
 }
 
 int dwx_sgd_apply_async(dwx_sampler *s) {
@@ -823,6 +935,7 @@ int dwx_sample_sgd_async(dwx_sampler *s, double stepsize) {
     make_plan(s, stepsize, 0);
     const size_t n = s->plan_chunks.size();
     for (size_t c = 0; c < n; ++c) {
+      s->cur_chunk = (uint32_t)c;
       enqueue_learn_chunk(s, (uint32_t)c);
       if (s->plan_batches > 1 || c + 1 == n) enqueue_apply(s);
     }
@@ -954,7 +1067,17 @@ int dwx_device_buffer(dwx_sampler *s, int which, void **dev_ptr, uint64_t *nbyte
     case DWX_BUF_ASSIGN_FREE: *dev_ptr = s->d_assign_free; *nbytes = c.V * 4; break;
     case DWX_BUF_ASSIGN_EVID: *dev_ptr = s->d_assign_evid; *nbytes = c.V * 4; break;
     case DWX_BUF_TALLIES: *dev_ptr = s->d_tally; *nbytes = c.R * 4; break;
-    case DWX_BUF_TSTATIC: *dev_ptr = s->d_t_static; *nbytes = c.W * 8; break;
+    case DWX_BUF_TSTATIC: {
+      auto it = s->levels.find(1);
+      *dev_ptr = it == s->levels.end() ? nullptr : it->second->d_t_static;
+      *nbytes = c.W * 8;
+      break;
+    }
+    case DWX_BUF_TSTATIC_PLAN:
+      if (!s->plan_valid || !s->plan_level) return fail(DWX_E_INVALID, "no plan: call dwx_sgd_plan first");
+      *dev_ptr = s->plan_level->fast ? s->plan_level->d_t_static : nullptr;
+      *nbytes = s->plan_level->fast ? (uint64_t)s->plan_level->rows * c.W * 8 : 0;
+      break;
     default: return fail(DWX_E_INVALID, "unknown buffer id");
   }
   return DWX_OK;

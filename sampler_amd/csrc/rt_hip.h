@@ -44,6 +44,9 @@ inline void h2d(void *d, const void *h, size_t n, stream_t s) {
 inline void d2h(void *h, const void *d, size_t n, stream_t s) {
   if (n) DWX_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
 }
+inline void d2d(void *dst, const void *src, size_t n, stream_t s) {
+  if (n) DWX_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));
+}
 inline void dmemset(void *d, int v, size_t n, stream_t s) {
   if (n) DWX_HIP(hipMemsetAsync(d, v, n, s));
 }

@@ -48,6 +48,7 @@ class HipEngine:
         self._tholder = _CudaArray(tp, tn, "<i8", 8)
         self.t_static = torch.as_tensor(self._tholder, device=dev)
         self.stream = torch.cuda.ExternalStream(sampler.stream(), device=dev)
+        self._plan_batches, self._dynamic_counts, self._shared_levels = 1, False, set()
 
     def allreduce_static_counts(self, group=None):
         """Once after create: every rank only counted its own shard's boolean updates."""
@@ -55,7 +56,29 @@ class HipEngine:
             dist.all_reduce(self.t_static, op=dist.ReduceOp.SUM, group=group)
 
     def sgd_plan(self, stepsize, force_batches=0):
-        return self.s.sgd_plan(stepsize, force_batches)
+        from . import dwx
+        batches, n_chunks, eta = self.s.sgd_plan(stepsize, force_batches)
+        # a split plan either carries per-chunk static update counts (summed across ranks once,
+        # see share_plan_static_counts) or counts dynamically into the T half of the gradient
+        # vector, which then has to travel with every all-reduce
+        self._plan_batches = batches
+        self._dynamic_counts = batches > 1 and self.s.device_buffer(dwx.BUF_TSTATIC_PLAN)[1] == 0
+        return batches, n_chunks, eta
+
+    def share_plan_static_counts(self, n_chunks_all, group=None):
+        """Once per batch count of a split plan: size the per-chunk static-count table for the
+        slowest rank's chunk count and sum it across shards (each rank counted its own block)."""
+        from . import dwx
+        if self._plan_batches <= 1 or self._dynamic_counts or self._plan_batches in self._shared_levels:
+            return
+        self.s.sgd_plan_rows(n_chunks_all)
+        ptr, nbytes = self.s.device_buffer(dwx.BUF_TSTATIC_PLAN)
+        holder = _CudaArray(ptr, nbytes, "<i8", 8)
+        t = torch.as_tensor(holder, device=self.grad.device)
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        self.stream.synchronize()      # the wrapper may go away; the table stays in the library
+        self._shared_levels.add(self._plan_batches)
 
     def sgd_accumulate(self, chunk):
         self.s.sgd_accumulate(chunk)
@@ -74,7 +97,8 @@ class HipEngine:
 
     def allreduce_grad(self, group=None):
         with torch.cuda.stream(self.stream):
-            dist.all_reduce(self.grad_reduced, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(self.grad if self._dynamic_counts else self.grad_reduced,
+                            op=dist.ReduceOp.SUM, group=group)
 
     # ---- replicas (the reference's n_datacopy) ----
     def sample_sgd(self, stepsize):
@@ -237,6 +261,8 @@ class ShardedDimmWitted:
             t = torch.tensor([n_mine], dtype=torch.int64, device=self.e.grad.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             n_chunks = int(t[0])
+            if batches > 1 and hasattr(self.e, "share_plan_static_counts"):
+                self.e.share_plan_static_counts(n_chunks, self.group)
         else:
             _, n_chunks, _ = self.e.sgd_plan(stepsize, batches)
         return batches, n_chunks

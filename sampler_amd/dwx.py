@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libdwx.so")
 
 DWX_OK, DWX_E_INVALID, DWX_E_LIMIT, DWX_E_DEVICE, DWX_E_NOMEM = 0, -1, -2, -3, -4
-BUF_WEIGHTS, BUF_GRAD, BUF_ASSIGN_FREE, BUF_ASSIGN_EVID, BUF_TALLIES, BUF_TSTATIC = range(6)
+BUF_WEIGHTS, BUF_GRAD, BUF_ASSIGN_FREE, BUF_ASSIGN_EVID, BUF_TALLIES, BUF_TSTATIC, BUF_TSTATIC_PLAN = range(7)
 
 # every symbol include/dwx.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -24,7 +24,7 @@ SYMBOLS = [
     "dwx_graph_create", "dwx_graph_destroy", "dwx_graph_get_info", "dwx_graph_get_schedule",
     "dwx_graph_get_values", "dwx_graph_get_positions", "dwx_graph_get_index",
     "dwx_sampler_create", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
-    "dwx_wait", "dwx_sgd_plan", "dwx_sgd_get_chunks", "dwx_sgd_accumulate_async",
+    "dwx_wait", "dwx_sgd_plan", "dwx_sgd_plan_rows", "dwx_sgd_get_chunks", "dwx_sgd_accumulate_async",
     "dwx_sgd_apply_async", "dwx_sgd_finish",
     "dwx_get_weights", "dwx_set_weights", "dwx_average_weights_async",
     "dwx_clear_tallies", "dwx_get_tallies",
@@ -90,6 +90,7 @@ class Library:
         L.dwx_sample_sgd_async.argtypes = [vp, dbl]
         L.dwx_wait.argtypes = [vp]
         L.dwx_sgd_plan.argtypes = [vp, dbl, C.c_uint32, vp, vp, vp]
+        L.dwx_sgd_plan_rows.argtypes = [vp, C.c_uint32]
         L.dwx_sgd_get_chunks.argtypes = [vp, vp]
         L.dwx_sgd_accumulate_async.argtypes = [vp, C.c_uint32]
         L.dwx_sgd_apply_async.argtypes = [vp]
@@ -228,6 +229,9 @@ class GibbsSampler:
         self.lib.check(self.lib.L.dwx_sgd_plan(self.h, stepsize, force_batches, C.byref(b), C.byref(n),
                                                C.byref(e)))
         return b.value, n.value, e.value
+
+    def sgd_plan_rows(self, n_rows):
+        self.lib.check(self.lib.L.dwx_sgd_plan_rows(self.h, int(n_rows)))
 
     def sgd_chunks(self, n_chunks):
         off = np.zeros(n_chunks + 1, np.uint64)

@@ -51,6 +51,23 @@ def main():
     ev[pos] = 1 - ev[pos]                       # write through the view = what a halo scatter does
     torch.cuda.synchronize()
     assert np.array_equal(a.assignments("evid")[:10], 1 - b.assignments("evid")[:10])
+    # split learning sweeps through the collective path: per-chunk static counts are sized and
+    # "summed" (world size 1) once per batch count, every chunk is accumulate -> all-reduce ->
+    # apply; must equal the library's own split sweep
+    e2, f2 = dwx.GibbsSampler(g, seed=41), dwx.GibbsSampler(g, seed=41)
+    eng2 = HipEngine(e2)
+    drv2 = ShardedDimmWitted(eng2, 3, 0, 0.4, 0.9)
+    drv2.distributed = True
+    eng2.allreduce_static_counts()
+    assert e2.sgd_plan(0.4)[0] > 1 and e2.sgd_plan(0.4 * 0.81)[0] > 1
+    drv2.learn()
+    assert eng2._shared_levels and not eng2._dynamic_counts
+    cur = 0.4
+    for _ in range(3):
+        f2.sample_sgd(cur); cur *= 0.9
+    f2.wait()
+    assert np.array_equal(e2.weights, f2.weights) and np.abs(e2.weights).max() > 0
+    assert np.array_equal(e2.assignments("free"), f2.assignments("free"))
     # replica mode at world size 1: the f64 weight all-reduce and the int32 tally all-reduce
     # run on the sampler's stream over the raw device buffers; averaging over 1 replica
     # must leave the state of a plain sampler

@@ -213,3 +213,29 @@ def test_replica_weight_averaging(lib):
     a.wait(); b.wait()
     assert np.array_equal(a.assignments("evid"), b.assignments("evid"))
     assert np.array_equal(a.tallies()[0], b.tallies()[0])
+
+
+def test_split_sweep_with_pull_tiles_and_static_counts(lib):
+    """Split learning sweeps on graphs whose tiles use the pull-based gradient (W > 1024):
+    every chunk pulls its own part of the (chunk, weight)-sorted incidence list and applies
+    with its own row of static update counts -- same result as the oracle following the
+    same chunks.  Also a two-colour graph (pairwise factors), categorical variables (their
+    counts stay dynamic), learn_non_evidence, and a plan with more chunks than the table
+    limit (atomics fallback)."""
+    from sampler_amd import dwx
+    from randgraph import random_graph
+    raw = synthetic.cfg3(8000, n_weights=1300, seed=7)
+    g = dwx.Graph(raw, lib=lib, tile_vars=64)
+    s = dwx.GibbsSampler(g, seed=3)
+    assert 2 <= s.sgd_plan(0.05)[0] <= 64                   # split, with per-chunk tables
+    run_parity(lib, raw, n_learn=4, n_infer=2, stepsize=0.05, compile_opts=dict(tile_vars=64))
+    run_parity(lib, raw, n_learn=3, n_infer=1, stepsize=0.08, learn_non_evidence=True,
+               compile_opts=dict(tile_vars=64))
+    run_parity(lib, synthetic.cfg3b(4000, n_weights=1400, seed=15), n_learn=4, n_infer=2, stepsize=0.05,
+               compile_opts=dict(tile_vars=64))
+    run_parity(lib, random_graph(8, V=1500, F=9000, W=1300, p_cat=0.3), n_learn=4, n_infer=2, stepsize=0.2,
+               learn_non_evidence=True, compile_opts=dict(tile_vars=32))
+    # > 64 chunks: no tables, per-record atomics and dynamic counts
+    s2 = dwx.GibbsSampler(dwx.Graph(raw, lib=lib, tile_vars=16), seed=3)
+    assert s2.sgd_plan(5.0)[1] > 64
+    run_parity(lib, raw, n_learn=2, n_infer=1, stepsize=5.0, compile_opts=dict(tile_vars=16))
