@@ -130,6 +130,10 @@ def main():
     if use_dist and not drv.distributed:      # forced self-check at world size 1
         drv.distributed = True
         engine.allreduce_static_counts()
+    if os.environ.get("DWX_BENCH_PLAN_WORLD"):
+        # experiment: one rank of an N-GPU run (its mini-batch plan and collectives, minus the
+        # xGMI time): plan as if N equal shards contributed to every weight
+        drv.plan_world = int(os.environ["DWX_BENCH_PLAN_WORLD"])
 
     def step(cur):
         drv.learn_epoch(cur)      # sample_sgd (+ RCCL all-reduce of the gradient vector)

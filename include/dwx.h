@@ -176,6 +176,10 @@ int dwx_wait(dwx_sampler *s);
  *   + dwx_sgd_apply_async where due];  dwx_sgd_finish. */
 int dwx_sgd_plan(dwx_sampler *s, double stepsize, uint32_t force_batches, uint32_t *batches,
                  uint32_t *n_chunks, double *effective_stepsize);
+/* The curvature estimate R(batches) dwx_sgd_plan works with (cached per batch count).  A
+ * multi-GPU driver takes the maximum over ranks once per batch count and can then derive
+ * the common plan for any step size without a per-sweep agreement round. */
+int dwx_sgd_curvature(dwx_sampler *s, uint32_t batches, double *lambda);
 /* Multi-GPU only: make the current split plan's static-count table n_rows tall (rows
  * beyond this rank's own chunks are zero), so that all ranks can sum equally sized tables
  * and every rank can apply the update of a chunk it idles through. */

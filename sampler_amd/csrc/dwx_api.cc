@@ -879,6 +879,12 @@ int dwx_sgd_plan(dwx_sampler *s, double stepsize, uint32_t force_batches, uint32
   });
 }
 
+int dwx_sgd_curvature(dwx_sampler *s, uint32_t batches, double *lambda) {
+  if (!s || !lambda) return fail(DWX_E_INVALID, "null argument");
+  if (batches == 0) return fail(DWX_E_INVALID, "batches must be >= 1");
+  return guarded([&]() { *lambda = row_sum_bound(s, batches); });
+}
+
 int dwx_sgd_plan_rows(dwx_sampler *s, uint32_t n_rows) {
   if (!s) return fail(DWX_E_INVALID, "null sampler");
   if (!s->plan_valid || !s->plan_level) return fail(DWX_E_INVALID, "no plan: call dwx_sgd_plan first");

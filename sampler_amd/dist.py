@@ -65,6 +65,17 @@ class HipEngine:
         self._dynamic_counts = batches > 1 and self.s.device_buffer(dwx.BUF_TSTATIC_PLAN)[1] == 0
         return batches, n_chunks, eta
 
+    @property
+    def step_cap(self):
+        return self.s.opts.step_cap
+
+    @property
+    def max_batches(self):
+        return int(self.s.graph.info.num_tiles)
+
+    def curvature(self, batches):
+        return self.s.sgd_curvature(batches)
+
     def share_plan_static_counts(self, n_chunks_all, group=None):
         """Once per batch count of a split plan: size the per-chunk static-count table for the
         slowest rank's chunk count and sum it across shards (each rank counted its own block)."""
@@ -207,6 +218,7 @@ class HaloExchange:
 class ShardedDimmWitted:
     """Epoch driver over variable-block shards (DimmWitted::learn / inference,
     src/dimmwitted.cc:121-207, with the replica loop replaced by ranks)."""
+    MAX_BATCHES = 1 << 20          # the library clamps to its tile count
 
     def __init__(self, engine, n_learning_epoch, n_inference_epoch, stepsize=0.01, decay=0.95,
                  group=None, halo=None):
@@ -217,8 +229,10 @@ class ShardedDimmWitted:
         self.decay = decay
         self.group = group
         self.halo = halo          # HaloExchange or None (no cross-shard factors)
-        self._unsplit_upto = None  # largest step all ranks agreed to run as one batch ...
-        self._unsplit_chunks = 1   # ... and the (step-independent) launch count of that plan
+        self._lam = {}             # batches -> global curvature (agreed once)
+        self._max_batches = None   # agreed upper end of the batch-count search
+        self.plan_world = None     # experiments: plan as if this many equal shards took part
+        self._level_chunks = {}    # batches -> chunk count of the slowest rank (agreed once)
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         if self.distributed:
             self.e.allreduce_static_counts(group)
@@ -229,16 +243,7 @@ class ShardedDimmWitted:
         """One learning sweep: plan the mini-batches (every rank must cut its block into the
         same number of pieces, because every piece ends in a collective), then per chunk
         accumulate -> all-reduce -> apply (un-split sweeps apply once, after the last chunk)."""
-        world = dist.get_world_size(self.group) if self.distributed else 1
-        if self.distributed and self._unsplit_upto is not None and stepsize <= self._unsplit_upto:
-            # the batch count is monotone in the step: once every rank agreed on an un-split
-            # sweep at some step, smaller steps need no agreement round (and no host sync)
-            batches, n_chunks = 1, self._unsplit_chunks
-            self.e.sgd_plan(stepsize, 1)
-        else:
-            batches, n_chunks = self._agree_plan(stepsize, world)
-            if self.distributed and batches == 1:
-                self._unsplit_upto, self._unsplit_chunks = stepsize, n_chunks
+        batches, n_chunks, eta = self._plan(stepsize)
         for c in range(n_chunks):
             self.e.sgd_accumulate(c)          # ranks with fewer chunks idle through the rest
             if batches > 1 or c + 1 == n_chunks:
@@ -249,23 +254,62 @@ class ShardedDimmWitted:
         if self.halo is not None:
             self.halo.exchange(("free", "evid"))
 
-    def _agree_plan(self, stepsize, world):
-        # a weight's row sum adds up over shards: plan for the whole graph's step
-        batches, n_chunks, _ = self.e.sgd_plan(stepsize * world)
-        if self.distributed:
-            t = torch.tensor([batches, n_chunks], dtype=torch.int64, device=self.e.grad.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            batches, n_chunks_all = int(t[0]), int(t[1])
-            # re-plan with the agreed batch count and this rank's true step
-            _, n_mine, _ = self.e.sgd_plan(stepsize, batches)
-            t = torch.tensor([n_mine], dtype=torch.int64, device=self.e.grad.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            n_chunks = int(t[0])
-            if batches > 1 and hasattr(self.e, "share_plan_static_counts"):
-                self.e.share_plan_static_counts(n_chunks, self.group)
-        else:
-            _, n_chunks, _ = self.e.sgd_plan(stepsize, batches)
-        return batches, n_chunks
+    def _global_curvature(self, batches, world):
+        """world x max over ranks of the library's curvature estimate for `batches` pieces per
+        launch: a weight's curvature adds up over shards.  One MAX all-reduce per batch count,
+        ever (the estimate does not depend on the step)."""
+        if batches not in self._lam:
+            lam = float(self.e.curvature(batches))
+            if self.distributed:
+                t = torch.tensor([lam], dtype=torch.float64, device=self.e.grad.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                lam = float(t[0])
+            self._lam[batches] = world * lam
+        return self._lam[batches]
+
+    def _batch_limit(self):
+        """No rank can cut finer than its tile count: the search for a batch count ends at the
+        largest tile count of any rank (agreed once, so that every rank ends at the same one)."""
+        if self._max_batches is None:
+            n = int(getattr(self.e, "max_batches", self.MAX_BATCHES))
+            if self.distributed:
+                t = torch.tensor([n], dtype=torch.int64, device=self.e.grad.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                n = int(t[0])
+            self._max_batches = max(1, n)
+        return self._max_batches
+
+    def _plan(self, stepsize):
+        """The rule of dwx_sgd_plan (include/dwx.h) on the GLOBAL curvature, evaluated
+        identically on every rank from cached numbers: after the first sweep at a given batch
+        count there is no agreement round and no host synchronisation per sweep."""
+        world = dist.get_world_size(self.group) if self.distributed else 1
+        world = self.plan_world or world
+        cap = float(self.e.step_cap)
+        batches, eta = 1, stepsize
+        if cap > 0 and stepsize > 0:
+            need = stepsize * self._global_curvature(1, world) / cap
+            limit = self._batch_limit()
+            while batches < need and batches < limit:
+                batches *= 2
+            while batches < limit and stepsize * self._global_curvature(batches, world) > cap:
+                batches *= 2
+            lam = self._global_curvature(batches, world)
+            if stepsize * lam > cap:
+                eta = cap / lam            # even the finest cut is too coarse: shrink the step
+        # this rank's plan with the common batch count; its own step bound cannot bind
+        # (local curvature <= global / world), so every rank applies the same eta
+        _, n_mine, eta_local = self.e.sgd_plan(eta, batches)
+        if batches not in self._level_chunks:
+            n_all = n_mine
+            if self.distributed:
+                t = torch.tensor([n_mine], dtype=torch.int64, device=self.e.grad.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                n_all = int(t[0])
+            self._level_chunks[batches] = n_all
+            if self.distributed and batches > 1 and hasattr(self.e, "share_plan_static_counts"):
+                self.e.share_plan_static_counts(n_all, self.group)
+        return batches, self._level_chunks[batches], eta
 
     def learn(self):
         cur = self.stepsize

@@ -24,7 +24,7 @@ SYMBOLS = [
     "dwx_graph_create", "dwx_graph_destroy", "dwx_graph_get_info", "dwx_graph_get_schedule",
     "dwx_graph_get_values", "dwx_graph_get_positions", "dwx_graph_get_index",
     "dwx_sampler_create", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
-    "dwx_wait", "dwx_sgd_plan", "dwx_sgd_plan_rows", "dwx_sgd_get_chunks", "dwx_sgd_accumulate_async",
+    "dwx_wait", "dwx_sgd_plan", "dwx_sgd_curvature", "dwx_sgd_plan_rows", "dwx_sgd_get_chunks", "dwx_sgd_accumulate_async",
     "dwx_sgd_apply_async", "dwx_sgd_finish",
     "dwx_get_weights", "dwx_set_weights", "dwx_average_weights_async",
     "dwx_clear_tallies", "dwx_get_tallies",
@@ -91,6 +91,7 @@ class Library:
         L.dwx_wait.argtypes = [vp]
         L.dwx_sgd_plan.argtypes = [vp, dbl, C.c_uint32, vp, vp, vp]
         L.dwx_sgd_plan_rows.argtypes = [vp, C.c_uint32]
+        L.dwx_sgd_curvature.argtypes = [vp, C.c_uint32, vp]
         L.dwx_sgd_get_chunks.argtypes = [vp, vp]
         L.dwx_sgd_accumulate_async.argtypes = [vp, C.c_uint32]
         L.dwx_sgd_apply_async.argtypes = [vp]
@@ -229,6 +230,11 @@ class GibbsSampler:
         self.lib.check(self.lib.L.dwx_sgd_plan(self.h, stepsize, force_batches, C.byref(b), C.byref(n),
                                                C.byref(e)))
         return b.value, n.value, e.value
+
+    def sgd_curvature(self, batches):
+        out = C.c_double()
+        self.lib.check(self.lib.L.dwx_sgd_curvature(self.h, int(batches), C.byref(out)))
+        return out.value
 
     def sgd_plan_rows(self, n_rows):
         self.lib.check(self.lib.L.dwx_sgd_plan_rows(self.h, int(n_rows)))

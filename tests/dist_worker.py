@@ -26,6 +26,12 @@ class OracleEngine:
         self.split_above, self.max_chunks = split_above, max_chunks
         self.n_chunks = 1
         self.plans = []
+        self.curv_calls = 0
+        # what the library would report (a stand-in): one batch is fine up to the threshold
+        # step, two batches are no better than one (query half / evidence half), four cut the
+        # curvature by four
+        self.step_cap = 1.5 if split_above is not None else 0.0
+        self.max_batches = 4
         self.o = orc.Oracle(raw, reg_param=reg_param)
         self.o.set_var_id_offset(var_id_offset)
         self.order = np.arange(raw.num_variables, dtype=np.uint64)
@@ -35,12 +41,17 @@ class OracleEngine:
         self.grad = torch.from_numpy(self.o.grad)      # int64 view of [G | T]
         self.static_reduced = False
 
+    def curvature(self, batches):
+        self.curv_calls += 1
+        lam1 = self.step_cap / self.split_above
+        return {1: lam1, 2: lam1}.get(batches, lam1 / batches)
+
     def allreduce_static_counts(self, group=None):
         self.static_reduced = True                     # the oracle counts T dynamically
 
     def sgd_plan(self, stepsize, force_batches=0):
         self.eta = stepsize          # the driver's last call carries this rank's true step
-        batches = force_batches or (4 if self.split_above is not None and stepsize > self.split_above else 1)
+        batches = force_batches or 1     # the driver plans (ShardedDimmWitted._plan) and forces
         self.n_chunks = min(batches, self.max_chunks)
         self.plans.append((stepsize, force_batches, batches))
         return batches, self.n_chunks, stepsize
@@ -93,7 +104,7 @@ def main():
     drv.inference()
     np.savez(os.path.join(out, "rank%d.npz" % rank), weights=eng.o.weights, tallies=eng.o.tallies,
              free=eng.o.assignments("free"), evid=eng.o.assignments("evid"), begin=begin,
-             plans=np.array(eng.plans, np.float64))
+             plans=np.array(eng.plans, np.float64), curv_calls=eng.curv_calls)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -56,13 +56,13 @@ def main():
     # apply; must equal the library's own split sweep
     e2, f2 = dwx.GibbsSampler(g, seed=41), dwx.GibbsSampler(g, seed=41)
     eng2 = HipEngine(e2)
-    drv2 = ShardedDimmWitted(eng2, 3, 0, 0.4, 0.9)
+    drv2 = ShardedDimmWitted(eng2, 3, 0, 0.01, 0.9)
     drv2.distributed = True
     eng2.allreduce_static_counts()
-    assert e2.sgd_plan(0.4)[0] > 1 and e2.sgd_plan(0.4 * 0.81)[0] > 1
+    assert 1 < e2.sgd_plan(0.01)[0] <= 64 and e2.sgd_plan(0.01 * 0.81)[0] > 1
     drv2.learn()
     assert eng2._shared_levels and not eng2._dynamic_counts
-    cur = 0.4
+    cur = 0.01
     for _ in range(3):
         f2.sample_sgd(cur); cur *= 0.9
     f2.wait()

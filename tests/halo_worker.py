@@ -42,6 +42,8 @@ class OracleShardEngine:
     def _prep(self):
         self.o.set_var_id_offset(self.begin)
 
+    step_cap = 0.0          # no mini-batch plan: one batch per sweep
+
     def allreduce_static_counts(self, group=None):
         pass
 

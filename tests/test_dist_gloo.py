@@ -143,9 +143,11 @@ def test_two_rank_split_sweeps_agree_on_the_plan_and_match_single_process():
         b = int(res[r]["begin"]); n = len(res[r]["free"])
         assert np.array_equal(res[r]["free"], o.assignments("free")[b:b + n])
         assert np.array_equal(res[r]["evid"], o.assignments("evid")[b:b + n])
-    # negotiation stops once an un-split plan was agreed: the last sweep only re-plans locally
+    # the ranks negotiate per batch COUNT (curvature of 1, 2 and 4 batches: three rounds for
+    # six sweeps), never per sweep, and every sweep is planned with the agreed count
     plans = res[0]["plans"]
-    assert plans[-1][1] == 1 and plans[-2][1] == 1 and plans[0][1] == 0
+    assert int(res[0]["curv_calls"]) == 3 and len(plans) == 6
+    assert [int(p[1]) for p in plans] == [4] * n_split + [1] * (6 - n_split)
 
 
 def test_two_rank_replicas_average_weights_like_n_datacopy():
