@@ -89,6 +89,13 @@ def main():
     ap.add_argument("--tile-edges", type=int, default=0, help="graph-compile knob (experiments)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line.  Libraries that print to the process's stdout
+    # (RCCL's version banner: NCCL_DEBUG=VERSION is exported on the GPU boxes) are sent to
+    # stderr: descriptor 1 becomes a copy of descriptor 2, the result goes to the saved one.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from sampler_amd import dwx, synthetic
@@ -223,7 +230,7 @@ def main():
             except Exception as e:  # the baseline must never lose the GPU measurement
                 out["cpu_baseline"] = {"value": None, "unit": "variables/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     sampler.close()
     if use_dist:
         dist.destroy_process_group()

@@ -529,6 +529,16 @@ void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
   }
   s->plan_batches = B;
   s->plan_eta = eta;
+  if (B > 1 && !s->levels.count(B)) {
+    // The step decays from sweep to sweep, so a run that starts at B batches will walk down
+    // through B/2, B/4, ...: prepare those levels (curvature estimate, tables) together with
+    // the first one, so that the one-off host work lands in the first learning sweep instead
+    // of interrupting later ones.
+    for (uint32_t b = B / 2; b >= 2; b /= 2) {
+      if (cap > 0) (void)row_sum_bound(s, b);
+      (void)build_level(s, b);
+    }
+  }
   s->plan_level = build_level(s, B);
   s->plan_chunks = s->plan_level->chunks;
   s->cur_chunk = 0;

@@ -299,16 +299,27 @@ class ShardedDimmWitted:
                 eta = cap / lam            # even the finest cut is too coarse: shrink the step
         # this rank's plan with the common batch count; its own step bound cannot bind
         # (local curvature <= global / world), so every rank applies the same eta
-        _, n_mine, eta_local = self.e.sgd_plan(eta, batches)
         if batches not in self._level_chunks:
-            n_all = n_mine
-            if self.distributed:
-                t = torch.tensor([n_mine], dtype=torch.int64, device=self.e.grad.device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-                n_all = int(t[0])
-            self._level_chunks[batches] = n_all
-            if self.distributed and batches > 1 and hasattr(self.e, "share_plan_static_counts"):
-                self.e.share_plan_static_counts(n_all, self.group)
+            # first use of this batch count: agree on the slowest rank's chunk count and share
+            # the static-count tables -- for this level AND the coarser ones the decaying step
+            # will walk down through, so that all one-off work (host-side table builds, these
+            # collectives) lands in the first learning sweep
+            b = batches
+            while b >= 1:
+                if b not in self._level_chunks:
+                    if b > 1 and cap > 0:
+                        self._global_curvature(b, world)
+                    _, n_mine, _ = self.e.sgd_plan(eta, b)
+                    n_all = n_mine
+                    if self.distributed:
+                        t = torch.tensor([n_mine], dtype=torch.int64, device=self.e.grad.device)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                        n_all = int(t[0])
+                    self._level_chunks[b] = n_all
+                    if self.distributed and b > 1 and hasattr(self.e, "share_plan_static_counts"):
+                        self.e.share_plan_static_counts(n_all, self.group)
+                b //= 2
+        self.e.sgd_plan(eta, batches)
         return batches, self._level_chunks[batches], eta
 
     def learn(self):

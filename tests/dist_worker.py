@@ -53,7 +53,7 @@ class OracleEngine:
         self.eta = stepsize          # the driver's last call carries this rank's true step
         batches = force_batches or 1     # the driver plans (ShardedDimmWitted._plan) and forces
         self.n_chunks = min(batches, self.max_chunks)
-        self.plans.append((stepsize, force_batches, batches))
+        self.cur_batches = batches
         return batches, self.n_chunks, stepsize
 
     def chunk_vars(self, chunk, n_chunks=None):
@@ -67,6 +67,7 @@ class OracleEngine:
         self.o.sched_accumulate(sl, np.array([0, len(sl)], np.uint64), self.seed, self.sweep)
 
     def sgd_finish(self):
+        self.plans.append((self.eta, self.cur_batches))    # the plan this sweep ran with
         self.sweep += 1
 
     def allreduce_grad(self, group=None):

@@ -144,7 +144,7 @@ def test_two_rank_split_sweeps_agree_on_the_plan_and_match_single_process():
         assert np.array_equal(res[r]["free"], o.assignments("free")[b:b + n])
         assert np.array_equal(res[r]["evid"], o.assignments("evid")[b:b + n])
     # the ranks negotiate per batch COUNT (curvature of 1, 2 and 4 batches: three rounds for
-    # six sweeps), never per sweep, and every sweep is planned with the agreed count
+    # six sweeps), never per sweep, and every sweep runs with the agreed count
     plans = res[0]["plans"]
     assert int(res[0]["curv_calls"]) == 3 and len(plans) == 6
     assert [int(p[1]) for p in plans] == [4] * n_split + [1] * (6 - n_split)
