@@ -166,8 +166,9 @@ int dwx_wait(dwx_sampler *s);
  * into `batches` runs of tiles carrying equal SGD work, batches = the first power of two
  * >= stepsize * R(1) / step_cap with stepsize * R(batches) <= step_cap, i.e. as many
  * pieces as keep one batched step inside the region where it tracks the sequential
- * updates (1 for configs 2-5 of BASELINE.json at their quoted step; dozens for heavily
- * tied weights with a large step).  force_batches != 0 overrides (all ranks of a multi-GPU
+ * updates (1 for configs 2-3 of BASELINE.json at their quoted step; dozens for heavily
+ * tied weights with a large step; never more than 64 -- beyond that the step is shortened,
+ * see effective_stepsize).  force_batches != 0 overrides (all ranks of a multi-GPU
  * run must use the same value).  A plan is a list of chunks (consecutive device-order runs
  * of variables, never crossing a colour; n_chunks <= batches * colours -- tiles that learn
  * nothing ride along with a neighbour); with batches == 1 the update is applied once after

@@ -270,7 +270,9 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
   const uint32_t nc = (uint32_t)L->chunks.size();
   // beyond this the per-chunk tables cost more than they save: such plans keep the
   // per-record atomics and dynamic counts
-  L->fast = nc >= 1 && nc <= 64 && (uint64_t)nc * c.W * 8 <= ((uint64_t)2 << 30);
+  uint32_t table_chunks = 4 * MAX_PLAN_BATCHES;
+  if (const char *e = getenv("DWX_PLAN_TABLE_CHUNKS")) table_chunks = (uint32_t)std::max(1L, atol(e));   // test hook
+  L->fast = nc >= 1 && nc <= table_chunks && (uint64_t)nc * c.W * 8 <= ((uint64_t)2 << 30);
   if (batches == 1) L->fast = true;
   if (L->fast && c.W) {
     // groups of the tables: the chunks of a split sweep (an update follows each of them); ONE
@@ -510,6 +512,12 @@ void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
   uint32_t max_tiles = 1;
   for (size_t l = 0; l + 1 < c.launch_off.size(); ++l)
     max_tiles = std::max(max_tiles, c.launch_tile[l + 1] - c.launch_tile[l]);
+  // No plan cuts finer than MAX_PLAN_BATCHES: beyond that the step is shortened instead.  The
+  // iteration then runs at the edge of its stability region -- near-Newton steps along the
+  // stiffest direction -- and still reaches the optimum the sequential updates reach (a
+  // handful of weights tied to millions of factors would otherwise turn every sweep into
+  // thousands of one-tile launches).
+  max_tiles = std::min(max_tiles, MAX_PLAN_BATCHES);
   const double cap = s->opts.step_cap;
   uint32_t B = 1;
   double eta = stepsize;

@@ -218,7 +218,7 @@ class HaloExchange:
 class ShardedDimmWitted:
     """Epoch driver over variable-block shards (DimmWitted::learn / inference,
     src/dimmwitted.cc:121-207, with the replica loop replaced by ranks)."""
-    MAX_BATCHES = 1 << 20          # the library clamps to its tile count
+    MAX_BATCHES = 64               # = MAX_PLAN_BATCHES of the library (device_types.h)
 
     def __init__(self, engine, n_learning_epoch, n_inference_epoch, stepsize=0.01, decay=0.95,
                  group=None, halo=None):
@@ -276,7 +276,7 @@ class ShardedDimmWitted:
                 t = torch.tensor([n], dtype=torch.int64, device=self.e.grad.device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
                 n = int(t[0])
-            self._max_batches = max(1, n)
+            self._max_batches = max(1, min(n, self.MAX_BATCHES))
         return self._max_batches
 
     def _plan(self, stepsize):

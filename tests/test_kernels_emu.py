@@ -215,7 +215,7 @@ def test_replica_weight_averaging(lib):
     assert np.array_equal(a.tallies()[0], b.tallies()[0])
 
 
-def test_split_sweep_with_pull_tiles_and_static_counts(lib):
+def test_split_sweep_with_pull_tiles_and_static_counts(lib, monkeypatch):
     """Split learning sweeps on graphs whose tiles use the pull-based gradient (W > 1024):
     every chunk pulls its own part of the (chunk, weight)-sorted incidence list and applies
     with its own row of static update counts -- same result as the oracle following the
@@ -235,7 +235,11 @@ def test_split_sweep_with_pull_tiles_and_static_counts(lib):
                compile_opts=dict(tile_vars=64))
     run_parity(lib, random_graph(8, V=1500, F=9000, W=1300, p_cat=0.3), n_learn=4, n_infer=2, stepsize=0.2,
                learn_non_evidence=True, compile_opts=dict(tile_vars=32))
-    # > 64 chunks: no tables, per-record atomics and dynamic counts
+    # never more than 64 batches per launch: beyond that the step is shortened
     s2 = dwx.GibbsSampler(dwx.Graph(raw, lib=lib, tile_vars=16), seed=3)
-    assert s2.sgd_plan(5.0)[1] > 64
+    b2, n2, eta2 = s2.sgd_plan(5.0)
+    assert b2 == 64 and n2 <= 64 and eta2 < 5.0
     run_parity(lib, raw, n_learn=2, n_infer=1, stepsize=5.0, compile_opts=dict(tile_vars=16))
+    # plans too large for the per-chunk tables: per-record atomics and dynamic counts
+    monkeypatch.setenv("DWX_PLAN_TABLE_CHUNKS", "4")
+    run_parity(lib, raw, n_learn=3, n_infer=1, stepsize=0.05, compile_opts=dict(tile_vars=64))
