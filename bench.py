@@ -166,6 +166,18 @@ def main():
     ms_i, nl_i, ns_i = sampler.kernel_time("infer")
     ms_l, nl_l, ns_l = sampler.kernel_time("learn")
     ms_p, nl_p, ns_p = sampler.kernel_time("pull")
+    # outside the timed region: inference sweeps that FOLLOW EACH OTHER on unchanged weights
+    # (what `dw gibbs -i N` runs) stream tabulated potential terms instead of gathering
+    # weights; the step above alternates learning and inference and never gets there
+    sampler.kernel_time_reset(True)
+    for _ in range(6):
+        engine.sample()
+    engine.wait()
+    sampler.kernel_time_reset(True)
+    for _ in range(10):
+        engine.sample()
+    engine.wait()
+    ms_r, nl_r, ns_r = sampler.kernel_time("infer")
     sampler.kernel_time_reset(False)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -223,6 +235,8 @@ def main():
             "learn_vars_per_sec": V * n_gpus / (ms_l / max(ns_l, 1) * 1e-3) if ns_l else None,
             "infer_kernel_ms": ms_i / max(nl_i, 1), "learn_kernel_ms": ms_l / max(nl_l, 1),
             "pull_grad_kernel_ms": (ms_p / nl_p) if nl_p else None,
+            "infer_repeat_kernel_ms": (ms_r / nl_r) if nl_r else None,
+            "infer_repeat_vars_per_sec": V * n_gpus / (ms_r / max(ns_r, 1) * 1e-3) if ns_r else None,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:

@@ -117,6 +117,8 @@ struct KernelParams {
   const uint32_t *row_ptr;    // [R+1] edge-record offsets
   const double *row_truth;    // [R] truthiness per value row, or null
   const EdgeRec *edges;       // [NIdx]
+  const void *edge_terms;     // [NIdx] 16-byte {w*sign(hit)*f, w*sign(miss)*f} (f64) of the pre-signed
+                              // records under the CURRENT weights, or null (inference sweeps only)
   const double *edge_fval64;  // [NIdx] or null
   const VifRec *vifs;         // [NVif]
   const TileDesc *tiles;      // [n_tiles]

@@ -111,6 +111,10 @@ struct dwx_sampler {
   double *d_weights = nullptr;
   float *d_w32 = nullptr;
   double *d_w_init = nullptr;   // initial weights, uploaded on the first replica averaging
+  // tabulated potential terms of the pre-signed records (inference with unchanged weights)
+  EdgeTerms *d_terms = nullptr;
+  int terms_state = 0;          // 0 weights changed since / 1 one inference sweep ran on them / 2 table valid
+  bool has_simple_tiles = false;
   // pull-based gradient (TILE_PULL tiles)
   unsigned long long *d_delta = nullptr;
   // One incidence list + static update counts per plan level (number of batches): sorted by
@@ -147,7 +151,7 @@ struct dwx_sampler {
     rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
     rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
     rt::dfree(d_edges); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
-    rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_delta);
+    rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_terms); rt::dfree(d_delta);
     rt::dfree(d_w_fixed); rt::dfree(d_grad);
     if (stream) rt::stream_destroy(stream);
   }
@@ -197,6 +201,19 @@ void enqueue_inference(dwx_sampler *s) {
   rt::set_device(s->device);
   KernelParams P = s->base;
   P.sweep = s->sweep;
+  // The second consecutive inference sweep on the same weights tabulates the pre-signed
+  // records' potential terms (one extra pass, about the cost of a sweep); from then on
+  // sweeps stream the table and gather no weights.  (Not on the first one: learning and
+  // inference sweeps may alternate, and then the table would be rebuilt for a single use.)
+  if (s->has_simple_tiles && s->terms_state == 1 && c.NIdx) {
+    if (!s->d_terms) s->d_terms = (EdgeTerms *)rt::dmalloc(c.NIdx * sizeof(EdgeTerms));
+    const unsigned grid = std::min<unsigned>((unsigned)((c.NIdx + BLOCK_THREADS - 1) / BLOCK_THREADS), 256u * 32u);
+    rt::launch(build_terms_kernel, grid, BLOCK_THREADS, 0, s->stream, (const EdgeRec *)s->d_edges,
+               (const float *)s->d_w32, s->d_terms, (uint32_t)c.NIdx);
+    s->terms_state = 2;
+  }
+  P.edge_terms = s->terms_state == 2 ? s->d_terms : nullptr;
+  if (s->terms_state == 0) s->terms_state = 1;
   TimedSpan sp{};
   if (s->timing) {
     sp.a = rt::event_create(); sp.b = rt::event_create(); sp.c = rt::event_create(); sp.kind = 0;
@@ -597,6 +614,7 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
 
 void enqueue_apply(dwx_sampler *s) {
   rt::set_device(s->device);
+  s->terms_state = 0;   // the weights change
   const uint32_t W = (uint32_t)s->cg->W;
   if (!W) return;
   const unsigned grid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 2048u);
@@ -778,7 +796,8 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
 
     KernelParams &P = s->base;
     P.v_meta = s->d_v_meta; P.v_orig = s->d_v_orig; P.v_row = s->d_v_row; P.v_init = s->d_v_init;
-    P.row_ptr = s->d_row_ptr; P.row_truth = s->d_row_truth; P.edges = s->d_edges;
+    P.row_ptr = s->d_row_ptr; P.row_truth = s->d_row_truth; P.edges = s->d_edges; P.edge_terms = nullptr;
+    for (const TileDesc &td : c.tiles) if (td.flags & TILE_SIMPLE) { s->has_simple_tiles = true; break; }
     P.edge_fval64 = s->d_edge_fval64; P.vifs = s->d_vifs; P.tiles = s->d_tiles;
     P.assign_free = s->d_assign_free; P.assign_evid = s->d_assign_evid; P.tally = s->d_tally;
     P.w32 = s->d_w32; P.grad = s->d_grad; P.delta = s->d_delta;
@@ -990,6 +1009,7 @@ int dwx_set_weights(dwx_sampler *s, const double *in) {
   return guarded([&]() {
     rt::set_device(s->device);
     const uint32_t W = (uint32_t)s->cg->W;
+    s->terms_state = 0;
     rt::h2d(s->d_weights, in, (size_t)W * 8, s->stream);
     if (W) {
       const unsigned grid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 2048u);
@@ -1007,6 +1027,7 @@ int dwx_average_weights_async(dwx_sampler *s, uint32_t n_replicas) {
     rt::set_device(s->device);
     const uint32_t W = (uint32_t)s->cg->W;
     if (!W) return;
+    s->terms_state = 0;
     if (!s->d_w_init) {
       s->d_w_init = upload(s->cg->w_init, s->stream);
       rt::stream_sync(s->stream);

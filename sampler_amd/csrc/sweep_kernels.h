@@ -648,7 +648,10 @@ DWX_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 template <bool LEARN, int K>
 DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t t,
                               TilePrefetch<K> &f) {
-  DWX_LOAD_TILE_RECORDS(K, P.edges + d.e0, d.nedges, t, f.rec);
+  // inference over an all-unary tile whose potential terms are already tabulated
+  // (edge_terms, same 16-byte stride): stream those instead of the records
+  const EdgeRec *stream = (!LEARN && P.edge_terms && (d.flags & TILE_SIMPLE)) ? (const EdgeRec *)P.edge_terms : P.edges;
+  DWX_LOAD_TILE_RECORDS(K, stream + d.e0, d.nedges, t, f.rec);
 #pragma unroll
   for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k)
     f.rp[k] = P.row_ptr[d.r0 + umin(t + k * BLOCK_THREADS, d.nrows)];
@@ -692,11 +695,18 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
     const bool fits = tile_fits(P, d);   // workgroup-uniform
     const VarPre pre = f.pre;
     double A = 0.0, B = 0.0;
+    // tabulated terms (see issue_tile_loads): nothing to gather, nothing to multiply
+    const bool tabulated = !LEARN && P.edge_terms && (d.flags & TILE_SIMPLE);   // workgroup-uniform
     if (fits) {
       // gather the f32 sampling weight of every record this lane staged ...
       float w[K];
+      if (!tabulated) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) w[k] = P.w32[f.rec[k].wid];
+        for (int k = 0; k < K; ++k) w[k] = P.w32[f.rec[k].wid];
+      } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) w[k] = 0.0f;
+      }
       // ... and draw this lane's uniforms while the gathers are in flight
       philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
       // unconditional LDS writes: slots past the tile's last record receive copies of
@@ -793,14 +803,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
         // t1 = w * (sign(hit) * f), t0 = w * (sign(miss) * f), the sign already folded
         // into the record by the host.  Same products as FactorGraph::potential.
         EdgeTerms *s_terms = (EdgeTerms *)s_edges;
+        if (tabulated) {
+          // the stream already holds these very products (build_terms_kernel): copy through
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const EdgeRec r = f.rec[k];
-          const double wv = (double)w[k];
-          EdgeTerms tt;
-          tt.t1 = wv * (double)r.fval;                 // proposal hits
-          tt.t0 = wv * (double)bits_to_float(r.aux);   // proposal misses
-          s_terms[t + k * BLOCK_THREADS] = tt;
+          for (int k = 0; k < K; ++k) s_edges[t + k * BLOCK_THREADS] = f.rec[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const EdgeRec r = f.rec[k];
+            const double wv = (double)w[k];
+            EdgeTerms tt;
+            tt.t1 = wv * (double)r.fval;                 // proposal hits
+            tt.t0 = wv * (double)bits_to_float(r.aux);   // proposal misses
+            s_terms[t + k * BLOCK_THREADS] = tt;
+          }
         }
       } else {
 #pragma unroll
@@ -1043,6 +1059,27 @@ apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *gra
     x -= stepsize * Gg;
     weights[i] = x;
     w32[i] = (float)x;
+  }
+}
+
+// Inference with unchanged weights repeats the same products sweep after sweep: tabulate
+// them once.  For every pre-signed (unary) record, exactly the two terms the staging pass of
+// sweep_kernel computes -- f64 products of two f32 values, exact -- in a stream with the
+// records' own 16-byte stride; other records get zeros (their tiles never read the table).
+// Inference sweeps then stream the table and touch no weight: the 50 M random L2 requests
+// per sweep that bound config 3's inference are gone.
+__global__ void __launch_bounds__(BLOCK_THREADS)
+build_terms_kernel(const EdgeRec *edges, const float *w32, EdgeTerms *terms, uint32_t n) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const EdgeRec r = edges[i];
+    EdgeTerms tt{0.0, 0.0};
+    if (r.packed & EDGE_PRESIGNED) {
+      const double wv = (double)w32[r.wid];
+      tt.t1 = wv * (double)r.fval;
+      tt.t0 = wv * (double)bits_to_float(r.aux);
+    }
+    terms[i] = tt;
   }
 }
 

@@ -33,13 +33,20 @@ def run(name, raw, n_learn, n_infer, stepsize=0.001, **kw):
     s.wait()
     ms_i, nl_i, ns_i = s.kernel_time("infer")
     ms_l, nl_l, ns_l = s.kernel_time("learn")
+    ms_p, nl_p, ns_p = s.kernel_time("pull")
+    # (kernel_time counts a learning sweep once per chunk of its plan: report per SWEEP; the
+    # figure includes the pull-gradient kernels, not apply_kernel)
+    ns_l = n_learn
+    ms_l = ms_l + ms_p
+    batches, n_chunks, eta = s.sgd_plan(stepsize) if n_learn else (None, None, None)
     V = raw.num_variables
     out = {"config": name, "V": V, "colors": int(g.info.num_colors), "tiles": int(g.info.num_tiles),
            "giant_tiles": int(g.info.num_giant_tiles), "records": int(g.info.num_index_entries),
            "setup_s": round(t_setup, 2),
            "infer_ms_per_sweep": ms_i / max(ns_i, 1), "infer_vars_per_s": V / (ms_i / max(ns_i, 1) * 1e-3) if ns_i else None,
            "learn_ms_per_sweep": ms_l / max(ns_l, 1) if ns_l else None,
-           "learn_vars_per_s": V / (ms_l / ns_l * 1e-3) if ns_l else None}
+           "learn_vars_per_s": V / (ms_l / ns_l * 1e-3) if ns_l else None,
+           "sgd_batches": batches, "sgd_chunks": n_chunks, "effective_stepsize": eta}
     print(json.dumps(out), flush=True)
     s.close()
 
