@@ -84,6 +84,8 @@ def main():
                     help="override the per-GPU variable count (default 10M at 1 GPU, 12.5M else)")
     ap.add_argument("--cpu-sample-vars", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-repeat-infer", action="store_true",
+                    help="skip the untimed repeated-inference leg (profiling runs: keeps the kernel stats clean)")
     ap.add_argument("--weights", type=int, default=0, help="override the weight count (experiments)")
     ap.add_argument("--tile-vars", type=int, default=0, help="graph-compile knob (experiments)")
     ap.add_argument("--tile-edges", type=int, default=0, help="graph-compile knob (experiments)")
@@ -169,15 +171,17 @@ def main():
     # outside the timed region: inference sweeps that FOLLOW EACH OTHER on unchanged weights
     # (what `dw gibbs -i N` runs) stream tabulated potential terms instead of gathering
     # weights; the step above alternates learning and inference and never gets there
-    sampler.kernel_time_reset(True)
-    for _ in range(6):
-        engine.sample()
-    engine.wait()
-    sampler.kernel_time_reset(True)
-    for _ in range(10):
-        engine.sample()
-    engine.wait()
-    ms_r, nl_r, ns_r = sampler.kernel_time("infer")
+    ms_r = nl_r = ns_r = 0
+    if not args.no_repeat_infer:
+        sampler.kernel_time_reset(True)
+        for _ in range(6):
+            engine.sample()
+        engine.wait()
+        sampler.kernel_time_reset(True)
+        for _ in range(10):
+            engine.sample()
+        engine.wait()
+        ms_r, nl_r, ns_r = sampler.kernel_time("infer")
     sampler.kernel_time_reset(False)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

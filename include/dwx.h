@@ -71,7 +71,7 @@ typedef struct dwx_graph_desc {
 typedef struct dwx_compile_opts {
   uint32_t tile_vars;          /* variables per workgroup tile (default 256, max 256)  */
   uint32_t tile_edges;         /* edge records staged in LDS per tile (default 3072)   */
-  uint32_t tile_rows;          /* value rows per tile (default 256 bool / 2048 categ.) */
+  uint32_t tile_rows;          /* value rows per tile (default 256 bool / 1536 categ.) */
   uint32_t conflict_arity_cap; /* factors wider than this do not constrain the
                                   colouring (Hogwild reads, as in the reference);
                                   default 256                                          */

@@ -57,9 +57,10 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     ap.add_argument("--tile-vars", type=int, default=0)
     ap.add_argument("--tile-edges", type=int, default=0)
+    ap.add_argument("--tile-rows", type=int, default=0)
     a = ap.parse_args()
     sc = a.scale
-    COMPILE.update(tile_vars=a.tile_vars, tile_edges=a.tile_edges)
+    COMPILE.update(tile_vars=a.tile_vars, tile_edges=a.tile_edges, tile_rows=a.tile_rows)
     todo = a.only.split(",") if a.only else ["cfg2", "cfg3", "cfg3b", "cfg4", "cfg4learn"]
     if "cfg2" in todo:
         run("cfg2", synthetic.cfg2(int(1_000_000 * sc)), 0, 20)
