@@ -223,6 +223,16 @@ def test_replica_weight_averaging(lib):
     E.test_replica_weight_averaging(lib)
 
 
+def test_tabulated_inference_terms_follow_every_weight_change(lib):
+    import test_kernels_emu as E
+    E.test_tabulated_inference_terms_follow_every_weight_change(lib)
+
+
+def test_split_sweep_with_pull_tiles_and_static_counts(lib, monkeypatch):
+    import test_kernels_emu as E
+    E.test_split_sweep_with_pull_tiles_and_static_counts(lib, monkeypatch)
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_binary_factor_tiles_all_functions(lib, seed):
     from randgraph import random_graph

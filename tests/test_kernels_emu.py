@@ -243,3 +243,48 @@ def test_split_sweep_with_pull_tiles_and_static_counts(lib, monkeypatch):
     # plans too large for the per-chunk tables: per-record atomics and dynamic counts
     monkeypatch.setenv("DWX_PLAN_TABLE_CHUNKS", "4")
     run_parity(lib, raw, n_learn=3, n_infer=1, stepsize=0.05, compile_opts=dict(tile_vars=64))
+
+
+def test_tabulated_inference_terms_follow_every_weight_change(lib):
+    """From the second consecutive inference sweep on unchanged weights on, all-unary tiles
+    stream a table of their potential terms instead of gathering weights.  The table must be
+    rebuilt after anything that changes the weights -- a learning sweep, dwx_set_weights,
+    replica averaging -- and must not be used by learning sweeps.  Exact parity with the
+    oracle through an interleaved sequence; mixed graph (tabulated and generic tiles)."""
+    from oracle import binding as orc
+    from sampler_amd import dwx
+    from parity import learn_sweep_both
+    from randgraph import random_graph
+    for raw in (synthetic.cfg3(3000, n_weights=1500, seed=5),
+                random_graph(21, V=1200, F=6000, W=60, p_cat=0.3, max_arity=2, exact_fvals=True)):
+        g = dwx.Graph(raw, lib=lib, tile_vars=64)
+        s, o = dwx.GibbsSampler(g, seed=13), orc.Oracle(raw)
+        order, off = g.schedule()
+        sweep = 0
+
+        def infer(n):
+            nonlocal sweep
+            for _ in range(n):
+                s.sample(); s.wait()
+                o.sched_sample(order, off, 13, sweep); sweep += 1
+                assert np.array_equal(s.assignments("evid"), o.assignments("evid"))
+
+        def learn(n, step):
+            nonlocal sweep
+            for _ in range(n):
+                learn_sweep_both(s, o, order, 13, sweep, step); sweep += 1
+                assert np.array_equal(s.assignments("free"), o.assignments("free"))
+                assert np.array_equal(s.assignments("evid"), o.assignments("evid"))
+                np.testing.assert_allclose(s.weights, o.weights, rtol=1e-12, atol=1e-12)
+
+        infer(4)                      # gather, build table, table, table
+        learn(2, 0.05)                # weights move: table stale
+        infer(3)
+        learn(1, 0.02); infer(1); learn(1, 0.02); infer(3)      # alternating, then repeated
+        w = o.weights.copy(); w[raw.w_is_fixed == 0] *= -0.5
+        s.weights = w; o.weights[:] = w
+        infer(3)
+        s.weights = 3 * w; s.average_weights(3)      # stands for an all-reduce + averaging
+        o.weights[:] = s.weights
+        infer(3)
+        assert np.array_equal(s.tallies()[0], o.tallies[:len(s.tallies()[0])])
