@@ -144,6 +144,8 @@ def main():
         # xGMI time): plan as if N equal shards contributed to every weight
         drv.plan_world = int(os.environ["DWX_BENCH_PLAN_WORLD"])
 
+    drv.prepare(stepsize)         # one-off planning work, whatever --warmup says
+
     def step(cur):
         drv.learn_epoch(cur)      # sample_sgd (+ RCCL all-reduce of the gradient vector)
         engine.sample()           # sample

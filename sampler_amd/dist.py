@@ -254,6 +254,11 @@ class ShardedDimmWitted:
         if self.halo is not None:
             self.halo.exchange(("free", "evid"))
 
+    def prepare(self, stepsize):
+        """Do the one-off work of the first learning sweep now (curvature estimates, plan
+        levels and their tables, the agreement collectives), e.g. before a timed region."""
+        self._plan(stepsize)
+
     def _global_curvature(self, batches, world):
         """world x max over ranks of the library's curvature estimate for `batches` pieces per
         launch: a weight's curvature adds up over shards.  One MAX all-reduce per batch count,

@@ -17,3 +17,70 @@ def test_hip_engine_rccl_plumbing_world_size_1():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "gpu dist plumbing ok" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stepsize", [0.0002, 0.05])
+def test_two_ranks_share_one_gpu_over_gloo(stepsize):
+    """Two ranks of the sharded driver with the product engine (real kernels, raw device
+    buffers, per-chunk static count tables shared across ranks, full or split sweeps) on one
+    GPU over gloo.  Weights must be bit-identical on both ranks and equal to the CPU oracle
+    replaying the same chunk sequence on the union graph; per-variable state must equal the
+    oracle's block.  stepsize 0.0002: un-split sweeps; 0.05: starts split and walks down."""
+    import tempfile
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import shard_graph
+    from oracle import binding as orc
+    from test_dist_gloo import _concat, _free_port
+    total, W, world = 40_000, 1500, 2
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as out:
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gpu_gloo_worker.py"),
+                                           out, str(total), str(W), str(stepsize)], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=600)[0] for p in procs]
+        for p, o in zip(procs, outs):
+            assert p.returncode == 0, o[-3000:]
+        res = [dict(np.load(os.path.join(out, "rank%d.npz" % r))) for r in range(world)]
+    assert np.array_equal(res[0]["weights"], res[1]["weights"])
+    assert np.array_equal(res[0]["batches"], res[1]["batches"]) and np.array_equal(res[0]["eta"], res[1]["eta"])
+    if stepsize > 0.01:
+        assert res[0]["batches"][0] > 1 and res[0]["batches"][-1] < res[0]["batches"][0]
+    else:
+        assert np.all(res[0]["batches"] == 1)
+    shards = [shard_graph(total, W, r, world, 1234)[0] for r in range(world)]
+    union = _concat(shards)
+    o = orc.Oracle(union, reg_param=0.01)
+    sweep = 0
+    for k in range(6):
+        n_chunks = max(len(res[r]["chunks%d" % k]) - 1 for r in range(world))
+        batches, eta = int(res[0]["batches"][k]), float(res[0]["eta"][k])
+        for c in range(n_chunks):
+            parts = []
+            for r in range(world):
+                off = res[r]["chunks%d" % k]
+                if c + 1 < len(off):
+                    parts.append(res[r]["order"][int(off[c]):int(off[c + 1])] + np.uint64(res[r]["begin"]))
+            sl = np.concatenate(parts)
+            o.sched_accumulate(sl, np.array([0, len(sl)], np.uint64), 4242, sweep)
+            if batches > 1 or c + 1 == n_chunks:
+                o.sched_apply(eta, 0.0)
+        sweep += 1
+    np.testing.assert_allclose(res[0]["weights"], o.weights, rtol=1e-12, atol=1e-12)
+    assert np.abs(o.weights).max() > 0
+    o.clear_tallies()
+    order = np.concatenate([res[r]["order"] + np.uint64(res[r]["begin"]) for r in range(world)])
+    for _ in range(3):
+        o.sched_sample(order, np.array([0, len(order)], np.uint64), 4242, sweep); sweep += 1
+    for r in range(world):
+        b = int(res[r]["begin"]); n = len(res[r]["free"])
+        assert np.array_equal(res[r]["free"], o.assignments("free")[b:b + n])
+        assert np.array_equal(res[r]["evid"], o.assignments("evid")[b:b + n])
+        assert np.array_equal(res[r]["tallies"], o.tallies[b:b + n])
