@@ -666,6 +666,24 @@ int gibbs(const CmdLine &args) {
       std::vector<uint64_t> tallies(info.num_values), nsamples(V), base(V), sparse(info.num_values);
       ok(dwx_get_tallies(sampler, tallies.data(), nsamples.data()));
       ok(dwx_graph_get_values(graph, base.data(), sparse.data()));
+      auto sampled = [&](uint64_t v) { return lg.var_role[v] < 1 || args.should_sample_evidence; };
+      if (progress) {
+        // InferenceResult::show_marginal_snippet (src/inference_result.cc:129-169): the first
+        // ten sampled variables
+        std::cout << "INFERENCE SNIPPETS (QUERY VARIABLES):" << std::endl;
+        size_t ct = 0;
+        for (uint64_t v = 0; v < V; ++v) {
+          if (!sampled(v)) continue;
+          ++ct;
+          std::cout << "   " << v << "  NSAMPLE=" << nsamples[v] << std::endl;
+          const uint64_t n = lg.var_dtype[v] == 0 ? 1 : lg.var_cardinality[v];
+          for (uint64_t j = 0; j < n; ++j)
+            std::cout << "      @ " << (lg.var_dtype[v] == 0 ? 1 : sparse[base[v] + j]) << " -> EXP="
+                      << 1.0 * tallies[base[v] + j] / nsamples[v] << std::endl;
+          if (ct % 10 == 0) break;
+        }
+        std::cout << "   ..." << std::endl;
+      }
       std::string fn = args.output_folder + "/inference_result.out.text";
       std::cout << "DUMPING... TEXT    : " << fn << std::endl;
       std::ofstream f(fn);
@@ -674,6 +692,29 @@ int gibbs(const CmdLine &args) {
       dump_marginals_in_text(f, lg, args.should_sample_evidence, base, sparse, tallies, nsamples);
       f.close();
       phase("dump marginals");
+      if (progress) {
+        // InferenceResult::show_marginal_histogram (src/inference_result.cc:171-209), 10 bins
+        const size_t bins = 10;
+        std::cout << "INFERENCE CALIBRATION (QUERY BINS):" << std::endl;
+        std::vector<size_t> abc(bins + 1, 0);
+        for (uint64_t v = 0; v < V; ++v) {
+          if (!sampled(v)) continue;
+          const uint64_t n = lg.var_dtype[v] == 0 ? 1 : lg.var_cardinality[v];
+          for (uint64_t k = 0; k < n; ++k) {
+            const size_t bin = (size_t)((double)tallies[base[v] + k] / nsamples[v] * bins);
+            if (bin <= bins) ++abc[bin];
+          }
+        }
+        abc[bins - 1] += abc[bins];
+        const std::ios::fmtflags flags(std::cout.flags());
+        std::cout << std::fixed;
+        const std::streamsize prec = std::cout.precision(1);   // max(ceil(log10(bins)), 1)
+        for (size_t i = 0; i < bins; ++i)
+          std::cout << "PROB BIN " << (float)i / bins << "~" << (float)(i + 1) / bins << "  -->  # " << abc[i]
+                    << std::endl;
+        std::cout.flags(flags);
+        std::cout << std::setprecision((int)prec);
+      }
     }
   } catch (const std::exception &e) {
     std::cerr << "dw: " << e.what() << std::endl;

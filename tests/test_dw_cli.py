@@ -150,3 +150,36 @@ def test_product_dw_equals_python_driver_on_gpu():
     assert s.weights_text() == w
     drv.inference()
     assert s.marginals_text() == m
+
+
+@pytest.mark.parametrize("fx", ["sparse_multinomial2", "biased_coin", "sparse_domains"])
+def test_dw_inference_snippets_and_calibration_blocks_like_the_reference(dw_emu, fx):
+    """Non-quiet runs end with the reference's INFERENCE SNIPPETS (first ten sampled variables,
+    one EXP line per value, sparse values) and the 10-bin INFERENCE CALIBRATION histogram
+    (src/inference_result.cc:129-209).  Same lines as the real reference binary up to the
+    Monte-Carlo numbers: identical variable/value labels, identical bin labels, equal totals."""
+    import re
+    from oracle import binding as orc
+    if not orc.have_reference():
+        pytest.skip("oracle/_ref/dw not present")
+    args = ["-l", "0", "-i", "50"] + (["--sample_evidence"] if fx != "sparse_domains" else [])
+
+    def blocks(text):
+        snip = text[text.index("INFERENCE SNIPPETS"):text.index("DUMPING... TEXT    : ", text.index("INFERENCE SNIPPETS"))]
+        cal = text[text.index("INFERENCE CALIBRATION"):]
+        return snip.splitlines(), cal.splitlines()[:11]
+
+    with tempfile.TemporaryDirectory() as a, tempfile.TemporaryDirectory() as b:
+        mine = run_dw(dw_emu, fx, a, args=args)
+        ref = run_dw(orc.REF_DW, fx, b, args=args)
+        assert mine.returncode == 0 and ref.returncode == 0, mine.stderr + ref.stderr
+    ms, mc = blocks(mine.stdout)
+    rs, rc = blocks(ref.stdout)
+    strip = lambda lines: [re.sub(r"EXP=.*", "EXP=", l) for l in lines]
+    assert strip(ms) == strip(rs)
+    assert all(re.fullmatch(r"      @ \d+ -> EXP=[0-9.e+-]+|   \d+  NSAMPLE=50|   \.\.\.|INFERENCE SNIPPETS \(QUERY VARIABLES\):", l) for l in ms)
+    labels = lambda lines: [l.split("-->")[0] for l in lines]
+    assert labels(mc) == labels(rc) and mc[0] == "INFERENCE CALIBRATION (QUERY BINS):"
+    assert mc[1].startswith("PROB BIN 0.0~0.1  -->  # ")
+    total = lambda lines: sum(int(l.split("#")[1]) for l in lines[1:])
+    assert total(mc) == total(rc) > 0
