@@ -693,27 +693,26 @@ int gibbs(const CmdLine &args) {
       f.close();
       phase("dump marginals");
       if (progress) {
-        // InferenceResult::show_marginal_histogram (src/inference_result.cc:171-209), 10 bins
-        const size_t bins = 10;
-        std::cout << "INFERENCE CALIBRATION (QUERY BINS):" << std::endl;
-        std::vector<size_t> abc(bins + 1, 0);
+        // the reference's closing calibration table (InferenceResult::show_marginal_histogram,
+        // src/inference_result.cc:171-209): how many sampled (variable, value) rows have their
+        // marginal in each tenth of [0, 1]; a marginal of exactly 1 counts in the last tenth
+        constexpr size_t kBins = 10;
+        size_t per_bin[kBins] = {0};
         for (uint64_t v = 0; v < V; ++v) {
-          if (!sampled(v)) continue;
-          const uint64_t n = lg.var_dtype[v] == 0 ? 1 : lg.var_cardinality[v];
-          for (uint64_t k = 0; k < n; ++k) {
-            const size_t bin = (size_t)((double)tallies[base[v] + k] / nsamples[v] * bins);
-            if (bin <= bins) ++abc[bin];
+          if (!sampled(v) || nsamples[v] == 0) continue;
+          const uint64_t rows = lg.var_dtype[v] == 0 ? 1 : lg.var_cardinality[v];
+          for (uint64_t k = 0; k < rows; ++k) {
+            const double p = (double)tallies[base[v] + k] / (double)nsamples[v];
+            ++per_bin[std::min(kBins - 1, (size_t)(p * kBins))];
           }
         }
-        abc[bins - 1] += abc[bins];
-        const std::ios::fmtflags flags(std::cout.flags());
-        std::cout << std::fixed;
-        const std::streamsize prec = std::cout.precision(1);   // max(ceil(log10(bins)), 1)
-        for (size_t i = 0; i < bins; ++i)
-          std::cout << "PROB BIN " << (float)i / bins << "~" << (float)(i + 1) / bins << "  -->  # " << abc[i]
-                    << std::endl;
-        std::cout.flags(flags);
-        std::cout << std::setprecision((int)prec);
+        std::cout << "INFERENCE CALIBRATION (QUERY BINS):" << std::endl;
+        char line[96];
+        for (size_t i = 0; i < kBins; ++i) {
+          snprintf(line, sizeof line, "PROB BIN %.1f~%.1f  -->  # %zu", (double)((float)i / kBins),
+                   (double)((float)(i + 1) / kBins), per_bin[i]);
+          std::cout << line << std::endl;
+        }
       }
     }
   } catch (const std::exception &e) {
