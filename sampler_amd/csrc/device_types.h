@@ -38,7 +38,16 @@ constexpr uint32_t EDGE_FIXED_FLAG = 1u << 5;   // the record's weight is fixed 
 // a boolean owner hit means "proposal == 1" and for a categorical owner "proposal ==
 // the value of the row the record sits in" (exact: signs are -1, 0 or +1).
 constexpr uint32_t EDGE_PRESIGNED = 1u << 6;
-constexpr uint32_t EDGE_ARITY_SHIFT = 8;      // bits 8-23: arity
+// Factor of arity 2 in a TILE_INLINE2 tile: the record carries the factor's two
+// FactorToVariable entries itself instead of pointing into vifs[] (one dependent 16-byte
+// load per record less).  aux = device position of the endpoint that is not the owner (the
+// owner's own position if both are the owner); the arity field is re-used:
+//   bit 8: position 0 is the owner, bit 9: position 1 is the owner,
+//   bits 10-16 / 17-23: dense predicate value (equal_to, < 128) of position 0 / 1.
+constexpr uint32_t EDGE_INLINE2 = 1u << 7;
+constexpr uint32_t INLINE2_A_IS_OWNER = 1u << 8, INLINE2_B_IS_OWNER = 1u << 9;
+constexpr uint32_t INLINE2_PRED_A_SHIFT = 10, INLINE2_PRED_B_SHIFT = 17, INLINE2_PRED_MASK = 0x7Fu;
+constexpr uint32_t EDGE_ARITY_SHIFT = 8;      // bits 8-23: arity (unless EDGE_INLINE2)
 constexpr uint32_t EDGE_ARITY_MASK = 0xFFFFu;
 constexpr uint32_t EDGE_OWNER_SHIFT = 24;     // bits 24-31: lane of the owning variable in its tile
 constexpr uint32_t MAX_ARITY = EDGE_ARITY_MASK;
@@ -72,6 +81,9 @@ constexpr uint32_t TILE_PULL = 1u << 2;
 // evaluates all records edge-parallel in the staging pass (batched vif-pair loads, then
 // batched neighbour gathers) and stages potential terms, as for TILE_SIMPLE.
 constexpr uint32_t TILE_TERMS2 = 1u << 3;
+// TILE_TERMS2 tile whose arity-2 records are EDGE_INLINE2 (only handed to kernels built with
+// K <= 6, the ones that implement TILE_TERMS2)
+constexpr uint32_t TILE_INLINE2 = 1u << 4;
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
 
 // v_meta bits

@@ -207,9 +207,9 @@ void enqueue_inference(dwx_sampler *s) {
   // inference sweeps may alternate, and then the table would be rebuilt for a single use.)
   if (s->has_simple_tiles && s->terms_state == 1 && c.NIdx) {
     if (!s->d_terms) s->d_terms = (EdgeTerms *)rt::dmalloc(c.NIdx * sizeof(EdgeTerms));
-    const unsigned grid = std::min<unsigned>((unsigned)((c.NIdx + BLOCK_THREADS - 1) / BLOCK_THREADS), 256u * 32u);
-    rt::launch(build_terms_kernel, grid, BLOCK_THREADS, 0, s->stream, (const EdgeRec *)s->d_edges,
-               (const float *)s->d_w32, s->d_terms, (uint32_t)c.NIdx);
+    const unsigned grid = std::min<unsigned>((unsigned)c.tiles.size(), 256u * 16u);
+    rt::launch(build_terms_kernel, grid, BLOCK_THREADS, 0, s->stream, (const TileDesc *)s->d_tiles,
+               (uint32_t)c.tiles.size(), (const EdgeRec *)s->d_edges, (const float *)s->d_w32, s->d_terms);
     s->terms_state = 2;
   }
   P.edge_terms = s->terms_state == 2 ? s->d_terms : nullptr;
@@ -421,7 +421,7 @@ double row_sum_bound(dwx_sampler *s, uint32_t batches) {
       return std::fabs((double)r.fval - (double)miss);
     }
     const double f = (r.packed & EDGE_F64_FLAG) ? c.edge_fval64[e] : (double)r.fval;
-    const uint32_t ar = (r.packed >> EDGE_ARITY_SHIFT) & EDGE_ARITY_MASK;
+    const uint32_t ar = (r.packed & EDGE_INLINE2) ? 2u : ((r.packed >> EDGE_ARITY_SHIFT) & EDGE_ARITY_MASK);
     return 2.0 * std::fabs(f) * std::max(1u, ar - 1);
   };
   auto triggers = [&](uint32_t m) {
@@ -797,7 +797,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     KernelParams &P = s->base;
     P.v_meta = s->d_v_meta; P.v_orig = s->d_v_orig; P.v_row = s->d_v_row; P.v_init = s->d_v_init;
     P.row_ptr = s->d_row_ptr; P.row_truth = s->d_row_truth; P.edges = s->d_edges; P.edge_terms = nullptr;
-    for (const TileDesc &td : c.tiles) if (td.flags & TILE_SIMPLE) { s->has_simple_tiles = true; break; }
+    for (const TileDesc &td : c.tiles) if (td.flags & (TILE_SIMPLE | TILE_INLINE2)) { s->has_simple_tiles = true; break; }
     P.edge_fval64 = s->d_edge_fval64; P.vifs = s->d_vifs; P.tiles = s->d_tiles;
     P.assign_free = s->d_assign_free; P.assign_evid = s->d_assign_evid; P.tally = s->d_tally;
     P.w32 = s->d_w32; P.grad = s->d_grad; P.delta = s->d_delta;

@@ -473,6 +473,33 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
                 ((simple && !cat && W > LDS_AGG_MAX_W) ? TILE_PULL : 0u) |
                 ((terms2 && !simple && !cat && t.nv <= 256) ? TILE_TERMS2 : 0u);
       if (t.flags & TILE_TERMS2) ++n_terms2;
+      // arity-2 records carry their two vif entries themselves where the kernels that will
+      // see the tile implement it (the K <= 6 builds; not the oversized-variable kernel) and
+      // the predicates fit 7 bits
+      if ((t.flags & TILE_TERMS2) && g.ecap <= 6 * BLOCK_THREADS && t.nrows <= g.rcap && t.nedges <= g.ecap) {
+        bool ok = true;
+        for (uint32_t e = t.e0; e < t.e0 + t.nedges && ok; ++e) {
+          const EdgeRec &r = g.edges[e];
+          if (r.packed & EDGE_PRESIGNED) continue;
+          const VifRec *vp = &g.vifs[r.aux];
+          ok = vp[0].equal_to <= INLINE2_PRED_MASK && vp[1].equal_to <= INLINE2_PRED_MASK;
+        }
+        if (ok) {
+          t.flags |= TILE_INLINE2;
+          for (uint32_t l = 0; l < t.nv; ++l)
+            for (uint32_t e = g.row_ptr[g.v_row[v0 + l]]; e < g.row_ptr[g.v_row[v0 + l + 1]]; ++e) {
+              EdgeRec &r = g.edges[e];
+              if (r.packed & EDGE_PRESIGNED) continue;
+              const VifRec a = g.vifs[r.aux], b = g.vifs[r.aux + 1];
+              const uint32_t me = v0 + l;
+              const bool a_me = a.vid == me, b_me = b.vid == me;
+              r.aux = !a_me ? a.vid : (!b_me ? b.vid : me);
+              r.packed = (r.packed & ~(EDGE_ARITY_MASK << EDGE_ARITY_SHIFT)) | EDGE_INLINE2 |
+                         (a_me ? INLINE2_A_IS_OWNER : 0u) | (b_me ? INLINE2_B_IS_OWNER : 0u) |
+                         (a.equal_to << INLINE2_PRED_A_SHIFT) | (b.equal_to << INLINE2_PRED_B_SHIFT);
+            }
+        }
+      }
       // every record learns the lane of its owning variable inside the tile
       for (uint32_t l = 0; l < t.nv; ++l)
         for (uint32_t e = g.row_ptr[g.v_row[v0 + l]]; e < g.row_ptr[g.v_row[v0 + l + 1]]; ++e)

@@ -101,6 +101,18 @@ DWX_DEV double unary_sign(uint32_t func, bool s) {
   }
 }
 
+// The two FactorToVariable entries of an EDGE_INLINE2 record, decoded from the record
+// itself (TILE_INLINE2 tiles; no load).  `me` = device position of the record's owner.  A
+// pre-signed record of such a tile decodes to (me, me): harmless, its terms come from the
+// record's own fields.
+DWX_DEV void decode_inline2(const EdgeRec &r, uint32_t me, VifRec &a, VifRec &b) {
+  const bool pre = r.packed & EDGE_PRESIGNED;
+  a.vid = (pre || (r.packed & INLINE2_A_IS_OWNER)) ? me : r.aux;
+  b.vid = (pre || (r.packed & INLINE2_B_IS_OWNER)) ? me : r.aux;
+  a.equal_to = (r.packed >> INLINE2_PRED_A_SHIFT) & INLINE2_PRED_MASK;
+  b.equal_to = (r.packed >> INLINE2_PRED_B_SHIFT) & INLINE2_PRED_MASK;
+}
+
 // binary factor from its two satisfied bits (a = first predicate, b = second / head)
 DWX_DEV double binary_sign(uint32_t func, bool a, bool b) {
   switch (func) {
@@ -173,6 +185,16 @@ DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const Vi
 enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3 };
 
 struct alignas(16) EdgeTerms { double t1, t0; };
+// Table entry of a record of a TILE_INLINE2 tile (build_terms_kernel), overlaying an EdgeRec:
+// wf = w * |f|-signed product (f64 of two f32: exact), `other` = device position of the other
+// endpoint (the owner's for a unary record), bits: func id in 0-3; unary: TAB2_UNARY, TAB2_C1
+// (t1 = wf, else 0) and c0 + 1 in two bits (t0 = c0 * wf); arity 2: the INLINE2 field.
+struct alignas(16) TabRec2 { double wf; uint32_t other; uint32_t bits; };
+constexpr uint32_t TAB2_UNARY = 1u << 4, TAB2_C1 = 1u << 5, TAB2_C0_SHIFT = 6;
+DWX_DEV double u32x2_to_double(uint32_t lo, uint32_t hi) {
+  const unsigned long long u = (unsigned long long)lo | ((unsigned long long)hi << 32);
+  double d; __builtin_memcpy(&d, &u, 8); return d;
+}
 static_assert(sizeof(EdgeTerms) == sizeof(EdgeRec), "terms overlay the staged records");
 
 struct TileView {
@@ -650,7 +672,7 @@ DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t
                               TilePrefetch<K> &f) {
   // inference over an all-unary tile whose potential terms are already tabulated
   // (edge_terms, same 16-byte stride): stream those instead of the records
-  const EdgeRec *stream = (!LEARN && P.edge_terms && (d.flags & TILE_SIMPLE)) ? (const EdgeRec *)P.edge_terms : P.edges;
+  const EdgeRec *stream = (!LEARN && P.edge_terms && (d.flags & (TILE_SIMPLE | TILE_INLINE2))) ? (const EdgeRec *)P.edge_terms : P.edges;
   DWX_LOAD_TILE_RECORDS(K, stream + d.e0, d.nedges, t, f.rec);
 #pragma unroll
   for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k)
@@ -696,7 +718,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
     const VarPre pre = f.pre;
     double A = 0.0, B = 0.0;
     // tabulated terms (see issue_tile_loads): nothing to gather, nothing to multiply
-    const bool tabulated = !LEARN && P.edge_terms && (d.flags & TILE_SIMPLE);   // workgroup-uniform
+    const bool tabulated = !LEARN && P.edge_terms && (d.flags & (TILE_SIMPLE | TILE_INLINE2));   // workgroup-uniform
     if (fits) {
       // gather the f32 sampling weight of every record this lane staged ...
       float w[K];
@@ -716,11 +738,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
       if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
         LearnRec *s_lrec = (LearnRec *)s_edges;
         VifRec va[K], vb[K];
+        if (d.flags & TILE_INLINE2) {   // workgroup-uniform
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const bool bin = !(f.rec[k].packed & EDGE_PRESIGNED);
-          const VifRec *vp = P.vifs + (bin ? f.rec[k].aux : 0u);
-          va[k] = vp[0]; vb[k] = vp[1];
+          for (int k = 0; k < K; ++k) decode_inline2(f.rec[k], d.v0 + edge_owner_lane(f.rec[k]), va[k], vb[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const bool bin = !(f.rec[k].packed & EDGE_PRESIGNED);
+            const VifRec *vp = P.vifs + (bin ? f.rec[k].aux : 0u);
+            va[k] = vp[0]; vb[k] = vp[1];
+          }
         }
         uint32_t of[K], oe[K];
 #pragma unroll
@@ -760,12 +787,47 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
         // neighbour-assignment gathers, are all in flight together (inside the per-variable
         // loop they would be 2 dependent round trips per record, serialised).
         EdgeTerms *s_terms = (EdgeTerms *)s_edges;
-        VifRec va[K], vb[K];
+        if (tabulated) {
+          // the stream holds TabRec2 entries (build_terms_kernel): w*f tabulated, the other
+          // endpoint inline -- one neighbour gather per record is all that is left
+          uint32_t other[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const bool bin = !(f.rec[k].packed & EDGE_PRESIGNED);
-          const VifRec *vp = P.vifs + (bin ? f.rec[k].aux : 0u);   // padded: always in bounds
-          va[k] = vp[0]; vb[k] = vp[1];
+          for (int k = 0; k < K; ++k) other[k] = P.assign_evid[f.rec[k].packed];   // TabRec2::other
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const EdgeRec r = f.rec[k];
+            const double wf = u32x2_to_double(r.wid, r.aux);
+            const uint32_t bits = float_to_bits(r.fval);
+            EdgeTerms tt;
+            if (bits & TAB2_UNARY) {
+              tt.t1 = (bits & TAB2_C1) ? wf : 0.0;
+              const uint32_t c0 = (bits >> TAB2_C0_SHIFT) & 3u;   // 0: -1, 1: 0, 2: +1
+              tt.t0 = c0 == 1u ? 0.0 : (c0 == 2u ? wf : -wf);
+            } else {
+              const uint32_t pa = (bits >> INLINE2_PRED_A_SHIFT) & INLINE2_PRED_MASK;
+              const uint32_t pb = (bits >> INLINE2_PRED_B_SHIFT) & INLINE2_PRED_MASK;
+              const bool a_me = bits & INLINE2_A_IS_OWNER, b_me = bits & INLINE2_B_IS_OWNER;
+              const bool a_o = other[k] == pa, b_o = other[k] == pb;
+              const bool a1 = a_me ? (pa == 1u) : a_o, b1 = b_me ? (pb == 1u) : b_o;
+              const bool a0 = a_me ? (pa == 0u) : a_o, b0 = b_me ? (pb == 0u) : b_o;
+              const uint32_t fn = bits & EDGE_FUNC_MASK;
+              tt.t1 = binary_sign(fn, a1, b1) * wf;
+              tt.t0 = binary_sign(fn, a0, b0) * wf;
+            }
+            s_terms[t + k * BLOCK_THREADS] = tt;
+          }
+        } else {
+        VifRec va[K], vb[K];
+        if (d.flags & TILE_INLINE2) {   // workgroup-uniform
+#pragma unroll
+          for (int k = 0; k < K; ++k) decode_inline2(f.rec[k], d.v0 + edge_owner_lane(f.rec[k]), va[k], vb[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const bool bin = !(f.rec[k].packed & EDGE_PRESIGNED);
+            const VifRec *vp = P.vifs + (bin ? f.rec[k].aux : 0u);   // padded: always in bounds
+            va[k] = vp[0]; vb[k] = vp[1];
+          }
         }
         uint32_t other[K];
 #pragma unroll
@@ -796,6 +858,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
             tt.t0 = wv * (binary_sign(fn, a0, b0) * fv);
           }
           s_terms[t + k * BLOCK_THREADS] = tt;
+        }
         }
       } else if (!LEARN && (d.flags & TILE_SIMPLE)) {
         // inference, all-unary tile: do the per-record arithmetic here, edge-parallel
@@ -1069,17 +1132,38 @@ apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *gra
 // Inference sweeps then stream the table and touch no weight: the 50 M random L2 requests
 // per sweep that bound config 3's inference are gone.
 __global__ void __launch_bounds__(BLOCK_THREADS)
-build_terms_kernel(const EdgeRec *edges, const float *w32, EdgeTerms *terms, uint32_t n) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const EdgeRec r = edges[i];
-    EdgeTerms tt{0.0, 0.0};
-    if (r.packed & EDGE_PRESIGNED) {
+build_terms_kernel(const TileDesc *tiles, uint32_t n_tiles, const EdgeRec *edges, const float *w32,
+                   EdgeTerms *terms) {
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const TileDesc d = tiles[tile];
+    const bool simple = d.flags & TILE_SIMPLE, inline2 = d.flags & TILE_INLINE2;
+    if (!simple && !inline2) continue;        // such tiles never read the table
+    for (uint32_t i = threadIdx.x; i < d.nedges; i += BLOCK_THREADS) {
+      const EdgeRec r = edges[d.e0 + i];
       const double wv = (double)w32[r.wid];
-      tt.t1 = wv * (double)r.fval;
-      tt.t0 = wv * (double)bits_to_float(r.aux);
+      if (simple) {
+        EdgeTerms tt;
+        tt.t1 = wv * (double)r.fval;
+        tt.t0 = wv * (double)bits_to_float(r.aux);
+        terms[d.e0 + i] = tt;
+      } else {
+        TabRec2 tr;
+        if (r.packed & EDGE_PRESIGNED) {
+          // hit / miss values are s * f with s in {-1, 0, +1}: one product, two small codes
+          const float hit = r.fval, miss = bits_to_float(r.aux);
+          const float ref = hit != 0.0f ? hit : miss;
+          tr.wf = wv * (double)ref;
+          const uint32_t c0 = miss == 0.0f ? 1u : (miss == ref ? 2u : 0u);
+          tr.bits = (r.packed & EDGE_FUNC_MASK) | TAB2_UNARY | (hit != 0.0f ? TAB2_C1 : 0u) | (c0 << TAB2_C0_SHIFT);
+          tr.other = d.v0 + edge_owner_lane(r);
+        } else {
+          tr.wf = wv * (double)r.fval;
+          tr.bits = r.packed & (EDGE_FUNC_MASK | (EDGE_ARITY_MASK << EDGE_ARITY_SHIFT));
+          tr.other = r.aux;
+        }
+        ((TabRec2 *)terms)[d.e0 + i] = tr;
+      }
     }
-    terms[i] = tt;
   }
 }
 
