@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--weights", type=int, default=0, help="override the weight count (experiments)")
     ap.add_argument("--tile-vars", type=int, default=0, help="graph-compile knob (experiments)")
     ap.add_argument("--tile-edges", type=int, default=0, help="graph-compile knob (experiments)")
+    ap.add_argument("--wide-records", action="store_true",
+                    help="graph-compile knob (experiments): 16-byte records even though the graph is all-unary")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line.  Libraries that print to the process's stdout
@@ -126,7 +128,8 @@ def main():
     stepsize, decay, reg = 0.001, 0.95, 0.01       # SURVEY.md §8(d) config-3 run flags
     t0 = time.time()
     raw = synthetic.cfg3(V, n_weights=W, seed=1234, shard=rank)
-    graph = dwx.Graph(raw, tile_vars=args.tile_vars, tile_edges=args.tile_edges)
+    graph = dwx.Graph(raw, tile_vars=args.tile_vars, tile_edges=args.tile_edges,
+                      no_compact_records=1 if args.wide_records else 0)
     sampler = dwx.GibbsSampler(graph, device=local_rank, reg_param=reg, seed=20260103,
                                var_id_offset=rank * V)
     if rank == 0:

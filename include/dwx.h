@@ -76,7 +76,8 @@ typedef struct dwx_compile_opts {
                                   colouring (Hogwild reads, as in the reference);
                                   default 256                                          */
   uint32_t n_threads;          /* host threads for the build (0 = all cores)           */
-  uint32_t reserved;
+  uint32_t no_compact_records; /* 1: keep 16-byte records even for all-unary graphs
+                                  (default 0: such graphs stream 8-byte records)       */
 } dwx_compile_opts;
 
 typedef struct dwx_graph_info {

@@ -52,6 +52,19 @@ constexpr uint32_t EDGE_ARITY_MASK = 0xFFFFu;
 constexpr uint32_t EDGE_OWNER_SHIFT = 24;     // bits 24-31: lane of the owning variable in its tile
 constexpr uint32_t MAX_ARITY = EDGE_ARITY_MASK;
 
+// Compact form of a pre-signed record, 8 bytes: what the sweep kernels stream when EVERY
+// tile of the graph is TILE_SIMPLE (all-unary graphs: half the record stream of a sweep).
+//   key: bits 0-26 weight id, bit 27 weight is fixed, bits 28-29 sign(hit) + 1,
+//        bits 30-31 sign(miss) + 1;   f: the feature value (f32-exact by construction)
+// so hit = sign(hit) * f and miss = sign(miss) * f are rebuilt with two bit operations.
+struct alignas(8) EdgeRec8 {
+  uint32_t key;
+  float f;
+};
+static_assert(sizeof(EdgeRec8) == 8, "EdgeRec8 must be 8 bytes");
+constexpr uint32_t REC8_WID_BITS = 27, REC8_WID_MASK = (1u << REC8_WID_BITS) - 1;
+constexpr uint32_t REC8_FIXED = 1u << 27, REC8_HIT_SHIFT = 28, REC8_MISS_SHIFT = 30;
+
 // factor -> variable entry (src/variable.h:154-167), 8 bytes, device variable ids
 struct alignas(8) VifRec {
   uint32_t vid;       // DEVICE position of the variable
@@ -129,6 +142,7 @@ struct KernelParams {
   const uint32_t *row_ptr;    // [R+1] edge-record offsets
   const double *row_truth;    // [R] truthiness per value row, or null
   const EdgeRec *edges;       // [NIdx]
+  const EdgeRec8 *edges8;     // [NIdx] compact records of an all-TILE_SIMPLE graph, or null
   const void *edge_terms;     // [NIdx] 16-byte {w*sign(hit)*f, w*sign(miss)*f} (f64) of the pre-signed
                               // records under the CURRENT weights, or null (inference sweeps only)
   const double *edge_fval64;  // [NIdx] or null

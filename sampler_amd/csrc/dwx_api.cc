@@ -104,6 +104,9 @@ struct dwx_sampler {
   std::vector<uint64_t> sgd_work;             // [tiles + 1] prefix sums of SGD-visited records
   bool wide_learn = false;   // the graph has TILE_TERMS2 tiles: 32-byte staged records when learning
   unsigned persistent_blocks[2] = {1, 1};
+  bool rec8 = false;                    // the graph streams 8-byte records (CompiledGraph::edges8)
+  unsigned persistent_blocks8[2] = {1, 1};
+  EdgeRec8 *d_edges8 = nullptr;
   double *d_row_truth = nullptr, *d_edge_fval64 = nullptr;
   EdgeRec *d_edges = nullptr;
   VifRec *d_vifs = nullptr;
@@ -150,7 +153,7 @@ struct dwx_sampler {
     for (auto &sp : spans) { rt::event_destroy(sp.a); rt::event_destroy(sp.b); rt::event_destroy(sp.c); }
     rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
     rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
-    rt::dfree(d_edges); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
+    rt::dfree(d_edges); rt::dfree(d_edges8); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
     rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_terms); rt::dfree(d_delta);
     rt::dfree(d_w_fixed); rt::dfree(d_grad);
     if (stream) rt::stream_destroy(stream);
@@ -167,9 +170,17 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   P.tile_begin = t0;
   P.tile_end = t1;
   // persistent grid: as many workgroups as stay resident, each striding over tiles
-  const unsigned grid = std::min<unsigned>(t1 - t0, s->persistent_blocks[LEARN ? 1 : 0]);
+  // all-unary graph: 8-byte record stream (a run on the terms table streams those instead)
+  const bool rec8 = s->rec8 && !P.edge_terms;
+  const unsigned grid = std::min<unsigned>(t1 - t0, (rec8 ? s->persistent_blocks8 : s->persistent_blocks)[LEARN ? 1 : 0]);
   const size_t lds = s->lds_bytes[LEARN ? 1 : 0];
-  if (LEARN && s->wide_learn) {
+  if (rec8) {
+    switch (s->stage_k) {
+      case 3: rt::launch(sweep_kernel<LEARN, 3, false, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      case 6: rt::launch(sweep_kernel<LEARN, 6, false, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      default: rt::launch(sweep_kernel<LEARN, 12, false, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+    }
+  } else if (LEARN && s->wide_learn) {
     switch (s->stage_k) {
       case 3: rt::launch(sweep_kernel<LEARN, 3, LEARN>, grid, BLOCK_THREADS, lds, s->stream, P); break;
       case 6: rt::launch(sweep_kernel<LEARN, 6, LEARN>, grid, BLOCK_THREADS, lds, s->stream, P); break;
@@ -772,6 +783,8 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     if (!c.row_truth.empty()) s->d_row_truth = upload(c.row_truth, st);
     if (!c.edge_fval64.empty()) s->d_edge_fval64 = upload(c.edge_fval64, st);
     s->d_edges = upload(c.edges, st, 1);
+    s->rec8 = !c.edges8.empty();
+    if (s->rec8) s->d_edges8 = upload(c.edges8, st, 1);
     s->d_vifs = upload(c.vifs, st);
     // InferenceResult init (src/inference_result.cc:24-42): both chains start at the
     // evidence value or 0, tallies zero, weights at their initial values
@@ -796,7 +809,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
 
     KernelParams &P = s->base;
     P.v_meta = s->d_v_meta; P.v_orig = s->d_v_orig; P.v_row = s->d_v_row; P.v_init = s->d_v_init;
-    P.row_ptr = s->d_row_ptr; P.row_truth = s->d_row_truth; P.edges = s->d_edges; P.edge_terms = nullptr;
+    P.row_ptr = s->d_row_ptr; P.row_truth = s->d_row_truth; P.edges = s->d_edges; P.edges8 = s->d_edges8; P.edge_terms = nullptr;
     for (const TileDesc &td : c.tiles) if (td.flags & (TILE_SIMPLE | TILE_INLINE2)) { s->has_simple_tiles = true; break; }
     P.edge_fval64 = s->d_edge_fval64; P.vifs = s->d_vifs; P.tiles = s->d_tiles;
     P.assign_free = s->d_assign_free; P.assign_evid = s->d_assign_evid; P.tally = s->d_tally;
@@ -848,6 +861,19 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
         case 3: prepare(sweep_kernel<false, 3>, sweep_kernel<true, 3>); break;
         case 6: prepare(sweep_kernel<false, 6>, sweep_kernel<true, 6>); break;
         default: prepare(sweep_kernel<false, 12>, sweep_kernel<true, 12>); break;
+      }
+    }
+    if (s->rec8) {
+      auto prepare8 = [&](auto infer, auto learn) {
+        rt::allow_dynamic_lds(infer, s->lds_bytes[0]);
+        rt::allow_dynamic_lds(learn, s->lds_bytes[1]);
+        s->persistent_blocks8[0] = rt::resident_blocks(infer, BLOCK_THREADS, s->lds_bytes[0]);
+        s->persistent_blocks8[1] = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_bytes[1]);
+      };
+      switch (s->stage_k) {
+        case 3: prepare8(sweep_kernel<false, 3, false, true>, sweep_kernel<true, 3, false, true>); break;
+        case 6: prepare8(sweep_kernel<false, 6, false, true>, sweep_kernel<true, 6, false, true>); break;
+        default: prepare8(sweep_kernel<false, 12, false, true>, sweep_kernel<true, 12, false, true>); break;
       }
     }
     rt::stream_sync(st);

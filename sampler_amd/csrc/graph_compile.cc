@@ -45,7 +45,7 @@ uint64_t CompiledGraph::device_bytes() const {
   uint64_t b = 0;
   b += 4 * (V * 4 + 1);                       // v_meta, v_orig, v_init, v_row
   b += 4 * (R + 1) + (row_truth.empty() ? 0 : 8 * R);
-  b += 16 * NIdx + (edge_fval64.empty() ? 0 : 8 * NIdx) + 8 * NVif;
+  b += 16 * NIdx + 8 * edges8.size() + (edge_fval64.empty() ? 0 : 8 * NIdx) + 8 * NVif;
   b += 32 * tiles.size();
   b += 4 * V * 2 + 4 * R;                     // assignments x2, tallies
   b += W * (8 + 4 + 1 + 16 + 8);              // weights f64 + f32 copy, fixed, grad G/T, T static
@@ -508,6 +508,31 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     }
     }, 64);
     g.n_terms2_tiles = n_terms2;
+    // All-unary graph (every record pre-signed): the sweeps stream 8-byte records instead
+    // (the 16-byte ones stay for the oversized-variable kernel and the terms table).
+    {
+      bool all_simple = g.NIdx > 0 && W <= REC8_WID_MASK && !o.no_compact_records;
+      for (size_t i = 0; i < g.tiles.size() && all_simple; ++i) all_simple = (g.tiles[i].flags & TILE_SIMPLE) != 0;
+      g.edges8.clear();
+      if (all_simple) {
+        g.edges8.resize(g.NIdx);
+        parallel_ranges(g.NIdx, nth, [&](uint64_t eb, uint64_t ee) {
+          for (uint64_t e = eb; e < ee; ++e) {
+            const EdgeRec &r = g.edges[e];
+            float miss;
+            std::memcpy(&miss, &r.aux, 4);
+            // hit = s_hit * f, miss = s_miss * f with signs in {-1, 0, +1}: recover (s, f)
+            const float f = r.fval != 0.0f ? std::fabs(r.fval) : std::fabs(miss);
+            auto code = [&](float x) -> uint32_t { return x == 0.0f ? 1u : (x < 0.0f ? 0u : 2u); };
+            EdgeRec8 c;
+            c.key = r.wid | ((r.packed & EDGE_FIXED_FLAG) ? REC8_FIXED : 0u) |
+                    (code(r.fval) << REC8_HIT_SHIFT) | (code(miss) << REC8_MISS_SHIFT);
+            c.f = f;
+            g.edges8[e] = c;
+          }
+        });
+      }
+    }
     g.giant_tiles.clear(); g.launch_giant.clear(); g.launch_giant_query_end.clear();
     for (uint64_t l = 0; l < nl; ++l) {
       g.launch_giant.push_back((uint32_t)g.giant_tiles.size());

@@ -46,6 +46,7 @@ struct CompiledGraph {
   std::vector<uint32_t> row_ptr;   // [R+1]
   std::vector<double> row_truth;   // [R] or empty
   std::vector<EdgeRec> edges;      // [NIdx]
+  std::vector<EdgeRec8> edges8;    // [NIdx] when every tile is TILE_SIMPLE (and W < 2^27), else empty
   std::vector<double> edge_fval64; // [NIdx] or empty
   std::vector<VifRec> vifs;        // [NVif]
   std::vector<uint32_t> tile_v;       // [n_tiles+1]

@@ -630,10 +630,46 @@ DWX_DEV void load_tile_records(const EdgeRec *base, uint32_t nedges, uint32_t t,
 #define DWX_LOAD_TILE_RECORDS(K, base, nedges, t, rec) load_tile_records<K>(base, nedges, t, rec)
 #endif
 
-// Everything a lane holds in registers for the tile it will stage next.
+// The same stream for the 8-byte records of an all-TILE_SIMPLE graph (buffer_load_dwordx2).
+#ifndef DWX_LOAD_TILE_RECORDS8
+typedef uint32_t dwx_u32x2 __attribute__((ext_vector_type(2)));
 template <int K>
+DWX_DEV void load_tile_records8(const EdgeRec8 *base, uint32_t nedges, uint32_t t, EdgeRec8 (&rec)[K]) {
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(nedges * sizeof(EdgeRec8)), 0x00020000);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const dwx_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(
+        rsrc, (int)(t * sizeof(EdgeRec8)), (int)(k * BLOCK_THREADS * sizeof(EdgeRec8)), /*nt*/ 2);
+    rec[k].key = v.x; rec[k].f = bits_to_float(v.y);
+  }
+}
+#define DWX_LOAD_TILE_RECORDS8(K, base, nedges, t, rec) load_tile_records8<K>(base, nedges, t, rec)
+#endif
+
+// An 8-byte record back in its 16-byte pre-signed form (a zero-filled lane past the tile's
+// end decodes to weight 0 and two -0.0f: staged, never read).
+DWX_DEV float rec8_signed(uint32_t code, float f) {   // code = sign + 1
+  const uint32_t b = float_to_bits(f);
+  return bits_to_float(code == 1u ? 0u : (code == 0u ? (b ^ 0x80000000u) : b));
+}
+DWX_DEV EdgeRec expand_record(const EdgeRec8 &c) {
+  EdgeRec r;
+  r.wid = c.key & REC8_WID_MASK;
+  r.fval = rec8_signed((c.key >> REC8_HIT_SHIFT) & 3u, c.f);
+  r.aux = float_to_bits(rec8_signed((c.key >> REC8_MISS_SHIFT) & 3u, c.f));
+  r.packed = EDGE_PRESIGNED | (1u << EDGE_ARITY_SHIFT) | ((c.key & REC8_FIXED) ? EDGE_FIXED_FLAG : 0u);
+  return r;
+}
+DWX_DEV EdgeRec expand_record(const EdgeRec &r) { return r; }
+
+template <bool REC8> struct StreamRec { typedef EdgeRec type; };
+template <> struct StreamRec<true> { typedef EdgeRec8 type; };
+
+// Everything a lane holds in registers for the tile it will stage next.
+template <int K, bool REC8>
 struct TilePrefetch {
-  EdgeRec rec[K];
+  typename StreamRec<REC8>::type rec[K];
   uint32_t rp[ROWPTR_UNROLL];
   VarPre pre;
 };
@@ -668,12 +704,21 @@ DWX_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 // re-load the tile's last row pointer / variable (the arrays carry one padding
 // element) -- and all K + ROWPTR_UNROLL + 4 loads of a lane are in flight together.
 template <bool LEARN, int K>
-DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t t,
-                              TilePrefetch<K> &f) {
+DWX_DEV void issue_record_loads(const KernelParams &P, const TileDesc &d, uint32_t t, EdgeRec (&rec)[K]) {
   // inference over an all-unary tile whose potential terms are already tabulated
   // (edge_terms, same 16-byte stride): stream those instead of the records
   const EdgeRec *stream = (!LEARN && P.edge_terms && (d.flags & (TILE_SIMPLE | TILE_INLINE2))) ? (const EdgeRec *)P.edge_terms : P.edges;
-  DWX_LOAD_TILE_RECORDS(K, stream + d.e0, d.nedges, t, f.rec);
+  DWX_LOAD_TILE_RECORDS(K, stream + d.e0, d.nedges, t, rec);
+}
+template <bool LEARN, int K>
+DWX_DEV void issue_record_loads(const KernelParams &P, const TileDesc &d, uint32_t t, EdgeRec8 (&rec)[K]) {
+  DWX_LOAD_TILE_RECORDS8(K, P.edges8 + d.e0, d.nedges, t, rec);
+}
+
+template <bool LEARN, int K, bool REC8>
+DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t t,
+                              TilePrefetch<K, REC8> &f) {
+  issue_record_loads<LEARN, K>(P, d, t, f.rec);
 #pragma unroll
   for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k)
     f.rp[k] = P.row_ptr[d.r0 + umin(t + k * BLOCK_THREADS, d.nrows)];
@@ -689,7 +734,10 @@ DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t
 // handled by giant_kernel.
 // WIDE (learning only): the graph has TILE_TERMS2 tiles; their records are staged as
 // 32-byte LearnRec (LDS doubles, one workgroup per CU, so registers are plentiful).
-template <bool LEARN, int K, bool WIDE = false>
+// REC8: every tile of the graph is TILE_SIMPLE and the record stream is P.edges8 (8 bytes per
+// record; never launched with the terms table -- that run streams 16-byte terms through the
+// REC8 = false build).
+template <bool LEARN, int K, bool WIDE = false, bool REC8 = false>
 // (the learning kernel's LDS footprint admits 2 workgroups per CU at K = 12: give the
 // register allocator the matching budget instead of spilling at the 3-per-CU limit)
 __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) sweep_kernel(const KernelParams P) {
@@ -708,8 +756,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
   uint32_t next = tile + stride;
   bool has_next = next < P.tile_end;
   TileDesc dn = scalarise(P.tiles[has_next ? next : tile]);   // one descriptor ahead
-  TilePrefetch<K> f;
-  issue_tile_loads<LEARN, K>(P, d, t, f);
+  TilePrefetch<K, REC8> f;
+  issue_tile_loads<LEARN, K, REC8>(P, d, t, f);
   if (s_agg) {   // the first __syncthreads of the loop orders this before any use
     for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) s_agg[i] = 0;
   }
@@ -718,13 +766,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
     const VarPre pre = f.pre;
     double A = 0.0, B = 0.0;
     // tabulated terms (see issue_tile_loads): nothing to gather, nothing to multiply
-    const bool tabulated = !LEARN && P.edge_terms && (d.flags & (TILE_SIMPLE | TILE_INLINE2));   // workgroup-uniform
+    const bool tabulated = !REC8 && !LEARN && P.edge_terms && (d.flags & (TILE_SIMPLE | TILE_INLINE2));   // workgroup-uniform
     if (fits) {
       // gather the f32 sampling weight of every record this lane staged ...
+      EdgeRec rec[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) rec[k] = expand_record(f.rec[k]);
       float w[K];
       if (!tabulated) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) w[k] = P.w32[f.rec[k].wid];
+        for (int k = 0; k < K; ++k) w[k] = P.w32[rec[k].wid];
       } else {
 #pragma unroll
         for (int k = 0; k < K; ++k) w[k] = 0.0f;
@@ -735,31 +786,31 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
       // it and are never read
       // (TILE_TERMS2 staging keeps two vif records and the neighbour values per staged
       // record live: only instantiated for K <= 6; the host clears the flag for K = 12)
-      if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
+      if (!REC8 && K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
         LearnRec *s_lrec = (LearnRec *)s_edges;
         VifRec va[K], vb[K];
         if (d.flags & TILE_INLINE2) {   // workgroup-uniform
 #pragma unroll
-          for (int k = 0; k < K; ++k) decode_inline2(f.rec[k], d.v0 + edge_owner_lane(f.rec[k]), va[k], vb[k]);
+          for (int k = 0; k < K; ++k) decode_inline2(rec[k], d.v0 + edge_owner_lane(rec[k]), va[k], vb[k]);
         } else {
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            const bool bin = !(f.rec[k].packed & EDGE_PRESIGNED);
-            const VifRec *vp = P.vifs + (bin ? f.rec[k].aux : 0u);
+            const bool bin = !(rec[k].packed & EDGE_PRESIGNED);
+            const VifRec *vp = P.vifs + (bin ? rec[k].aux : 0u);
             va[k] = vp[0]; vb[k] = vp[1];
           }
         }
         uint32_t of[K], oe[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const uint32_t me = d.v0 + edge_owner_lane(f.rec[k]);
+          const uint32_t me = d.v0 + edge_owner_lane(rec[k]);
           const VifRec o = (va[k].vid == me) ? vb[k] : va[k];
           of[k] = P.assign_free[o.vid];
           oe[k] = P.assign_evid[o.vid];
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const EdgeRec r = f.rec[k];
+          const EdgeRec r = rec[k];
           LearnRec lr;
           lr.wid = r.wid; lr.packed = r.packed; lr.w = w[k]; lr.pad = 0;
           if (r.packed & EDGE_PRESIGNED) {
@@ -781,7 +832,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
           }
           s_lrec[t + k * BLOCK_THREADS] = lr;
         }
-      } else if (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)) {
+      } else if (!REC8 && K <= 6 && !LEARN && (d.flags & TILE_TERMS2)) {
         // inference, boolean tile with pre-signed and arity-2 records: evaluate every
         // record here.  Three batched phases so that a lane's K vif-pair loads, then its K
         // neighbour-assignment gathers, are all in flight together (inside the per-variable
@@ -792,10 +843,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
           // endpoint inline -- one neighbour gather per record is all that is left
           uint32_t other[K];
 #pragma unroll
-          for (int k = 0; k < K; ++k) other[k] = P.assign_evid[f.rec[k].packed];   // TabRec2::other
+          for (int k = 0; k < K; ++k) other[k] = P.assign_evid[rec[k].packed];   // TabRec2::other
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            const EdgeRec r = f.rec[k];
+            const EdgeRec r = rec[k];
             const double wf = u32x2_to_double(r.wid, r.aux);
             const uint32_t bits = float_to_bits(r.fval);
             EdgeTerms tt;
@@ -820,26 +871,26 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
         VifRec va[K], vb[K];
         if (d.flags & TILE_INLINE2) {   // workgroup-uniform
 #pragma unroll
-          for (int k = 0; k < K; ++k) decode_inline2(f.rec[k], d.v0 + edge_owner_lane(f.rec[k]), va[k], vb[k]);
+          for (int k = 0; k < K; ++k) decode_inline2(rec[k], d.v0 + edge_owner_lane(rec[k]), va[k], vb[k]);
         } else {
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            const bool bin = !(f.rec[k].packed & EDGE_PRESIGNED);
-            const VifRec *vp = P.vifs + (bin ? f.rec[k].aux : 0u);   // padded: always in bounds
+            const bool bin = !(rec[k].packed & EDGE_PRESIGNED);
+            const VifRec *vp = P.vifs + (bin ? rec[k].aux : 0u);   // padded: always in bounds
             va[k] = vp[0]; vb[k] = vp[1];
           }
         }
         uint32_t other[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const uint32_t me = d.v0 + edge_owner_lane(f.rec[k]);
+          const uint32_t me = d.v0 + edge_owner_lane(rec[k]);
           // the neighbour: the position that is not the owner (if both are the owner, any)
           const VifRec o = (va[k].vid == me) ? vb[k] : va[k];
           other[k] = P.assign_evid[o.vid];
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const EdgeRec r = f.rec[k];
+          const EdgeRec r = rec[k];
           const double wv = (double)w[k];
           EdgeTerms tt;
           if (r.packed & EDGE_PRESIGNED) {
@@ -860,7 +911,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
           s_terms[t + k * BLOCK_THREADS] = tt;
         }
         }
-      } else if (!LEARN && (d.flags & TILE_SIMPLE)) {
+      } else if (!LEARN && (REC8 || (d.flags & TILE_SIMPLE))) {
         // inference, all-unary tile: do the per-record arithmetic here, edge-parallel
         // and straight-line, and stage the two potential terms instead of the record:
         // t1 = w * (sign(hit) * f), t0 = w * (sign(miss) * f), the sign already folded
@@ -869,11 +920,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
         if (tabulated) {
           // the stream already holds these very products (build_terms_kernel): copy through
 #pragma unroll
-          for (int k = 0; k < K; ++k) s_edges[t + k * BLOCK_THREADS] = f.rec[k];
+          for (int k = 0; k < K; ++k) s_edges[t + k * BLOCK_THREADS] = rec[k];
         } else {
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            const EdgeRec r = f.rec[k];
+            const EdgeRec r = rec[k];
             const double wv = (double)w[k];
             EdgeTerms tt;
             tt.t1 = wv * (double)r.fval;                 // proposal hits
@@ -885,7 +936,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const uint32_t i = t + k * BLOCK_THREADS;
-          EdgeRec r = f.rec[k];
+          EdgeRec r = rec[k];
           if (LEARN) { s_w[i] = w[k]; } else { r.wid = float_to_bits(w[k]); }
           s_edges[i] = r;
         }
@@ -907,15 +958,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
     const TileDesc raw_nn = P.tiles[has_nn ? nn : tile];
     TileDesc dl = dn;
     if (!has_next) { dl.nedges = 0; dl.nrows = 0; dl.nv = 1; }
-    issue_tile_loads<LEARN, K>(P, dl, t, f);
+    issue_tile_loads<LEARN, K, REC8>(P, dl, t, f);
     // process the current tile out of LDS
     const bool pull = LEARN && fits && (d.flags & TILE_PULL) && !(P.flags & OPT_NO_PULL);   // uniform
     int delta = 0;
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
-      if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2))
+      if (!REC8 && K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2))
         learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B);
-      else if ((d.flags & TILE_SIMPLE) || (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)))
+      else if (REC8 || (d.flags & TILE_SIMPLE) || (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)))
         delta = process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B, pull);
       else
         process_variable<LEARN, WMODE, false>(P, T, d.v0 + t, pre, A, B);

@@ -81,5 +81,14 @@ inline void emu_load_tile_records(const dwx::EdgeRec *base, uint32_t nedges, uin
   }
 }
 #define DWX_LOAD_TILE_RECORDS(K, base, nedges, t, rec) emu_load_tile_records<K>(base, nedges, t, rec)
+template <int K>
+inline void emu_load_tile_records8(const dwx::EdgeRec8 *base, uint32_t nedges, uint32_t t,
+                                   dwx::EdgeRec8 (&rec)[K]) {
+  for (int k = 0; k < K; ++k) {
+    const uint32_t i = t + k * dwx::BLOCK_THREADS;
+    rec[k] = i < nedges ? base[i] : dwx::EdgeRec8{0u, 0.0f};
+  }
+}
+#define DWX_LOAD_TILE_RECORDS8(K, base, nedges, t, rec) emu_load_tile_records8<K>(base, nedges, t, rec)
 
 #endif

@@ -57,6 +57,24 @@ def test_synth_cfg4(lib):
                stepsize=0.01)
 
 
+@pytest.mark.parametrize("compact", [True, False])
+def test_all_unary_compact_records(lib, compact):
+    # all-unary graphs stream 8-byte records (EdgeRec8) by default: every sign class
+    # (+f/-f, f/0, f/f), negative and zero feature values, fixed weights, boolean and
+    # categorical owners -- and the same graph with 16-byte records
+    from randgraph import random_graph
+    for seed in (21, 22):
+        raw = random_graph(seed, V=90, F=400, W=9, max_arity=1, exact_fvals=True, with_domains=False)
+        raw.fac_feature_value[::17] = 0.0
+        run_parity(lib, raw, n_learn=5, n_infer=5, stepsize=0.1, learn_non_evidence=seed == 22,
+                   compile_opts=dict(no_compact_records=0 if compact else 1))
+        run_parity(lib, raw, n_learn=4, n_infer=4, stepsize=0.1, sample_evidence=True,
+                   compile_opts=dict(no_compact_records=0 if compact else 1, tile_vars=9, tile_edges=24,
+                                     tile_rows=12))
+    run_parity(lib, synthetic.cfg3(1500, n_weights=2000, seed=4), n_learn=4, n_infer=4,
+               compile_opts=dict(no_compact_records=0 if compact else 1))
+
+
 def test_small_tiles_and_giant_variable(lib):
     # tiny LDS budgets force ragged tiles and the direct-from-HBM path for
     # variables that do not fit one tile
