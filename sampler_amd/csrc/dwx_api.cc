@@ -106,6 +106,11 @@ struct dwx_sampler {
   unsigned persistent_blocks[2] = {1, 1};
   bool rec8 = false;                    // the graph streams 8-byte records (CompiledGraph::edges8)
   unsigned persistent_blocks8[2] = {1, 1};
+  // every tile that fits is TILE_PULL: a learning sweep with the pull gradient stages 16-byte
+  // terms only (no f32 weight array behind the records) -- smaller LDS, one more workgroup per CU
+  bool all_pull = false;
+  size_t lds_learn_pull = 0;
+  unsigned persistent_blocks_pull = 1;   // REC8 learning kernel at lds_learn_pull
   EdgeRec8 *d_edges8 = nullptr;
   double *d_row_truth = nullptr, *d_edge_fval64 = nullptr;
   EdgeRec *d_edges = nullptr;
@@ -172,8 +177,10 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   // persistent grid: as many workgroups as stay resident, each striding over tiles
   // all-unary graph: 8-byte record stream (a run on the terms table streams those instead)
   const bool rec8 = s->rec8 && !P.edge_terms;
-  const unsigned grid = std::min<unsigned>(t1 - t0, (rec8 ? s->persistent_blocks8 : s->persistent_blocks)[LEARN ? 1 : 0]);
-  const size_t lds = s->lds_bytes[LEARN ? 1 : 0];
+  const bool slim = LEARN && rec8 && s->all_pull && !(P.flags & OPT_NO_PULL);
+  const unsigned grid = std::min<unsigned>(t1 - t0, slim ? s->persistent_blocks_pull :
+                                           (rec8 ? s->persistent_blocks8 : s->persistent_blocks)[LEARN ? 1 : 0]);
+  const size_t lds = slim ? s->lds_learn_pull : s->lds_bytes[LEARN ? 1 : 0];
   if (rec8) {
     switch (s->stage_k) {
       case 3: rt::launch(sweep_kernel<LEARN, 3, false, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
@@ -864,11 +871,16 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       }
     }
     if (s->rec8) {
+      s->all_pull = true;
+      for (const TileDesc &td : c.tiles)
+        if (td.nrows <= c.rcap && td.nedges <= c.ecap && !(td.flags & TILE_PULL)) { s->all_pull = false; break; }
+      s->lds_learn_pull = s->lds_bytes[0];
       auto prepare8 = [&](auto infer, auto learn) {
         rt::allow_dynamic_lds(infer, s->lds_bytes[0]);
         rt::allow_dynamic_lds(learn, s->lds_bytes[1]);
         s->persistent_blocks8[0] = rt::resident_blocks(infer, BLOCK_THREADS, s->lds_bytes[0]);
         s->persistent_blocks8[1] = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_bytes[1]);
+        s->persistent_blocks_pull = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_learn_pull);
       };
       switch (s->stage_k) {
         case 3: prepare8(sweep_kernel<false, 3, false, true>, sweep_kernel<true, 3, false, true>); break;

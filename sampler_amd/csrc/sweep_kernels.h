@@ -767,6 +767,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
     double A = 0.0, B = 0.0;
     // tabulated terms (see issue_tile_loads): nothing to gather, nothing to multiply
     const bool tabulated = !REC8 && !LEARN && P.edge_terms && (d.flags & (TILE_SIMPLE | TILE_INLINE2));   // workgroup-uniform
+    // learning, pull-gradient tile (all-unary boolean, no gradient scatter): the compute
+    // phase needs only the records' potential terms, exactly as an inference sweep does
+    const bool pull = LEARN && tile_fits(P, d) && (d.flags & TILE_PULL) && !(P.flags & OPT_NO_PULL);   // uniform
     if (fits) {
       // gather the f32 sampling weight of every record this lane staged ...
       EdgeRec rec[K];
@@ -911,7 +914,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
           s_terms[t + k * BLOCK_THREADS] = tt;
         }
         }
-      } else if (!LEARN && (REC8 || (d.flags & TILE_SIMPLE))) {
+      } else if (LEARN ? pull : (REC8 || (d.flags & TILE_SIMPLE))) {
         // inference, all-unary tile: do the per-record arithmetic here, edge-parallel
         // and straight-line, and stage the two potential terms instead of the record:
         // t1 = w * (sign(hit) * f), t0 = w * (sign(miss) * f), the sign already folded
@@ -960,14 +963,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
     if (!has_next) { dl.nedges = 0; dl.nrows = 0; dl.nv = 1; }
     issue_tile_loads<LEARN, K, REC8>(P, dl, t, f);
     // process the current tile out of LDS
-    const bool pull = LEARN && fits && (d.flags & TILE_PULL) && !(P.flags & OPT_NO_PULL);   // uniform
     int delta = 0;
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
       if (!REC8 && K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2))
         learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B);
+      else if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
+        delta = process_variable<LEARN, W_TERMS, true>(P, T, d.v0 + t, pre, A, B, true);
       else if (REC8 || (d.flags & TILE_SIMPLE) || (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)))
-        delta = process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B, pull);
+        delta = process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B, false);
       else
         process_variable<LEARN, WMODE, false>(P, T, d.v0 + t, pre, A, B);
     }
