@@ -203,10 +203,12 @@ def main():
         # block (both chains); an inference launch visits the query variables only
         # (evidence is skipped, as in the reference, but still counted in vars/sec)
         Vq = int(graph.info.num_query_variables)
+        # config 3 is all-unary: its sweeps run sweep8_kernel (8-byte records) unless --wide-records
+        kern = "sweep_kernel" if args.wide_records else "sweep8_kernel"
         if ms_l >= ms_i:
-            kname, per_launch_ms, bpv, units = "sweep_kernel<LEARN=true>", ms_l / max(nl_l, 1), B_LEARN, V
+            kname, per_launch_ms, bpv, units = kern + "<LEARN=true>", ms_l / max(nl_l, 1), B_LEARN, V
         else:
-            kname, per_launch_ms, bpv, units = "sweep_kernel<LEARN=false>", ms_i / max(nl_i, 1), B_INFER, Vq
+            kname, per_launch_ms, bpv, units = kern + "<LEARN=false>", ms_i / max(nl_i, 1), B_INFER, Vq
         achieved = bpv * units / (per_launch_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")

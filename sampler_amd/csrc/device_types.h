@@ -129,7 +129,10 @@ constexpr uint32_t MAX_ECAP = BLOCK_THREADS * STAGE_UNROLL;  // 3072 records = 4
 // workgroup accumulates G/T in LDS and flushes once at the end.
 constexpr uint32_t LDS_AGG_MAX_W = 1024;
 constexpr uint32_t MAX_PLAN_BATCHES = 64;                    // mini-batches per colour launch, at most
-constexpr uint32_t PULL_RUN = 16;                           // incidence entries per lane
+#ifndef DWX_PULL_RUN
+#define DWX_PULL_RUN 16
+#endif
+constexpr uint32_t PULL_RUN = DWX_PULL_RUN;                  // incidence entries per lane
 constexpr uint32_t ROWPTR_UNROLL = 2;                       // row pointers prefetched per lane
 
 // Everything one sweep launch needs; passed by value.

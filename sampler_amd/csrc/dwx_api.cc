@@ -30,6 +30,10 @@
 
 #include "sweep_kernels.h"
 
+#ifndef DWX_PULL_GRID
+#define DWX_PULL_GRID 16u   // pull_grad_kernel workgroups per CU (grid-stride beyond)
+#endif
+
 using namespace dwx;
 
 namespace {
@@ -183,9 +187,9 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   const size_t lds = slim ? s->lds_learn_pull : s->lds_bytes[LEARN ? 1 : 0];
   if (rec8) {
     switch (s->stage_k) {
-      case 3: rt::launch(sweep_kernel<LEARN, 3, false, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
-      case 6: rt::launch(sweep_kernel<LEARN, 6, false, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
-      default: rt::launch(sweep_kernel<LEARN, 12, false, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      case 3: rt::launch(sweep8_kernel<LEARN, 3>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      case 6: rt::launch(sweep8_kernel<LEARN, 6>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      default: rt::launch(sweep8_kernel<LEARN, 12>, grid, BLOCK_THREADS, lds, s->stream, P); break;
     }
   } else if (LEARN && s->wide_learn) {
     switch (s->stage_k) {
@@ -617,7 +621,7 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
   if (pe > pb) {
     const uint32_t n = pe - pb;
     const unsigned chunk_sz = BLOCK_THREADS * PULL_RUN;
-    const unsigned grid = std::min<unsigned>((n + chunk_sz - 1) / chunk_sz, 256u * 16u);
+    const unsigned grid = std::min<unsigned>((n + chunk_sz - 1) / chunk_sz, 256u * DWX_PULL_GRID);
     rt::launch(pull_grad_kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)(L.d_inc_wid + pb),
                (const uint32_t *)(L.d_inc_slot + pb), (const float *)(L.d_inc_d + pb), n,
                (const unsigned long long *)s->d_delta, s->d_grad);
@@ -871,7 +875,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       }
     }
     if (s->rec8) {
-      s->all_pull = true;
+      s->all_pull = P.lds_agg_off == 0;   // (TILE_PULL implies it; a graph of oversized variables only has no such tile)
       for (const TileDesc &td : c.tiles)
         if (td.nrows <= c.rcap && td.nedges <= c.ecap && !(td.flags & TILE_PULL)) { s->all_pull = false; break; }
       s->lds_learn_pull = s->lds_bytes[0];
@@ -883,9 +887,9 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
         s->persistent_blocks_pull = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_learn_pull);
       };
       switch (s->stage_k) {
-        case 3: prepare8(sweep_kernel<false, 3, false, true>, sweep_kernel<true, 3, false, true>); break;
-        case 6: prepare8(sweep_kernel<false, 6, false, true>, sweep_kernel<true, 6, false, true>); break;
-        default: prepare8(sweep_kernel<false, 12, false, true>, sweep_kernel<true, 12, false, true>); break;
+        case 3: prepare8(sweep8_kernel<false, 3>, sweep8_kernel<true, 3>); break;
+        case 6: prepare8(sweep8_kernel<false, 6>, sweep8_kernel<true, 6>); break;
+        default: prepare8(sweep8_kernel<false, 12>, sweep8_kernel<true, 12>); break;
       }
     }
     rt::stream_sync(st);

@@ -197,6 +197,12 @@ DWX_DEV double u32x2_to_double(uint32_t lo, uint32_t hi) {
 }
 static_assert(sizeof(EdgeTerms) == sizeof(EdgeRec), "terms overlay the staged records");
 
+DWX_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+#ifndef DWX_WALK_BATCH
+#define DWX_WALK_BATCH 5
+#endif
+constexpr uint32_t WALK_BATCH = DWX_WALK_BATCH;   // staged terms read per step of a row walk
+
 struct TileView {
   const uint32_t *rowptr;  // indexed by (row - row_bias)
   uint32_t row_bias;
@@ -244,8 +250,17 @@ DWX_DEV double range_potential(const KernelParams &P, const TileView &T, uint32_
                                const uint32_t *assign, uint32_t me, uint32_t proposal) {
   double pot = 0.0;
   if (WMODE == W_TERMS) {
+    // WALK_BATCH LDS reads in flight per step instead of one dependent read per record; the
+    // additions stay sequential and in row order (a slot past the end re-reads the last
+    // record and adds +0.0, which changes nothing: a running sum is never -0.0)
     const EdgeTerms *terms = (const EdgeTerms *)T.edges;
-    for (uint32_t e = es; e < ee; ++e) pot += terms[e - T.edge_bias].t1;
+    for (uint32_t e = es; e < ee; e += WALK_BATCH) {
+      double t1[WALK_BATCH];
+#pragma unroll
+      for (uint32_t u = 0; u < WALK_BATCH; ++u) t1[u] = terms[umin(e + u, ee - 1) - T.edge_bias].t1;
+#pragma unroll
+      for (uint32_t u = 0; u < WALK_BATCH; ++u) pot += (e + u < ee) ? t1[u] : 0.0;
+    }
     return pot;
   }
   for (uint32_t e = es; e < ee; ++e) {
@@ -271,11 +286,17 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   pp = 0.0; pn = 0.0;
   if (WMODE == W_TERMS) {
-    const EdgeTerms *terms = (const EdgeTerms *)T.edges;
-    for (uint32_t e = es; e < ee; ++e) {
-      const EdgeTerms tt = terms[e - T.edge_bias];
-      pp += tt.t1;
-      pn += tt.t0;
+    const EdgeTerms *terms = (const EdgeTerms *)T.edges;   // batched as in range_potential
+    for (uint32_t e = es; e < ee; e += WALK_BATCH) {
+      EdgeTerms tt[WALK_BATCH];
+#pragma unroll
+      for (uint32_t u = 0; u < WALK_BATCH; ++u) tt[u] = terms[umin(e + u, ee - 1) - T.edge_bias];
+#pragma unroll
+      for (uint32_t u = 0; u < WALK_BATCH; ++u) {
+        const bool in = e + u < ee;
+        pp += in ? tt[u].t1 : 0.0;
+        pn += in ? tt[u].t0 : 0.0;
+      }
     }
     return;
   }
@@ -663,13 +684,10 @@ DWX_DEV EdgeRec expand_record(const EdgeRec8 &c) {
 }
 DWX_DEV EdgeRec expand_record(const EdgeRec &r) { return r; }
 
-template <bool REC8> struct StreamRec { typedef EdgeRec type; };
-template <> struct StreamRec<true> { typedef EdgeRec8 type; };
-
 // Everything a lane holds in registers for the tile it will stage next.
-template <int K, bool REC8>
+template <int K, class Rec = EdgeRec>
 struct TilePrefetch {
-  typename StreamRec<REC8>::type rec[K];
+  Rec rec[K];
   uint32_t rp[ROWPTR_UNROLL];
   VarPre pre;
 };
@@ -696,8 +714,6 @@ DWX_DEV bool tile_fits(const KernelParams &P, const TileDesc &d) {
   return d.nrows <= P.rcap && d.nedges <= P.ecap;
 }
 
-DWX_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
-
 // Branch-free on purpose: a predicated load compiles to a divergent branch with an
 // s_waitcnt vmcnt(0) behind it, which serialises the loads.  Every lane therefore
 // always loads -- out-of-range lanes get zero records from the buffer bounds check and
@@ -715,9 +731,9 @@ DWX_DEV void issue_record_loads(const KernelParams &P, const TileDesc &d, uint32
   DWX_LOAD_TILE_RECORDS8(K, P.edges8 + d.e0, d.nedges, t, rec);
 }
 
-template <bool LEARN, int K, bool REC8>
+template <bool LEARN, int K, class Rec>
 DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t t,
-                              TilePrefetch<K, REC8> &f) {
+                              TilePrefetch<K, Rec> &f) {
   issue_record_loads<LEARN, K>(P, d, t, f.rec);
 #pragma unroll
   for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k)
@@ -734,10 +750,7 @@ DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t
 // handled by giant_kernel.
 // WIDE (learning only): the graph has TILE_TERMS2 tiles; their records are staged as
 // 32-byte LearnRec (LDS doubles, one workgroup per CU, so registers are plentiful).
-// REC8: every tile of the graph is TILE_SIMPLE and the record stream is P.edges8 (8 bytes per
-// record; never launched with the terms table -- that run streams 16-byte terms through the
-// REC8 = false build).
-template <bool LEARN, int K, bool WIDE = false, bool REC8 = false>
+template <bool LEARN, int K, bool WIDE = false>
 // (the learning kernel's LDS footprint admits 2 workgroups per CU at K = 12: give the
 // register allocator the matching budget instead of spilling at the 3-per-CU limit)
 __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) sweep_kernel(const KernelParams P) {
@@ -756,8 +769,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
   uint32_t next = tile + stride;
   bool has_next = next < P.tile_end;
   TileDesc dn = scalarise(P.tiles[has_next ? next : tile]);   // one descriptor ahead
-  TilePrefetch<K, REC8> f;
-  issue_tile_loads<LEARN, K, REC8>(P, d, t, f);
+  TilePrefetch<K> f;
+  issue_tile_loads<LEARN, K>(P, d, t, f);
   if (s_agg) {   // the first __syncthreads of the loop orders this before any use
     for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) s_agg[i] = 0;
   }
@@ -766,15 +779,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
     const VarPre pre = f.pre;
     double A = 0.0, B = 0.0;
     // tabulated terms (see issue_tile_loads): nothing to gather, nothing to multiply
-    const bool tabulated = !REC8 && !LEARN && P.edge_terms && (d.flags & (TILE_SIMPLE | TILE_INLINE2));   // workgroup-uniform
+    const bool tabulated = !LEARN && P.edge_terms && (d.flags & (TILE_SIMPLE | TILE_INLINE2));   // workgroup-uniform
     // learning, pull-gradient tile (all-unary boolean, no gradient scatter): the compute
     // phase needs only the records' potential terms, exactly as an inference sweep does
     const bool pull = LEARN && tile_fits(P, d) && (d.flags & TILE_PULL) && !(P.flags & OPT_NO_PULL);   // uniform
     if (fits) {
       // gather the f32 sampling weight of every record this lane staged ...
-      EdgeRec rec[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) rec[k] = expand_record(f.rec[k]);
+      const EdgeRec (&rec)[K] = f.rec;
       float w[K];
       if (!tabulated) {
 #pragma unroll
@@ -789,7 +800,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
       // it and are never read
       // (TILE_TERMS2 staging keeps two vif records and the neighbour values per staged
       // record live: only instantiated for K <= 6; the host clears the flag for K = 12)
-      if (!REC8 && K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
+      if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
         LearnRec *s_lrec = (LearnRec *)s_edges;
         VifRec va[K], vb[K];
         if (d.flags & TILE_INLINE2) {   // workgroup-uniform
@@ -835,7 +846,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
           }
           s_lrec[t + k * BLOCK_THREADS] = lr;
         }
-      } else if (!REC8 && K <= 6 && !LEARN && (d.flags & TILE_TERMS2)) {
+      } else if (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)) {
         // inference, boolean tile with pre-signed and arity-2 records: evaluate every
         // record here.  Three batched phases so that a lane's K vif-pair loads, then its K
         // neighbour-assignment gathers, are all in flight together (inside the per-variable
@@ -914,7 +925,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
           s_terms[t + k * BLOCK_THREADS] = tt;
         }
         }
-      } else if (LEARN ? pull : (REC8 || (d.flags & TILE_SIMPLE))) {
+      } else if (LEARN ? pull : (bool)(d.flags & TILE_SIMPLE)) {
         // inference, all-unary tile: do the per-record arithmetic here, edge-parallel
         // and straight-line, and stage the two potential terms instead of the record:
         // t1 = w * (sign(hit) * f), t0 = w * (sign(miss) * f), the sign already folded
@@ -961,16 +972,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
     const TileDesc raw_nn = P.tiles[has_nn ? nn : tile];
     TileDesc dl = dn;
     if (!has_next) { dl.nedges = 0; dl.nrows = 0; dl.nv = 1; }
-    issue_tile_loads<LEARN, K, REC8>(P, dl, t, f);
+    issue_tile_loads<LEARN, K>(P, dl, t, f);
     // process the current tile out of LDS
     int delta = 0;
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
-      if (!REC8 && K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2))
+      if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2))
         learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B);
       else if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
         delta = process_variable<LEARN, W_TERMS, true>(P, T, d.v0 + t, pre, A, B, true);
-      else if (REC8 || (d.flags & TILE_SIMPLE) || (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)))
+      else if ((d.flags & TILE_SIMPLE) || (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)))
         delta = process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B, false);
       else
         process_variable<LEARN, WMODE, false>(P, T, d.v0 + t, pre, A, B);
@@ -982,6 +993,122 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
       if ((t & 63u) == 0) {
         unsigned long long *w = P.delta + ((size_t)tile * 4 + (t >> 6)) * 2;
         w[0] = nz; w[1] = ng;
+      }
+    }
+    if (!has_next) break;
+    __syncthreads();   // LDS is rewritten by the next iteration
+    d = dn;
+    dn = scalarise(raw_nn);
+    tile = next; next = nn; has_next = has_nn;
+  }
+  if (s_agg) {   // one flush per persistent workgroup
+    __syncthreads();
+    for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) {
+      const long long v = s_agg[i];
+      if (v) atomicAdd((unsigned long long *)&P.grad[i], (unsigned long long)v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- all-unary graphs
+// sweep8_kernel: the sweep of a graph whose EVERY tile is TILE_SIMPLE (all factors unary,
+// f32-exact feature values).  Same tiles, same pipeline, same LDS image and the same
+// per-variable code as sweep_kernel, but the record stream is P.edges8 (8 bytes per record:
+// half the stream, half the prefetch registers) and none of the non-unary variants exists.
+// Never launched with the terms table (that run streams 16-byte terms through sweep_kernel).
+//
+// What bounds it (config 3, 1 M weights): not HBM and not the L2 request rate but the CU's
+// vector L1 (TCP): every record costs one uncoalesced 4-byte gather that misses L1 -- a tile
+// of 2 560 records takes ~4.7 k cycles per CU when the table is L1-resident (1 000 weights)
+// and ~9.8 k when every gather goes to L2 (1 M weights), whatever the occupancy and however
+// early the gathers are issued (a two-tile-deep version of this loop, gathers of tile j+1
+// and records of tile j+2 in flight under the compute of tile j, ran 5 % SLOWER).
+template <bool LEARN, int K>
+__global__ void __launch_bounds__(BLOCK_THREADS, LEARN ? 2 : 3) sweep8_kernel(const KernelParams P) {
+  DWX_DYN_LDS(dyn_lds);
+  uint32_t *s_rowptr = (uint32_t *)dyn_lds;
+  double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
+  EdgeRec *s_edges = (EdgeRec *)(dyn_lds + P.lds_edge_off);
+  float *s_w = (float *)(dyn_lds + P.lds_w_off);
+  long long *s_agg = (LEARN && P.lds_agg_off) ? (long long *)(dyn_lds + P.lds_agg_off) : nullptr;
+  const uint32_t t = threadIdx.x;
+  uint32_t tile = P.tile_begin + blockIdx.x;
+  if (tile >= P.tile_end) return;
+  const uint32_t stride = gridDim.x;
+  TileDesc d = scalarise(P.tiles[tile]);
+  uint32_t next = tile + stride;
+  bool has_next = next < P.tile_end;
+  TileDesc dn = scalarise(P.tiles[has_next ? next : tile]);   // one descriptor ahead
+  TilePrefetch<K, EdgeRec8> f;
+  issue_tile_loads<LEARN, K>(P, d, t, f);
+  if (s_agg) {   // the first __syncthreads of the loop orders this before any use
+    for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) s_agg[i] = 0;
+  }
+  for (;;) {
+    const bool fits = tile_fits(P, d);   // workgroup-uniform
+    // learning, pull-gradient tile: the compute phase needs only the potential terms
+    const bool pull = LEARN && fits && (d.flags & TILE_PULL) && !(P.flags & OPT_NO_PULL);   // uniform
+    const VarPre pre = f.pre;
+    double A = 0.0, B = 0.0;
+    if (fits) {
+      // the f32 sampling weight of every record this lane stages (a zero-filled lane past
+      // the tile's end gathers w32[0]: one cached line) ...
+      float w[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) w[k] = P.w32[f.rec[k].key & REC8_WID_MASK];
+      // ... and this lane's uniforms while the gathers are in flight
+      philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
+      if (!LEARN || pull) {
+        // the two potential terms of every record, edge-parallel and straight-line:
+        // t1 = w * (sign(hit) * f), t0 = w * (sign(miss) * f) -- the products of
+        // FactorGraph::potential (src/factor_graph.h:127-145)
+        EdgeTerms *s_terms = (EdgeTerms *)s_edges;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const EdgeRec8 c = f.rec[k];
+          const double wv = (double)w[k];
+          EdgeTerms tt;
+          tt.t1 = wv * (double)rec8_signed((c.key >> REC8_HIT_SHIFT) & 3u, c.f);
+          tt.t0 = wv * (double)rec8_signed((c.key >> REC8_MISS_SHIFT) & 3u, c.f);
+          s_terms[t + k * BLOCK_THREADS] = tt;
+        }
+      } else {
+        // learning with a gradient scatter: the records in their 16-byte form + f32 weights
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const uint32_t i = t + k * BLOCK_THREADS;
+          s_w[i] = w[k];
+          s_edges[i] = expand_record(f.rec[k]);
+        }
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k) s_rowptr[t + k * BLOCK_THREADS] = f.rp[k];
+      for (uint32_t i = t + ROWPTR_UNROLL * BLOCK_THREADS; i <= d.nrows; i += BLOCK_THREADS)
+        s_rowptr[i] = P.row_ptr[d.r0 + i];
+      __syncthreads();
+    }
+    // prefetch, unconditionally and branch-free (see sweep_kernel): the descriptor two tiles
+    // ahead, then the next tile's records / row pointers / variable inputs
+    const uint32_t nn = next + stride;
+    const bool has_nn = has_next && nn < P.tile_end;
+    const TileDesc raw_nn = P.tiles[has_nn ? nn : tile];
+    TileDesc dl = dn;
+    if (!has_next) { dl.nedges = 0; dl.nrows = 0; dl.nv = 1; }
+    issue_tile_loads<LEARN, K>(P, dl, t, f);
+    // the current tile out of LDS
+    int delta = 0;
+    if (fits && t < d.nv) {
+      TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
+      if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
+        delta = process_variable<LEARN, W_TERMS, true>(P, T, d.v0 + t, pre, A, B, true);
+      else
+        process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B, false);
+    }
+    if (pull) {
+      const unsigned long long nz = DWX_BALLOT(delta != 0), ng = DWX_BALLOT(delta < 0);
+      if ((t & 63u) == 0) {
+        unsigned long long *wd = P.delta + ((size_t)tile * 4 + (t >> 6)) * 2;
+        wd[0] = nz; wd[1] = ng;
       }
     }
     if (!has_next) break;

@@ -13,7 +13,8 @@ import numpy as np
 from .rawgraph import GraphDesc, RawGraph
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libdwx.so")
+# DWX_LIB: another build of the same library (kernel experiments, tools/variant.sh)
+LIB_PATH = os.environ.get("DWX_LIB") or os.path.join(HERE, "csrc", "libdwx.so")
 
 DWX_OK, DWX_E_INVALID, DWX_E_LIMIT, DWX_E_DEVICE, DWX_E_NOMEM = 0, -1, -2, -3, -4
 BUF_WEIGHTS, BUF_GRAD, BUF_ASSIGN_FREE, BUF_ASSIGN_EVID, BUF_TALLIES, BUF_TSTATIC, BUF_TSTATIC_PLAN = range(7)

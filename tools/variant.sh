@@ -1,0 +1,12 @@
+#!/bin/bash
+# tools/variant.sh NAME [-DFLAG=VALUE ...] -- build sampler_amd/csrc/variants/NAME.so, a copy of
+# libdwx.so compiled with extra flags (kernel A/B experiments).  Use it with DWX_LIB=<path>.
+set -e
+cd "$(dirname "$0")/../sampler_amd/csrc"
+name=$1; shift
+mkdir -p variants
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function \
+  "$@" -x hip -c -o variants/$name.o dwx_api.cc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/$name.so variants/$name.o graph_compile.o -pthread
+rm -f variants/$name.o
+echo "built sampler_amd/csrc/variants/$name.so"
