@@ -133,6 +133,18 @@ constexpr uint32_t MAX_PLAN_BATCHES = 64;                    // mini-batches per
 #define DWX_PULL_RUN 16
 #endif
 constexpr uint32_t PULL_RUN = DWX_PULL_RUN;                  // incidence entries per lane
+// Block pull (pull_ell_kernel, un-split sweeps of graphs with many weights): the incidence
+// list as a table of BP_ROW * depth entries per (variable block, weight); a block's ballot
+// pairs live in LDS.  Entry: bits 0-18 slot inside the block ((tile - first tile) * 256 +
+// lane), bits 19-30 index into the table of distinct record deltas; BP_EMPTY = no entry.
+constexpr uint32_t BP_THREADS = 1024;
+constexpr uint32_t BP_TILES = 2048;               // tiles per variable block: 128 KiB of ballot pairs
+constexpr uint32_t BP_ROW = 4;                    // entries per 16-byte row
+constexpr uint32_t BP_SLOT_BITS = 19, BP_SLOT_MASK = (1u << BP_SLOT_BITS) - 1;
+constexpr uint32_t BP_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t BP_DELTA_SLOTS = 4096, BP_MAX_DELTAS = BP_DELTA_SLOTS - 1;   // (the last slot stays 0: BP_EMPTY decodes to it)
+// one block of ballot pairs + the table of deltas: exactly the 160 KiB of a CU
+constexpr uint32_t BP_LDS_BYTES = BP_TILES * 64 + BP_DELTA_SLOTS * 8;
 constexpr uint32_t ROWPTR_UNROLL = 2;                       // row pointers prefetched per lane
 
 // Everything one sweep launch needs; passed by value.

@@ -141,7 +141,16 @@ struct dwx_sampler {
     std::vector<uint32_t> inc_begin, inc_end;   // per chunk, entries (multiples of PULL_RUN)
     long long *d_t_static = nullptr;
     uint32_t rows = 0;
-    ~Level() { rt::dfree(d_inc_wid); rt::dfree(d_inc_slot); rt::dfree(d_inc_d); rt::dfree(d_t_static); }
+    // block pull (pull_ell_kernel; un-split level of a graph with many weights): entry rows
+    // per (variable block, weight); d_inc_* then only holds what did not fit a row
+    U32x4 *d_bp_ell = nullptr;
+    uint32_t *d_bp_tile0 = nullptr;
+    long long *d_bp_qtab = nullptr, *d_bp_partial = nullptr;   // partial: [blocks][Wp] sums
+    uint32_t bp_blocks = 0, bp_depth = 0, bp_parts = 0, bp_deltas = 0, bp_wp = 0;
+    ~Level() {
+      rt::dfree(d_inc_wid); rt::dfree(d_inc_slot); rt::dfree(d_inc_d); rt::dfree(d_t_static);
+      rt::dfree(d_bp_ell); rt::dfree(d_bp_tile0); rt::dfree(d_bp_qtab); rt::dfree(d_bp_partial);
+    }
   };
   std::map<uint32_t, std::unique_ptr<Level>> levels;
   Level *plan_level = nullptr;        // level of the current plan
@@ -372,8 +381,134 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
     const uint64_t n_inc = by_w.size();
     if (n_inc + (uint64_t)nc * PULL_RUN >= 0xFFFFFFFFull)
       throw std::invalid_argument("incidence list exceeds 2^32-1 entries");
+    // Block pull (un-split sweeps, many weights): rows of BP_ROW * depth entries per (variable
+    // block, weight) for pull_ell_kernel; an entry beyond its row stays on the list below.
+    RawArray<Inc> overflow;
+    bool block_pull = false;
+    {
+      uint64_t min_w = 262144, bp_tiles = BP_TILES;
+      if (const char *e = getenv("DWX_BLOCK_PULL_MIN_W")) min_w = (uint64_t)std::max(0L, atol(e));          // test hooks
+      if (const char *e = getenv("DWX_BLOCK_PULL_TILES")) bp_tiles = (uint64_t)std::min<long>(BP_TILES, std::max(1L, atol(e)));
+      const bool bp_timing = getenv("DWX_TIMING") != nullptr;
+      auto bp_t0 = std::chrono::steady_clock::now();
+      auto bp_phase = [&](const char *what) {
+        if (!bp_timing) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[dwx block pull] %-22s %.3f s\n", what, std::chrono::duration<double>(t - bp_t0).count());
+        bp_t0 = t;
+      };
+      if (batches == 1 && n_inc && c.W >= min_w) {
+        // (1) blocks: runs of <= bp_tiles consecutive tiles, started at tiles that own entries
+        std::vector<uint8_t> has(c.tiles.size(), 0);
+        parallel_ranges(n_inc, nth, [&](uint64_t b, uint64_t e) {
+          for (uint64_t i = b; i < e; ++i) {   // (test first: the flags are shared by all threads)
+            uint8_t &h = has[by_w[i].slot / BLOCK_THREADS];
+            if (!h) h = 1;
+          }
+        });
+        std::vector<uint32_t> tile0, block_of(c.tiles.size(), 0);
+        for (uint32_t ti = 0; ti < c.tiles.size(); ++ti) {
+          if (!has[ti]) continue;
+          if (tile0.empty() || ti >= tile0.back() + bp_tiles) tile0.push_back(ti);
+          block_of[ti] = (uint32_t)tile0.size() - 1;
+        }
+        const uint64_t nvb = tile0.size();
+        bp_phase("blocks");
+        // (2) the distinct record deltas (few: feature values repeat), as fixed-point steps
+        std::vector<uint32_t> dvals;
+        {
+          const uint32_t T = (uint32_t)std::min<uint64_t>(nth, std::max<uint64_t>(1, n_inc / 65536));
+          std::vector<std::vector<uint32_t>> local(std::max(1u, T));
+          parallel_parts(n_inc, std::max(1u, T), [&](uint32_t t, uint64_t b, uint64_t e) {
+            std::vector<uint32_t> &v = local[t];
+            uint32_t last = 0; bool have = false;
+            for (uint64_t i = b; i < e && v.size() <= 4 * BP_MAX_DELTAS; ++i) {
+              uint32_t bits; std::memcpy(&bits, &by_w[i].d, 4);
+              if (have && bits == last) continue;
+              last = bits; have = true;
+              v.push_back(bits);
+              if (v.size() % 4096 == 0) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+            }
+            std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
+          }, 0);
+          for (auto &v : local) dvals.insert(dvals.end(), v.begin(), v.end());
+          std::sort(dvals.begin(), dvals.end()); dvals.erase(std::unique(dvals.begin(), dvals.end()), dvals.end());
+        }
+        bp_phase("distinct deltas");
+        if (nvb && dvals.size() <= BP_MAX_DELTAS) {
+          block_pull = true;
+          const double lambda = (double)n_inc / ((double)c.W * (double)nvb);
+          const uint32_t depth = lambda > 3.2 ? 2u : 1u, cap = BP_ROW * depth;
+          const uint64_t Wp = (c.W + BP_THREADS - 1) / BP_THREADS * BP_THREADS;
+          RawArray<U32x4> ell(nvb * depth * Wp);
+          parallel_ranges(ell.size(), nth, [&](uint64_t b, uint64_t e) { std::memset((void *)(ell.data() + b), 0xFF, (e - b) * sizeof(U32x4)); });
+          bp_phase("table clear");
+          auto code_of = [&](const Inc &r) -> uint32_t {
+            uint32_t bits; std::memcpy(&bits, &r.d, 4);
+            const uint32_t di = (uint32_t)(std::lower_bound(dvals.begin(), dvals.end(), bits) - dvals.begin());
+            const uint32_t ti = r.slot / BLOCK_THREADS, lane = r.slot % BLOCK_THREADS;
+            return ((ti - tile0[block_of[ti]]) * BLOCK_THREADS + lane) | (di << BP_SLOT_BITS);
+          };
+          // entries of one weight come in tile order (stable sort): blocks in ascending order
+          std::vector<uint64_t> ov_start(c.W + 1, 0);
+          for (int pass = 0; pass < 2; ++pass) {
+            parallel_ranges(c.W, nth, [&](uint64_t wb, uint64_t we) {
+              for (uint64_t w = wb; w < we; ++w) {
+                uint32_t cur = ~0u, k = 0;
+                uint64_t o = pass == 0 ? 0 : ov_start[w];
+                for (uint64_t i = w_start[w]; i < w_start[w + 1]; ++i) {
+                  const Inc &r = by_w[i];
+                  const uint32_t vb = block_of[r.slot / BLOCK_THREADS];
+                  if (vb != cur) { cur = vb; k = 0; }
+                  if (k < cap) {
+                    if (pass == 0) ell[((uint64_t)vb * depth + k / BP_ROW) * Wp + w].v[k % BP_ROW] = code_of(r);
+                  } else if (pass == 0) {
+                    ++o;
+                  } else {
+                    Inc q = r; q.chunk = 0;
+                    overflow[o++] = q;
+                  }
+                  ++k;
+                }
+                if (pass == 0) ov_start[w + 1] = o;   // (count; prefix-summed below)
+              }
+            });
+            if (pass == 0) {
+              ov_start[0] = 0;
+              for (uint64_t w = 0; w < c.W; ++w) ov_start[w + 1] += ov_start[w];
+              overflow.reset(ov_start[c.W]);
+            }
+          }
+          bp_phase("table fill");
+          std::vector<long long> qtab(dvals.size());
+          for (size_t i = 0; i < dvals.size(); ++i) {
+            float d; std::memcpy(&d, &dvals[i], 4);
+            qtab[i] = std::llrint(FIX_SCALE * (double)d);
+          }
+          L->d_bp_ell = upload_raw(ell.data(), ell.size(), s->stream);
+          L->d_bp_tile0 = upload(tile0, s->stream);
+          L->d_bp_qtab = upload(qtab, s->stream);
+          L->d_bp_partial = (long long *)rt::dmalloc(nvb * Wp * 8);
+          L->bp_blocks = (uint32_t)nvb; L->bp_depth = depth; L->bp_deltas = (uint32_t)dvals.size(); L->bp_wp = (uint32_t)Wp;
+          // parts per block: one workgroup per CU over all blocks (it owns the CU's whole LDS)
+          L->bp_parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(rt::cu_count() / nvb, Wp / BP_THREADS));
+          rt::allow_dynamic_lds(pull_ell_kernel<1>, BP_LDS_BYTES);
+          rt::allow_dynamic_lds(pull_ell_kernel<2>, BP_LDS_BYTES);
+          rt::stream_sync(s->stream);   // ell dies with this scope
+          bp_phase("upload");
+          if (getenv("DWX_TIMING"))
+            fprintf(stderr, "[dwx block pull] %llu blocks x depth %u, %zu deltas, %llu of %llu entries on the list\n",
+                    (unsigned long long)nvb, depth, dvals.size(), (unsigned long long)overflow.size(),
+                    (unsigned long long)n_inc);
+        }
+      }
+    }
     const RawArray<Inc> *src = &by_w;
-    if (nc > 1) {
+    if (block_pull) {
+      by_w.clear();
+      src = &overflow;
+      c_start = {0, overflow.size()};
+    } else if (nc > 1) {
       parallel_group_by_key<Inc>(
           n_inc, nth, nc, [](const Inc &r) { return (uint64_t)r.chunk; },
           [&](uint64_t b, uint64_t e, auto &&emit) { for (uint64_t i = b; i < e; ++i) emit(by_w[i]); },
@@ -618,6 +753,21 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
     if (!split) { if (chunk + 1 == s->plan_chunks.size()) { pb = L.inc_begin.front(); pe = L.inc_end.back(); } }
     else { pb = L.inc_begin[chunk]; pe = L.inc_end[chunk]; }
   }
+  if (L.fast && L.bp_blocks && !split && chunk + 1 == s->plan_chunks.size()) {
+    const unsigned grid = L.bp_blocks * L.bp_parts;
+    if (L.bp_depth == 2)
+      rt::launch(pull_ell_kernel<2>, grid, BP_THREADS, BP_LDS_BYTES, s->stream, (const U32x4 *)L.d_bp_ell,
+                 (const uint32_t *)L.d_bp_tile0, L.bp_parts, (const long long *)L.d_bp_qtab, L.bp_deltas, L.bp_wp,
+                 (const unsigned long long *)s->d_delta, L.d_bp_partial);
+    else
+      rt::launch(pull_ell_kernel<1>, grid, BP_THREADS, BP_LDS_BYTES, s->stream, (const U32x4 *)L.d_bp_ell,
+                 (const uint32_t *)L.d_bp_tile0, L.bp_parts, (const long long *)L.d_bp_qtab, L.bp_deltas, L.bp_wp,
+                 (const unsigned long long *)s->d_delta, L.d_bp_partial);
+    const uint32_t W = (uint32_t)s->cg->W;
+    rt::launch(fold_partials_kernel, std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 4096u), BLOCK_THREADS, 0,
+               s->stream, (const long long *)L.d_bp_partial, L.bp_blocks, L.bp_wp, W, s->d_grad);
+    pulled = true;
+  }
   if (pe > pb) {
     const uint32_t n = pe - pb;
     const unsigned chunk_sz = BLOCK_THREADS * PULL_RUN;
@@ -811,8 +961,10 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       std::vector<float> w32(c.W);
       for (uint64_t i = 0; i < c.W; ++i) w32[i] = (float)c.w_init[i];
       s->d_w32 = upload(w32, st, 1);
-      s->d_delta = (unsigned long long *)rt::dmalloc((c.tiles.size() * 8 + 2) * 8);
-      rt::dmemset(s->d_delta, 0, (c.tiles.size() * 8 + 2) * 8, st);
+      // (+ one variable block of padding: pull_ell_kernel copies whole blocks)
+      const size_t n_delta = c.tiles.size() * 8 + 2 + (size_t)BP_TILES * 8;
+      s->d_delta = (unsigned long long *)rt::dmalloc(n_delta * 8);
+      rt::dmemset(s->d_delta, 0, n_delta * 8, st);
     }
     s->d_w_fixed = upload(c.w_fixed, st);
     s->d_grad = (long long *)rt::dmalloc(c.W * 16);

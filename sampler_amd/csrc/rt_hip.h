@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 
@@ -86,6 +87,13 @@ inline unsigned resident_blocks(K kernel, unsigned block, size_t lds) {
   DWX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block, lds));
   if (per_cu < 1) per_cu = 1;
   return (unsigned)(cus * per_cu);
+}
+
+inline unsigned cu_count() {
+  int dev = 0, cus = 0;
+  DWX_HIP(hipGetDevice(&dev));
+  DWX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  return (unsigned)std::max(1, cus);
 }
 
 template <class K, class... A>

@@ -1282,6 +1282,68 @@ pull_grad_kernel(const uint32_t *inc_wid, const uint32_t *inc_slot, const float 
   }
 }
 
+// Block pull: the same sums as pull_grad_kernel without its random L2 gathers and with no
+// atomics at all.  The owners of the incidence entries are cut into blocks of <= BP_TILES
+// consecutive tiles whose ballot pairs (128 KiB) fit LDS; ell holds, per block and weight,
+// BP_ROW * DEPTH entries (host: build_level; what does not fit a row goes through
+// pull_grad_kernel).  Workgroup (block b, part p) copies b's ballots into LDS once, then
+// streams its share of b's rows -- coalesced 16-byte loads, independent iterations, no
+// barrier -- and stores one partial sum per weight; fold_partials_kernel adds the blocks'
+// partials into grad.  Integer sums: the result equals pull_grad_kernel's.
+template <int DEPTH>
+__global__ void __launch_bounds__(BP_THREADS)
+pull_ell_kernel(const U32x4 *ell, const uint32_t *block_tile0, uint32_t parts, const long long *qtab,
+                uint32_t n_deltas, uint32_t Wp, const unsigned long long *delta, long long *partial) {
+  DWX_DYN_LDS(dyn_lds);
+  DeltaPair *s_delta = (DeltaPair *)dyn_lds;
+  constexpr uint32_t PAIRS = BP_TILES * 4;                 // ballot pairs per block
+  // the deltas' fixed-point steps live in LDS too (a dependent global load inside the loop
+  // would wait for every load issued before it: vmcnt retires in order)
+  long long *s_q = (long long *)(dyn_lds + PAIRS * sizeof(DeltaPair));
+  const uint32_t tid = threadIdx.x;
+  const uint32_t b = blockIdx.x / parts, part = blockIdx.x % parts;
+  const DeltaPair *src = (const DeltaPair *)delta + (size_t)block_tile0[b] * 4;   // (padded allocation)
+  for (uint32_t i = tid; i < PAIRS; i += BP_THREADS) s_delta[i] = src[i];
+  for (uint32_t i = tid; i < BP_DELTA_SLOTS; i += BP_THREADS) s_q[i] = i < n_deltas ? qtab[i] : 0;
+  __syncthreads();
+  // this part's weights: whole groups of BP_THREADS
+  const uint32_t groups = Wp / BP_THREADS, per = (groups + parts - 1) / parts;
+  const uint32_t g0 = part * per, g1 = g0 + per < groups ? g0 + per : groups;
+  const U32x4 *rows = ell + (size_t)b * DEPTH * Wp;
+  long long *out = partial + (size_t)b * Wp;
+#pragma unroll 4
+  for (uint32_t g = g0; g < g1; ++g) {
+    const uint32_t w = g * BP_THREADS + tid;
+    long long acc = 0;
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) {
+      const U32x4 row = rows[(size_t)dd * Wp + w];
+#pragma unroll
+      for (uint32_t k = 0; k < BP_ROW; ++k) {
+        // branch-free: an empty entry decodes to the block's last slot and to a zero step
+        const uint32_t e = row.v[k];
+        const uint32_t slot = e & BP_SLOT_MASK;
+        const DeltaPair dp = s_delta[slot >> 6];
+        const long long q = s_q[(e >> BP_SLOT_BITS) & (BP_DELTA_SLOTS - 1)];
+        const bool nz = (dp.nz >> (slot & 63u)) & 1ull, ng = (dp.ng >> (slot & 63u)) & 1ull;
+        acc += nz ? (ng ? -q : q) : 0;
+      }
+    }
+    out[w] = acc;
+  }
+}
+
+// grad[w] += sum over blocks of partial[block][w]
+__global__ void __launch_bounds__(BLOCK_THREADS)
+fold_partials_kernel(const long long *partial, uint32_t n_blocks, uint32_t Wp, uint32_t W, long long *grad) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < W; w += stride) {
+    long long acc = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) acc += partial[(size_t)b * Wp + w];
+    if (acc) grad[w] += acc;
+  }
+}
+
 // Batched InferenceResult::update_weight (src/inference_result.h:66-85): apply one
 // mini-batch's accumulated gradient to every non-fixed weight that received updates,
 // then clear the accumulators.  T = dynamic counts (atomics) + static counts (boolean

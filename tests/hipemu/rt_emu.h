@@ -43,6 +43,8 @@ inline void allow_dynamic_lds(K, size_t) {}
 template <class K>
 inline unsigned resident_blocks(K, unsigned, size_t) { return 3; }
 
+inline unsigned cu_count() { return 5; }
+
 template <class K, class... A>
 inline void launch(K kernel, unsigned grid, unsigned block, size_t lds, stream_t, A... args) {
   emu::run_grid(grid, block, lds, [&]() { kernel(args...); });

@@ -75,6 +75,22 @@ def test_all_unary_compact_records(lib, compact):
                compile_opts=dict(no_compact_records=0 if compact else 1))
 
 
+@pytest.mark.parametrize("block_tiles, depth_hint", [(8, 1), (32, 2), (1024, 2)])
+def test_block_pull(lib, monkeypatch, block_tiles, depth_hint):
+    # pull_ell_kernel (un-split sweeps of graphs with many weights; here forced onto a small
+    # graph): several variable blocks, one- and two-row tables, entries that overflow onto the
+    # list of pull_grad_kernel, mixed deltas (2f, f, -f ...), fixed weights
+    from randgraph import random_graph
+    monkeypatch.setenv("DWX_BLOCK_PULL_MIN_W", "0")
+    monkeypatch.setenv("DWX_BLOCK_PULL_TILES", str(block_tiles))
+    run_parity(lib, synthetic.cfg3(6000, n_weights=1100, seed=14), n_learn=4, n_infer=2, step_cap=0.0,
+               compile_opts=dict(tile_vars=32))
+    raw = random_graph(31, V=700, F=9000, W=1500, p_cat=0.0, max_arity=1, exact_fvals=True, with_domains=False)
+    run_parity(lib, raw, n_learn=4, n_infer=2, stepsize=0.02, step_cap=0.0, compile_opts=dict(tile_vars=16))
+    run_parity(lib, raw, n_learn=3, n_infer=1, stepsize=0.02, step_cap=0.0, learn_non_evidence=True,
+               compile_opts=dict(tile_vars=16, no_compact_records=1))
+
+
 def test_small_tiles_and_giant_variable(lib):
     # tiny LDS budgets force ragged tiles and the direct-from-HBM path for
     # variables that do not fit one tile
