@@ -254,6 +254,7 @@ DWX_DEV double range_potential(const KernelParams &P, const TileView &T, uint32_
     // additions stay sequential and in row order (a slot past the end re-reads the last
     // record and adds +0.0, which changes nothing: a running sum is never -0.0)
     const EdgeTerms *terms = (const EdgeTerms *)T.edges;
+    if (ee - es == 1u) return pot + terms[es - T.edge_bias].t1;   // (one read; the usual categorical row)
     for (uint32_t e = es; e < ee; e += WALK_BATCH) {
       double t1[WALK_BATCH];
 #pragma unroll
@@ -345,16 +346,41 @@ DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row
     // traffic.  (Not instantiated for the generic factor code: 8 inlined copies of it
     // would bloat the kernel far beyond the instruction cache.)
     double pot[SMALL_CARD];
-    uint32_t es = T.rowptr[row0 - T.row_bias];
     double m = -1e300;
+    if (WMODE == W_TERMS) {
+      // staged terms: all row pointers first, then the k-th term of EVERY row together (the
+      // rows are independent sums; each stays sequential in k) -- SMALL_CARD LDS reads in
+      // flight instead of a dependent pointer + term read per value
+      uint32_t rp[SMALL_CARD + 1];
 #pragma unroll
-    for (uint32_t d = 0; d < SMALL_CARD; ++d) {
-      pot[d] = -1e300;
-      if (d < card) {
-        const uint32_t ee = T.rowptr[row0 + d + 1 - T.row_bias];
-        pot[d] = range_potential<WMODE, SIMPLE>(P, T, es, ee, assign, me, d);
-        es = ee;
+      for (uint32_t d = 0; d <= SMALL_CARD; ++d) rp[d] = T.rowptr[row0 + umin(d, card) - T.row_bias];
+      uint32_t maxlen = 0;
+#pragma unroll
+      for (uint32_t d = 0; d < SMALL_CARD; ++d) { pot[d] = 0.0; maxlen = rp[d + 1] - rp[d] > maxlen ? rp[d + 1] - rp[d] : maxlen; }
+      const EdgeTerms *terms = (const EdgeTerms *)T.edges;
+      for (uint32_t k = 0; k < maxlen; ++k) {
+        double t1[SMALL_CARD];
+#pragma unroll
+        for (uint32_t d = 0; d < SMALL_CARD; ++d) t1[d] = terms[umin(rp[d] + k, rp[SMALL_CARD] - 1) - T.edge_bias].t1;
+#pragma unroll
+        for (uint32_t d = 0; d < SMALL_CARD; ++d) pot[d] += (rp[d] + k < rp[d + 1]) ? t1[d] : 0.0;
+      }
+#pragma unroll
+      for (uint32_t d = 0; d < SMALL_CARD; ++d) {
+        if (d >= card) pot[d] = -1e300;
         m = pot[d] > m ? pot[d] : m;
+      }
+    } else {
+      uint32_t es = T.rowptr[row0 - T.row_bias];
+#pragma unroll
+      for (uint32_t d = 0; d < SMALL_CARD; ++d) {
+        pot[d] = -1e300;
+        if (d < card) {
+          const uint32_t ee = T.rowptr[row0 + d + 1 - T.row_bias];
+          pot[d] = range_potential<WMODE, SIMPLE>(P, T, es, ee, assign, me, d);
+          es = ee;
+          m = pot[d] > m ? pot[d] : m;
+        }
       }
     }
     float ex[SMALL_CARD];
