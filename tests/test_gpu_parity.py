@@ -233,6 +233,36 @@ def test_split_sweep_with_pull_tiles_and_static_counts(lib, monkeypatch):
     E.test_split_sweep_with_pull_tiles_and_static_counts(lib, monkeypatch)
 
 
+@pytest.mark.parametrize("compact", [True, False])
+def test_all_unary_compact_records(lib, compact):
+    import test_kernels_emu as E
+    E.test_all_unary_compact_records(lib, compact)
+
+
+@pytest.mark.parametrize("block_tiles, depth_hint", [(8, 1), (32, 2), (2048, 2)])
+def test_block_pull(lib, monkeypatch, block_tiles, depth_hint):
+    import test_kernels_emu as E
+    E.test_block_pull(lib, monkeypatch, block_tiles, depth_hint)
+
+
+def test_block_pull_at_size_equals_list_pull_and_oracle(lib, monkeypatch):
+    # 2 M variables, 300 k weights: the block pull engages on its own (>= 262 144 weights);
+    # several variable blocks, two-row tables, entries left on the list.  Exact against the
+    # oracle, and bit-identical to the same run with the block pull switched off.
+    raw = synthetic.cfg3(2_000_000, n_weights=300_000, seed=21)
+    s, _ = run_parity(lib, raw, n_learn=3, n_infer=1, stepsize=0.01, step_cap=0.0, check_index=False)
+    w_block = s.weights.copy()
+    monkeypatch.setenv("DWX_BLOCK_PULL_MIN_W", str(10**9))
+    g = dwx.Graph(raw, lib=lib)
+    s2 = dwx.GibbsSampler(g, device=0, seed=77, reg_param=0.01, step_cap=0.0)
+    cur = 0.01
+    for _ in range(3):
+        s2.sample_sgd(cur); cur *= 0.9
+    s2.wait()
+    assert np.array_equal(s2.weights, w_block)
+    assert np.abs(w_block).max() > 0
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_binary_factor_tiles_all_functions(lib, seed):
     from randgraph import random_graph
