@@ -141,15 +141,21 @@ struct dwx_sampler {
     std::vector<uint32_t> inc_begin, inc_end;   // per chunk, entries (multiples of PULL_RUN)
     long long *d_t_static = nullptr;
     uint32_t rows = 0;
-    // block pull (pull_ell_kernel; un-split level of a graph with many weights): entry rows
-    // per (variable block, weight); d_inc_* then only holds what did not fit a row
-    U32x4 *d_bp_ell = nullptr;
-    uint32_t *d_bp_tile0 = nullptr;
-    long long *d_bp_qtab = nullptr, *d_bp_partial = nullptr;   // partial: [blocks][Wp] sums
-    uint32_t bp_blocks = 0, bp_depth = 0, bp_parts = 0, bp_deltas = 0, bp_wp = 0;
+    // block pull (pull_ell_kernel; graphs with many weights): per group of the tables (the
+    // un-split sweep, or each chunk of a split one) entry rows per (variable block, weight);
+    // d_inc_* then only holds what did not fit a row.  blocks == 0: the group pulls its list.
+    struct BlockTable {
+      U32x4 *d_ell = nullptr;
+      uint32_t *d_tile0 = nullptr;
+      uint32_t blocks = 0, depth = 0, parts = 0;
+    };
+    std::vector<BlockTable> bp;           // [groups] or empty
+    long long *d_bp_qtab = nullptr, *d_bp_partial = nullptr;   // shared: deltas; [max blocks][Wp] sums
+    uint32_t bp_deltas = 0, bp_wp = 0;
     ~Level() {
       rt::dfree(d_inc_wid); rt::dfree(d_inc_slot); rt::dfree(d_inc_d); rt::dfree(d_t_static);
-      rt::dfree(d_bp_ell); rt::dfree(d_bp_tile0); rt::dfree(d_bp_qtab); rt::dfree(d_bp_partial);
+      for (auto &t : bp) { rt::dfree(t.d_ell); rt::dfree(t.d_tile0); }
+      rt::dfree(d_bp_qtab); rt::dfree(d_bp_partial);
     }
   };
   std::map<uint32_t, std::unique_ptr<Level>> levels;
@@ -381,134 +387,9 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
     const uint64_t n_inc = by_w.size();
     if (n_inc + (uint64_t)nc * PULL_RUN >= 0xFFFFFFFFull)
       throw std::invalid_argument("incidence list exceeds 2^32-1 entries");
-    // Block pull (un-split sweeps, many weights): rows of BP_ROW * depth entries per (variable
-    // block, weight) for pull_ell_kernel; an entry beyond its row stays on the list below.
-    RawArray<Inc> overflow;
-    bool block_pull = false;
-    {
-      uint64_t min_w = 262144, bp_tiles = BP_TILES;
-      if (const char *e = getenv("DWX_BLOCK_PULL_MIN_W")) min_w = (uint64_t)std::max(0L, atol(e));          // test hooks
-      if (const char *e = getenv("DWX_BLOCK_PULL_TILES")) bp_tiles = (uint64_t)std::min<long>(BP_TILES, std::max(1L, atol(e)));
-      const bool bp_timing = getenv("DWX_TIMING") != nullptr;
-      auto bp_t0 = std::chrono::steady_clock::now();
-      auto bp_phase = [&](const char *what) {
-        if (!bp_timing) return;
-        auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[dwx block pull] %-22s %.3f s\n", what, std::chrono::duration<double>(t - bp_t0).count());
-        bp_t0 = t;
-      };
-      if (batches == 1 && n_inc && c.W >= min_w) {
-        // (1) blocks: runs of <= bp_tiles consecutive tiles, started at tiles that own entries
-        std::vector<uint8_t> has(c.tiles.size(), 0);
-        parallel_ranges(n_inc, nth, [&](uint64_t b, uint64_t e) {
-          for (uint64_t i = b; i < e; ++i) {   // (test first: the flags are shared by all threads)
-            uint8_t &h = has[by_w[i].slot / BLOCK_THREADS];
-            if (!h) h = 1;
-          }
-        });
-        std::vector<uint32_t> tile0, block_of(c.tiles.size(), 0);
-        for (uint32_t ti = 0; ti < c.tiles.size(); ++ti) {
-          if (!has[ti]) continue;
-          if (tile0.empty() || ti >= tile0.back() + bp_tiles) tile0.push_back(ti);
-          block_of[ti] = (uint32_t)tile0.size() - 1;
-        }
-        const uint64_t nvb = tile0.size();
-        bp_phase("blocks");
-        // (2) the distinct record deltas (few: feature values repeat), as fixed-point steps
-        std::vector<uint32_t> dvals;
-        {
-          const uint32_t T = (uint32_t)std::min<uint64_t>(nth, std::max<uint64_t>(1, n_inc / 65536));
-          std::vector<std::vector<uint32_t>> local(std::max(1u, T));
-          parallel_parts(n_inc, std::max(1u, T), [&](uint32_t t, uint64_t b, uint64_t e) {
-            std::vector<uint32_t> &v = local[t];
-            uint32_t last = 0; bool have = false;
-            for (uint64_t i = b; i < e && v.size() <= 4 * BP_MAX_DELTAS; ++i) {
-              uint32_t bits; std::memcpy(&bits, &by_w[i].d, 4);
-              if (have && bits == last) continue;
-              last = bits; have = true;
-              v.push_back(bits);
-              if (v.size() % 4096 == 0) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
-            }
-            std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
-          }, 0);
-          for (auto &v : local) dvals.insert(dvals.end(), v.begin(), v.end());
-          std::sort(dvals.begin(), dvals.end()); dvals.erase(std::unique(dvals.begin(), dvals.end()), dvals.end());
-        }
-        bp_phase("distinct deltas");
-        if (nvb && dvals.size() <= BP_MAX_DELTAS) {
-          block_pull = true;
-          const double lambda = (double)n_inc / ((double)c.W * (double)nvb);
-          const uint32_t depth = lambda > 3.2 ? 2u : 1u, cap = BP_ROW * depth;
-          const uint64_t Wp = (c.W + BP_THREADS - 1) / BP_THREADS * BP_THREADS;
-          RawArray<U32x4> ell(nvb * depth * Wp);
-          parallel_ranges(ell.size(), nth, [&](uint64_t b, uint64_t e) { std::memset((void *)(ell.data() + b), 0xFF, (e - b) * sizeof(U32x4)); });
-          bp_phase("table clear");
-          auto code_of = [&](const Inc &r) -> uint32_t {
-            uint32_t bits; std::memcpy(&bits, &r.d, 4);
-            const uint32_t di = (uint32_t)(std::lower_bound(dvals.begin(), dvals.end(), bits) - dvals.begin());
-            const uint32_t ti = r.slot / BLOCK_THREADS, lane = r.slot % BLOCK_THREADS;
-            return ((ti - tile0[block_of[ti]]) * BLOCK_THREADS + lane) | (di << BP_SLOT_BITS);
-          };
-          // entries of one weight come in tile order (stable sort): blocks in ascending order
-          std::vector<uint64_t> ov_start(c.W + 1, 0);
-          for (int pass = 0; pass < 2; ++pass) {
-            parallel_ranges(c.W, nth, [&](uint64_t wb, uint64_t we) {
-              for (uint64_t w = wb; w < we; ++w) {
-                uint32_t cur = ~0u, k = 0;
-                uint64_t o = pass == 0 ? 0 : ov_start[w];
-                for (uint64_t i = w_start[w]; i < w_start[w + 1]; ++i) {
-                  const Inc &r = by_w[i];
-                  const uint32_t vb = block_of[r.slot / BLOCK_THREADS];
-                  if (vb != cur) { cur = vb; k = 0; }
-                  if (k < cap) {
-                    if (pass == 0) ell[((uint64_t)vb * depth + k / BP_ROW) * Wp + w].v[k % BP_ROW] = code_of(r);
-                  } else if (pass == 0) {
-                    ++o;
-                  } else {
-                    Inc q = r; q.chunk = 0;
-                    overflow[o++] = q;
-                  }
-                  ++k;
-                }
-                if (pass == 0) ov_start[w + 1] = o;   // (count; prefix-summed below)
-              }
-            });
-            if (pass == 0) {
-              ov_start[0] = 0;
-              for (uint64_t w = 0; w < c.W; ++w) ov_start[w + 1] += ov_start[w];
-              overflow.reset(ov_start[c.W]);
-            }
-          }
-          bp_phase("table fill");
-          std::vector<long long> qtab(dvals.size());
-          for (size_t i = 0; i < dvals.size(); ++i) {
-            float d; std::memcpy(&d, &dvals[i], 4);
-            qtab[i] = std::llrint(FIX_SCALE * (double)d);
-          }
-          L->d_bp_ell = upload_raw(ell.data(), ell.size(), s->stream);
-          L->d_bp_tile0 = upload(tile0, s->stream);
-          L->d_bp_qtab = upload(qtab, s->stream);
-          L->d_bp_partial = (long long *)rt::dmalloc(nvb * Wp * 8);
-          L->bp_blocks = (uint32_t)nvb; L->bp_depth = depth; L->bp_deltas = (uint32_t)dvals.size(); L->bp_wp = (uint32_t)Wp;
-          // parts per block: one workgroup per CU over all blocks (it owns the CU's whole LDS)
-          L->bp_parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(rt::cu_count() / nvb, Wp / BP_THREADS));
-          rt::allow_dynamic_lds(pull_ell_kernel<1>, BP_LDS_BYTES);
-          rt::allow_dynamic_lds(pull_ell_kernel<2>, BP_LDS_BYTES);
-          rt::stream_sync(s->stream);   // ell dies with this scope
-          bp_phase("upload");
-          if (getenv("DWX_TIMING"))
-            fprintf(stderr, "[dwx block pull] %llu blocks x depth %u, %zu deltas, %llu of %llu entries on the list\n",
-                    (unsigned long long)nvb, depth, dvals.size(), (unsigned long long)overflow.size(),
-                    (unsigned long long)n_inc);
-        }
-      }
-    }
+    // the groups' lists: by weight inside a group
     const RawArray<Inc> *src = &by_w;
-    if (block_pull) {
-      by_w.clear();
-      src = &overflow;
-      c_start = {0, overflow.size()};
-    } else if (nc > 1) {
+    if (nc > 1) {
       parallel_group_by_key<Inc>(
           n_inc, nth, nc, [](const Inc &r) { return (uint64_t)r.chunk; },
           [&](uint64_t b, uint64_t e, auto &&emit) { for (uint64_t i = b; i < e; ++i) emit(by_w[i]); },
@@ -517,6 +398,165 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
       src = &by_c;
     } else {
       c_start = {0, n_inc};
+    }
+    // Block pull (graphs with many weights): per group, rows of BP_ROW * depth entries per
+    // (variable block, weight) for pull_ell_kernel; an entry beyond its row stays on the list.
+    RawArray<Inc> kept;                    // the lists of all groups after the tables took their entries
+    std::vector<uint64_t> kept_start;
+    {
+      uint64_t min_w = 262144, bp_tiles = BP_TILES;
+      if (const char *e = getenv("DWX_BLOCK_PULL_MIN_W")) min_w = (uint64_t)std::max(0L, atol(e));          // test hooks
+      if (const char *e = getenv("DWX_BLOCK_PULL_TILES")) bp_tiles = (uint64_t)std::min<long>(BP_TILES, std::max(1L, atol(e)));
+      const bool bp_timing = getenv("DWX_TIMING") != nullptr;
+      // the distinct record deltas (few: feature values repeat), as fixed-point steps
+      std::vector<uint32_t> dvals;
+      bool enabled = n_inc && c.W >= min_w;
+      if (enabled) {
+        const uint32_t T = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nth, n_inc / 65536));
+        std::vector<std::vector<uint32_t>> local(T);
+        parallel_parts(n_inc, T, [&](uint32_t t, uint64_t b, uint64_t e) {
+          std::vector<uint32_t> &v = local[t];
+          uint32_t last = 0; bool have = false;
+          for (uint64_t i = b; i < e && v.size() <= 4 * BP_MAX_DELTAS; ++i) {
+            uint32_t bits; std::memcpy(&bits, &(*src)[i].d, 4);
+            if (have && bits == last) continue;
+            last = bits; have = true;
+            v.push_back(bits);
+            if (v.size() % 4096 == 0) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+          }
+          std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
+        }, 0);
+        for (auto &v : local) dvals.insert(dvals.end(), v.begin(), v.end());
+        std::sort(dvals.begin(), dvals.end()); dvals.erase(std::unique(dvals.begin(), dvals.end()), dvals.end());
+        enabled = dvals.size() <= BP_MAX_DELTAS;
+      }
+      if (enabled) {
+        const uint64_t Wp = (c.W + BP_THREADS - 1) / BP_THREADS * BP_THREADS;
+        L->bp.resize(nc);
+        uint64_t max_blocks = 0;
+        std::vector<uint64_t> ov_count(nc, 0);
+        std::vector<std::vector<uint64_t>> ov_start(nc);   // per group, per weight: entries left on the list
+        std::vector<RawArray<Inc>> ov(nc);
+        std::vector<uint8_t> has(c.tiles.size(), 0);
+        std::vector<uint32_t> block_of(c.tiles.size(), 0);
+        for (uint32_t k = 0; k < nc; ++k) {
+          const Inc *ent = src->data() + c_start[k];
+          const uint64_t n = c_start[k + 1] - c_start[k];
+          if (!n) continue;
+          // (1) blocks: runs of <= bp_tiles consecutive tiles, started at tiles that own entries
+          std::fill(has.begin(), has.end(), 0);
+          parallel_ranges(n, nth, [&](uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) {   // (test first: the flags are shared by all threads)
+              uint8_t &h = has[ent[i].slot / BLOCK_THREADS];
+              if (!h) h = 1;
+            }
+          });
+          std::vector<uint32_t> tile0;
+          for (uint32_t ti = 0; ti < c.tiles.size(); ++ti) {
+            if (!has[ti]) continue;
+            if (tile0.empty() || ti >= tile0.back() + bp_tiles) tile0.push_back(ti);
+            block_of[ti] = (uint32_t)tile0.size() - 1;
+          }
+          const uint64_t nvb = tile0.size();
+          const double lambda = (double)n / ((double)c.W * (double)nvb);
+          if (lambda < 0.5) continue;   // nearly empty rows: this group keeps its list
+          const uint32_t depth = lambda > 3.2 ? 2u : 1u, cap = BP_ROW * depth;
+          // (2) where each weight's entries start inside the group (they are sorted by weight)
+          std::vector<uint64_t> w_at(c.W + 1, n);
+          parallel_ranges(n, nth, [&](uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) {
+              const uint32_t w = ent[i].wid, prev = i ? ent[i - 1].wid + 1 : 0;
+              if (!i || ent[i - 1].wid != w) for (uint32_t x = prev; x <= w; ++x) w_at[x] = i;
+            }
+          });
+          // (3) the table; entries of one weight come in tile order: blocks ascending
+          RawArray<U32x4> ell(nvb * depth * Wp);
+          parallel_ranges(ell.size(), nth, [&](uint64_t b, uint64_t e) { std::memset((void *)(ell.data() + b), 0xFF, (e - b) * sizeof(U32x4)); });
+          std::vector<uint64_t> &ovs = ov_start[k];
+          ovs.assign(c.W + 1, 0);
+          parallel_ranges(c.W, nth, [&](uint64_t wb, uint64_t we) {
+            for (uint64_t w = wb; w < we; ++w) {
+              uint32_t cur = ~0u, kk = 0;
+              uint64_t o = 0;
+              for (uint64_t i = w_at[w]; i < w_at[w + 1]; ++i) {
+                const Inc &r = ent[i];
+                const uint32_t ti = r.slot / BLOCK_THREADS, vb = block_of[ti];
+                if (vb != cur) { cur = vb; kk = 0; }
+                if (kk < cap) {
+                  uint32_t bits; std::memcpy(&bits, &r.d, 4);
+                  const uint32_t di = (uint32_t)(std::lower_bound(dvals.begin(), dvals.end(), bits) - dvals.begin());
+                  ell[((uint64_t)vb * depth + kk / BP_ROW) * Wp + w].v[kk % BP_ROW] =
+                      ((ti - tile0[vb]) * BLOCK_THREADS + r.slot % BLOCK_THREADS) | (di << BP_SLOT_BITS);
+                } else {
+                  ++o;
+                }
+                ++kk;
+              }
+              ovs[w + 1] = o;
+            }
+          });
+          for (uint64_t w = 0; w < c.W; ++w) ovs[w + 1] += ovs[w];
+          ov_count[k] = ovs[c.W];
+          // the entries the rows could not take, in list order (same walk, now copying)
+          ov[k].reset(ov_count[k]);
+          if (ov_count[k]) {
+            Inc *dst = ov[k].data();
+            parallel_ranges(c.W, nth, [&](uint64_t wb, uint64_t we) {
+              for (uint64_t w = wb; w < we; ++w) {
+                uint32_t cur = ~0u, kk = 0;
+                uint64_t o = ovs[w];
+                for (uint64_t i = w_at[w]; i < w_at[w + 1]; ++i) {
+                  const uint32_t vb = block_of[ent[i].slot / BLOCK_THREADS];
+                  if (vb != cur) { cur = vb; kk = 0; }
+                  if (kk >= cap) dst[o++] = ent[i];
+                  ++kk;
+                }
+              }
+            });
+          }
+          dwx_sampler::Level::BlockTable &bt = L->bp[k];
+          bt.d_ell = upload_raw(ell.data(), ell.size(), s->stream);
+          bt.d_tile0 = upload(tile0, s->stream);
+          bt.blocks = (uint32_t)nvb; bt.depth = depth;
+          // parts per block: one workgroup per CU over all blocks (it owns the CU's whole LDS)
+          bt.parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(rt::cu_count() / nvb, Wp / BP_THREADS));
+          max_blocks = std::max(max_blocks, nvb);
+          rt::stream_sync(s->stream);   // ell dies with this scope
+          if (bp_timing)
+            fprintf(stderr, "[dwx block pull] group %u: %llu blocks x depth %u, %zu deltas, %llu of %llu entries on the list\n",
+                    k, (unsigned long long)nvb, depth, dvals.size(), (unsigned long long)ov_count[k], (unsigned long long)n);
+        }
+        if (max_blocks) {
+          // the lists shrink to what the tables left (same order: by weight inside a group)
+          kept_start.assign(nc + 1, 0);
+          for (uint32_t k = 0; k < nc; ++k)
+            kept_start[k + 1] = kept_start[k] + (L->bp[k].blocks ? ov_count[k] : c_start[k + 1] - c_start[k]);
+          kept.reset(kept_start[nc]);
+          for (uint32_t k = 0; k < nc; ++k) {
+            const Inc *ent = src->data() + c_start[k];
+            const uint64_t n = c_start[k + 1] - c_start[k];
+            Inc *dst = kept.data() + kept_start[k];
+            if (!L->bp[k].blocks) std::copy(ent, ent + n, dst);
+            else std::copy(ov[k].data(), ov[k].data() + ov[k].size(), dst);
+          }
+          std::vector<long long> qtab(dvals.size());
+          for (size_t i = 0; i < dvals.size(); ++i) {
+            float d; std::memcpy(&d, &dvals[i], 4);
+            qtab[i] = std::llrint(FIX_SCALE * (double)d);
+          }
+          L->d_bp_qtab = upload(qtab, s->stream);
+          L->d_bp_partial = (long long *)rt::dmalloc(max_blocks * Wp * 8);
+          L->bp_deltas = (uint32_t)dvals.size(); L->bp_wp = (uint32_t)Wp;
+          rt::allow_dynamic_lds(pull_ell_kernel<1>, BP_LDS_BYTES);
+          rt::allow_dynamic_lds(pull_ell_kernel<2>, BP_LDS_BYTES);
+          rt::stream_sync(s->stream);
+          by_w.clear(); by_c.clear();
+          src = &kept;
+          c_start = kept_start;
+        } else {
+          L->bp.clear();
+        }
+      }
     }
     // columns; every chunk padded to whole runs with neutral entries (its last weight, zero
     // contribution), so the kernel's 16-byte loads never leave the chunk
@@ -753,20 +793,25 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
     if (!split) { if (chunk + 1 == s->plan_chunks.size()) { pb = L.inc_begin.front(); pe = L.inc_end.back(); } }
     else { pb = L.inc_begin[chunk]; pe = L.inc_end[chunk]; }
   }
-  if (L.fast && L.bp_blocks && !split && chunk + 1 == s->plan_chunks.size()) {
-    const unsigned grid = L.bp_blocks * L.bp_parts;
-    if (L.bp_depth == 2)
-      rt::launch(pull_ell_kernel<2>, grid, BP_THREADS, BP_LDS_BYTES, s->stream, (const U32x4 *)L.d_bp_ell,
-                 (const uint32_t *)L.d_bp_tile0, L.bp_parts, (const long long *)L.d_bp_qtab, L.bp_deltas, L.bp_wp,
-                 (const unsigned long long *)s->d_delta, L.d_bp_partial);
-    else
-      rt::launch(pull_ell_kernel<1>, grid, BP_THREADS, BP_LDS_BYTES, s->stream, (const U32x4 *)L.d_bp_ell,
-                 (const uint32_t *)L.d_bp_tile0, L.bp_parts, (const long long *)L.d_bp_qtab, L.bp_deltas, L.bp_wp,
-                 (const unsigned long long *)s->d_delta, L.d_bp_partial);
-    const uint32_t W = (uint32_t)s->cg->W;
-    rt::launch(fold_partials_kernel, std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 4096u), BLOCK_THREADS, 0,
-               s->stream, (const long long *)L.d_bp_partial, L.bp_blocks, L.bp_wp, W, s->d_grad);
-    pulled = true;
+  // block pull of the same group as the list below: the whole sweep (un-split, after the
+  // last colour launch) or this chunk
+  if (L.fast && !L.bp.empty() && (split || chunk + 1 == s->plan_chunks.size())) {
+    const dwx_sampler::Level::BlockTable &bt = L.bp[split ? chunk : 0];
+    if (bt.blocks) {
+      const unsigned grid = bt.blocks * bt.parts;
+      if (bt.depth == 2)
+        rt::launch(pull_ell_kernel<2>, grid, BP_THREADS, BP_LDS_BYTES, s->stream, (const U32x4 *)bt.d_ell,
+                   (const uint32_t *)bt.d_tile0, bt.parts, (const long long *)L.d_bp_qtab, L.bp_deltas, L.bp_wp,
+                   (const unsigned long long *)s->d_delta, L.d_bp_partial);
+      else
+        rt::launch(pull_ell_kernel<1>, grid, BP_THREADS, BP_LDS_BYTES, s->stream, (const U32x4 *)bt.d_ell,
+                   (const uint32_t *)bt.d_tile0, bt.parts, (const long long *)L.d_bp_qtab, L.bp_deltas, L.bp_wp,
+                   (const unsigned long long *)s->d_delta, L.d_bp_partial);
+      const uint32_t W = (uint32_t)s->cg->W;
+      rt::launch(fold_partials_kernel, std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 4096u), BLOCK_THREADS, 0,
+                 s->stream, (const long long *)L.d_bp_partial, bt.blocks, L.bp_wp, W, s->d_grad);
+      pulled = true;
+    }
   }
   if (pe > pb) {
     const uint32_t n = pe - pb;

@@ -245,6 +245,12 @@ def test_block_pull(lib, monkeypatch, block_tiles, depth_hint):
     E.test_block_pull(lib, monkeypatch, block_tiles, depth_hint)
 
 
+@pytest.mark.parametrize("block_tiles", [4, 2048])
+def test_block_pull_in_split_sweeps(lib, monkeypatch, block_tiles):
+    import test_kernels_emu as E
+    E.test_block_pull_in_split_sweeps(lib, monkeypatch, block_tiles)
+
+
 def test_block_pull_at_size_equals_list_pull_and_oracle(lib, monkeypatch):
     # 2 M variables, 300 k weights: the block pull engages on its own (>= 262 144 weights);
     # several variable blocks, two-row tables, entries left on the list.  Exact against the

@@ -279,6 +279,24 @@ def test_split_sweep_with_pull_tiles_and_static_counts(lib, monkeypatch):
     run_parity(lib, raw, n_learn=3, n_infer=1, stepsize=0.05, compile_opts=dict(tile_vars=64))
 
 
+@pytest.mark.parametrize("block_tiles", [4, 2048])
+def test_block_pull_in_split_sweeps(lib, monkeypatch, block_tiles):
+    """Split plans with the block pull: every chunk has its own entry rows (and the rest of
+    its list); chunks whose rows would be nearly empty keep the plain list.  The decaying step
+    walks through several plan levels; also a two-colour graph and learn_non_evidence."""
+    from sampler_amd import dwx
+    monkeypatch.setenv("DWX_BLOCK_PULL_MIN_W", "0")
+    monkeypatch.setenv("DWX_BLOCK_PULL_TILES", str(block_tiles))
+    raw = synthetic.cfg3(8000, n_weights=1300, seed=7)
+    s = dwx.GibbsSampler(dwx.Graph(raw, lib=lib, tile_vars=64), seed=3)
+    assert 2 <= s.sgd_plan(0.05)[0] <= 64
+    run_parity(lib, raw, n_learn=5, n_infer=1, stepsize=0.05, decay=0.6, compile_opts=dict(tile_vars=64))
+    run_parity(lib, raw, n_learn=3, n_infer=1, stepsize=0.08, learn_non_evidence=True,
+               compile_opts=dict(tile_vars=64))
+    run_parity(lib, synthetic.cfg3b(4000, n_weights=1400, seed=15), n_learn=4, n_infer=2, stepsize=0.05,
+               compile_opts=dict(tile_vars=64))
+
+
 def test_tabulated_inference_terms_follow_every_weight_change(lib):
     """From the second consecutive inference sweep on unchanged weights on, all-unary tiles
     stream a table of their potential terms instead of gathering weights.  The table must be
