@@ -195,12 +195,19 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   P.tile_end = t1;
   // persistent grid: as many workgroups as stay resident, each striding over tiles
   // all-unary graph: 8-byte record stream (a run on the terms table streams those instead)
-  const bool rec8 = s->rec8 && !P.edge_terms;
+  const bool rec8 = s->rec8;
+  const bool tab8 = rec8 && !LEARN && P.edge_terms;   // inference on the 8-byte terms table
   const bool slim = LEARN && rec8 && s->all_pull && !(P.flags & OPT_NO_PULL);
   const unsigned grid = std::min<unsigned>(t1 - t0, slim ? s->persistent_blocks_pull :
                                            (rec8 ? s->persistent_blocks8 : s->persistent_blocks)[LEARN ? 1 : 0]);
   const size_t lds = slim ? s->lds_learn_pull : s->lds_bytes[LEARN ? 1 : 0];
-  if (rec8) {
+  if (tab8) {
+    switch (s->stage_k) {
+      case 3: rt::launch(sweep8_kernel<false, 3, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      case 6: rt::launch(sweep8_kernel<false, 6, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      default: rt::launch(sweep8_kernel<false, 12, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+    }
+  } else if (rec8) {
     switch (s->stage_k) {
       case 3: rt::launch(sweep8_kernel<LEARN, 3>, grid, BLOCK_THREADS, lds, s->stream, P); break;
       case 6: rt::launch(sweep8_kernel<LEARN, 6>, grid, BLOCK_THREADS, lds, s->stream, P); break;
@@ -243,10 +250,16 @@ void enqueue_inference(dwx_sampler *s) {
   // sweeps stream the table and gather no weights.  (Not on the first one: learning and
   // inference sweeps may alternate, and then the table would be rebuilt for a single use.)
   if (s->has_simple_tiles && s->terms_state == 1 && c.NIdx) {
-    if (!s->d_terms) s->d_terms = (EdgeTerms *)rt::dmalloc(c.NIdx * sizeof(EdgeTerms));
     const unsigned grid = std::min<unsigned>((unsigned)c.tiles.size(), 256u * 16u);
-    rt::launch(build_terms_kernel, grid, BLOCK_THREADS, 0, s->stream, (const TileDesc *)s->d_tiles,
-               (uint32_t)c.tiles.size(), (const EdgeRec *)s->d_edges, (const float *)s->d_w32, s->d_terms);
+    if (s->rec8) {   // all-unary graph: the 8-byte table
+      if (!s->d_terms) s->d_terms = (EdgeTerms *)rt::dmalloc(c.NIdx * 8);
+      rt::launch(build_terms8_kernel, grid, BLOCK_THREADS, 0, s->stream, (const EdgeRec8 *)s->d_edges8,
+                 (uint64_t)c.NIdx, (const float *)s->d_w32, (unsigned long long *)s->d_terms);
+    } else {
+      if (!s->d_terms) s->d_terms = (EdgeTerms *)rt::dmalloc(c.NIdx * sizeof(EdgeTerms));
+      rt::launch(build_terms_kernel, grid, BLOCK_THREADS, 0, s->stream, (const TileDesc *)s->d_tiles,
+                 (uint32_t)c.tiles.size(), (const EdgeRec *)s->d_edges, (const float *)s->d_w32, s->d_terms);
+    }
     s->terms_state = 2;
   }
   P.edge_terms = s->terms_state == 2 ? s->d_terms : nullptr;
@@ -1084,9 +1097,9 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
         s->persistent_blocks_pull = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_learn_pull);
       };
       switch (s->stage_k) {
-        case 3: prepare8(sweep8_kernel<false, 3>, sweep8_kernel<true, 3>); break;
-        case 6: prepare8(sweep8_kernel<false, 6>, sweep8_kernel<true, 6>); break;
-        default: prepare8(sweep8_kernel<false, 12>, sweep8_kernel<true, 12>); break;
+        case 3: prepare8(sweep8_kernel<false, 3>, sweep8_kernel<true, 3>); rt::allow_dynamic_lds(sweep8_kernel<false, 3, true>, s->lds_bytes[0]); break;
+        case 6: prepare8(sweep8_kernel<false, 6>, sweep8_kernel<true, 6>); rt::allow_dynamic_lds(sweep8_kernel<false, 6, true>, s->lds_bytes[0]); break;
+        default: prepare8(sweep8_kernel<false, 12>, sweep8_kernel<true, 12>); rt::allow_dynamic_lds(sweep8_kernel<false, 12, true>, s->lds_bytes[0]); break;
       }
     }
     rt::stream_sync(st);

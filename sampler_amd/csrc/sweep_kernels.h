@@ -700,6 +700,8 @@ DWX_DEV float rec8_signed(uint32_t code, float f) {   // code = sign + 1
   const uint32_t b = float_to_bits(f);
   return bits_to_float(code == 1u ? 0u : (code == 0u ? (b ^ 0x80000000u) : b));
 }
+// one potential term from a table entry: code = sign + 1 (as in EdgeRec8), wf = w * f
+DWX_DEV double terms8_signed(uint32_t code, double wf) { return code == 1u ? 0.0 : (code == 0u ? -wf : wf); }
 DWX_DEV EdgeRec expand_record(const EdgeRec8 &c) {
   EdgeRec r;
   r.wid = c.key & REC8_WID_MASK;
@@ -754,7 +756,9 @@ DWX_DEV void issue_record_loads(const KernelParams &P, const TileDesc &d, uint32
 }
 template <bool LEARN, int K>
 DWX_DEV void issue_record_loads(const KernelParams &P, const TileDesc &d, uint32_t t, EdgeRec8 (&rec)[K]) {
-  DWX_LOAD_TILE_RECORDS8(K, P.edges8 + d.e0, d.nedges, t, rec);
+  // (an inference sweep on the 8-byte terms table streams that instead: same stride)
+  const EdgeRec8 *stream = (!LEARN && P.edge_terms) ? (const EdgeRec8 *)P.edge_terms : P.edges8;
+  DWX_LOAD_TILE_RECORDS8(K, stream + d.e0, d.nedges, t, rec);
 }
 
 template <bool LEARN, int K, class Rec>
@@ -1049,8 +1053,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
 // and ~9.8 k when every gather goes to L2 (1 M weights), whatever the occupancy and however
 // early the gathers are issued (a two-tile-deep version of this loop, gathers of tile j+1
 // and records of tile j+2 in flight under the compute of tile j, ran 5 % SLOWER).
-template <bool LEARN, int K>
+// TAB (inference on unchanged weights, from the second consecutive sweep on): the stream is
+// the 8-byte terms table of build_terms8_kernel -- per record the exact f64 product w * f with
+// the two sign codes in its four lowest mantissa bits (the product of two f32 has at most 48
+// significant bits: at least five trailing zeros) -- and no weight is gathered at all.
+template <bool LEARN, int K, bool TAB = false>
 __global__ void __launch_bounds__(BLOCK_THREADS, LEARN ? 2 : 3) sweep8_kernel(const KernelParams P) {
+  static_assert(!(LEARN && TAB), "the terms table serves inference sweeps only");
   DWX_DYN_LDS(dyn_lds);
   uint32_t *s_rowptr = (uint32_t *)dyn_lds;
   double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
@@ -1080,11 +1089,24 @@ __global__ void __launch_bounds__(BLOCK_THREADS, LEARN ? 2 : 3) sweep8_kernel(co
       // the f32 sampling weight of every record this lane stages (a zero-filled lane past
       // the tile's end gathers w32[0]: one cached line) ...
       float w[K];
+      if (!TAB) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) w[k] = P.w32[f.rec[k].key & REC8_WID_MASK];
+        for (int k = 0; k < K; ++k) w[k] = P.w32[f.rec[k].key & REC8_WID_MASK];
+      }
       // ... and this lane's uniforms while the gathers are in flight
       philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
-      if (!LEARN || pull) {
+      if (TAB) {
+        EdgeTerms *s_terms = (EdgeTerms *)s_edges;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const uint32_t lo = f.rec[k].key, hi = float_to_bits(f.rec[k].f);
+          const double wf = u32x2_to_double(lo & ~15u, hi);
+          EdgeTerms tt;
+          tt.t1 = terms8_signed(lo & 3u, wf);
+          tt.t0 = terms8_signed((lo >> 2) & 3u, wf);
+          s_terms[t + k * BLOCK_THREADS] = tt;
+        }
+      } else if (!LEARN || pull) {
         // the two potential terms of every record, edge-parallel and straight-line:
         // t1 = w * (sign(hit) * f), t0 = w * (sign(miss) * f) -- the products of
         // FactorGraph::potential (src/factor_graph.h:127-145)
@@ -1434,6 +1456,21 @@ build_terms_kernel(const TileDesc *tiles, uint32_t n_tiles, const EdgeRec *edges
         ((TabRec2 *)terms)[d.e0 + i] = tr;
       }
     }
+  }
+}
+
+// The terms table of an all-unary graph (compact records): 8 bytes per record, the exact
+// product w * f (f64 of two f32) with sign(hit) + 1 and sign(miss) + 1 in its four lowest
+// mantissa bits -- zero in every such product, so nothing is lost.
+__global__ void __launch_bounds__(BLOCK_THREADS)
+build_terms8_kernel(const EdgeRec8 *edges8, uint64_t n, const float *w32, unsigned long long *terms) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const EdgeRec8 c = edges8[i];
+    const double wf = (double)w32[c.key & REC8_WID_MASK] * (double)c.f;
+    unsigned long long u;
+    __builtin_memcpy(&u, &wf, 8);
+    terms[i] = u | ((c.key >> REC8_HIT_SHIFT) & 15u);   // hit code in bits 0-1, miss code in bits 2-3
   }
 }
 
