@@ -146,6 +146,7 @@ constexpr uint32_t BP_DELTA_SLOTS = 4096, BP_MAX_DELTAS = BP_DELTA_SLOTS - 1;   
 // one block of ballot pairs + the table of deltas: exactly the 160 KiB of a CU
 constexpr uint32_t BP_LDS_BYTES = BP_TILES * 64 + BP_DELTA_SLOTS * 8;
 constexpr uint32_t ROWPTR_UNROLL = 2;                       // row pointers prefetched per lane
+constexpr uint32_t ROWPTR_UNROLL_CAT = 7;                   // ... for categorical all-unary graphs (sweep8_kernel)                       // row pointers prefetched per lane
 
 // Everything one sweep launch needs; passed by value.
 struct KernelParams {

@@ -109,6 +109,7 @@ struct dwx_sampler {
   bool wide_learn = false;   // the graph has TILE_TERMS2 tiles: 32-byte staged records when learning
   unsigned persistent_blocks[2] = {1, 1};
   bool rec8 = false;                    // the graph streams 8-byte records (CompiledGraph::edges8)
+  bool rp_cat = false;                  // ... with every row pointer of a categorical tile prefetched (K = 6 builds)
   unsigned persistent_blocks8[2] = {1, 1};
   // every tile that fits is TILE_PULL: a learning sweep with the pull gradient stages 16-byte
   // terms only (no f32 weight array behind the records) -- smaller LDS, one more workgroup per CU
@@ -201,7 +202,11 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   const unsigned grid = std::min<unsigned>(t1 - t0, slim ? s->persistent_blocks_pull :
                                            (rec8 ? s->persistent_blocks8 : s->persistent_blocks)[LEARN ? 1 : 0]);
   const size_t lds = slim ? s->lds_learn_pull : s->lds_bytes[LEARN ? 1 : 0];
-  if (tab8) {
+  constexpr int RPC = (int)ROWPTR_UNROLL_CAT;
+  if (rec8 && s->rp_cat) {
+    if (tab8) rt::launch(sweep8_kernel<false, 6, true, RPC>, grid, BLOCK_THREADS, lds, s->stream, P);
+    else rt::launch(sweep8_kernel<LEARN, 6, false, RPC>, grid, BLOCK_THREADS, lds, s->stream, P);
+  } else if (tab8) {
     switch (s->stage_k) {
       case 3: rt::launch(sweep8_kernel<false, 3, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
       case 6: rt::launch(sweep8_kernel<false, 6, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
@@ -1046,7 +1051,8 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     if (c.ecap > MAX_ECAP) throw std::invalid_argument("tile_edges exceeds the staging capacity");
     s->stage_k = c.ecap <= 3 * BLOCK_THREADS ? 3 : (c.ecap <= 6 * BLOCK_THREADS ? 6 : 12);
     const size_t slots = (size_t)s->stage_k * BLOCK_THREADS;
-    const size_t nrp = std::max<size_t>(c.rcap + 1, ROWPTR_UNROLL * BLOCK_THREADS);
+    s->rp_cat = !c.edges8.empty() && c.has_categorical && s->stage_k == 6;
+    const size_t nrp = std::max<size_t>(c.rcap + 1, (s->rp_cat ? ROWPTR_UNROLL_CAT : ROWPTR_UNROLL) * BLOCK_THREADS);
     size_t off = (nrp * 4 + 15) & ~(size_t)15;
     P.lds_pot_off = c.has_categorical ? (uint32_t)off : 0u;
     if (c.has_categorical) off += (size_t)c.rcap * 8;
@@ -1096,6 +1102,11 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
         s->persistent_blocks8[1] = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_bytes[1]);
         s->persistent_blocks_pull = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_learn_pull);
       };
+      if (s->rp_cat) {
+        constexpr int RPC = (int)ROWPTR_UNROLL_CAT;
+        prepare8(sweep8_kernel<false, 6, false, RPC>, sweep8_kernel<true, 6, false, RPC>);
+        rt::allow_dynamic_lds(sweep8_kernel<false, 6, true, RPC>, s->lds_bytes[0]);
+      } else
       switch (s->stage_k) {
         case 3: prepare8(sweep8_kernel<false, 3>, sweep8_kernel<true, 3>); rt::allow_dynamic_lds(sweep8_kernel<false, 3, true>, s->lds_bytes[0]); break;
         case 6: prepare8(sweep8_kernel<false, 6>, sweep8_kernel<true, 6>); rt::allow_dynamic_lds(sweep8_kernel<false, 6, true>, s->lds_bytes[0]); break;

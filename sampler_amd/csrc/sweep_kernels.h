@@ -713,10 +713,10 @@ DWX_DEV EdgeRec expand_record(const EdgeRec8 &c) {
 DWX_DEV EdgeRec expand_record(const EdgeRec &r) { return r; }
 
 // Everything a lane holds in registers for the tile it will stage next.
-template <int K, class Rec = EdgeRec>
+template <int K, class Rec = EdgeRec, int RP = (int)ROWPTR_UNROLL>
 struct TilePrefetch {
   Rec rec[K];
-  uint32_t rp[ROWPTR_UNROLL];
+  uint32_t rp[RP];     // row pointers t, t + 256, ... of the tile
   VarPre pre;
 };
 
@@ -761,12 +761,12 @@ DWX_DEV void issue_record_loads(const KernelParams &P, const TileDesc &d, uint32
   DWX_LOAD_TILE_RECORDS8(K, stream + d.e0, d.nedges, t, rec);
 }
 
-template <bool LEARN, int K, class Rec>
+template <bool LEARN, int K, class Rec, int RP>
 DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t t,
-                              TilePrefetch<K, Rec> &f) {
+                              TilePrefetch<K, Rec, RP> &f) {
   issue_record_loads<LEARN, K>(P, d, t, f.rec);
 #pragma unroll
-  for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k)
+  for (uint32_t k = 0; k < (uint32_t)RP; ++k)
     f.rp[k] = P.row_ptr[d.r0 + umin(t + k * BLOCK_THREADS, d.nrows)];
   f.pre = load_var_pre<LEARN>(P, d.v0 + umin(t, d.nv - 1));
 }
@@ -1057,7 +1057,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
 // the 8-byte terms table of build_terms8_kernel -- per record the exact f64 product w * f with
 // the two sign codes in its four lowest mantissa bits (the product of two f32 has at most 48
 // significant bits: at least five trailing zeros) -- and no weight is gathered at all.
-template <bool LEARN, int K, bool TAB = false>
+// RP: row pointers prefetched per lane.  Boolean tiles have 257; a categorical tile has up to
+// rcap + 1 = 1537 -- with RP = 7 all of them ride the prefetch instead of being loaded and
+// awaited while staging (config 4: 0.296 -> 0.246 ms); boolean graphs keep 2 (the extra
+// loads cost config 3's repeated inference 15 %).
+template <bool LEARN, int K, bool TAB = false, int RP = (int)ROWPTR_UNROLL>
 __global__ void __launch_bounds__(BLOCK_THREADS, LEARN ? 2 : 3) sweep8_kernel(const KernelParams P) {
   static_assert(!(LEARN && TAB), "the terms table serves inference sweeps only");
   DWX_DYN_LDS(dyn_lds);
@@ -1074,7 +1078,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, LEARN ? 2 : 3) sweep8_kernel(co
   uint32_t next = tile + stride;
   bool has_next = next < P.tile_end;
   TileDesc dn = scalarise(P.tiles[has_next ? next : tile]);   // one descriptor ahead
-  TilePrefetch<K, EdgeRec8> f;
+  TilePrefetch<K, EdgeRec8, RP> f;
   issue_tile_loads<LEARN, K>(P, d, t, f);
   if (s_agg) {   // the first __syncthreads of the loop orders this before any use
     for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) s_agg[i] = 0;
@@ -1130,8 +1134,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, LEARN ? 2 : 3) sweep8_kernel(co
         }
       }
 #pragma unroll
-      for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k) s_rowptr[t + k * BLOCK_THREADS] = f.rp[k];
-      for (uint32_t i = t + ROWPTR_UNROLL * BLOCK_THREADS; i <= d.nrows; i += BLOCK_THREADS)
+      for (uint32_t k = 0; k < (uint32_t)RP; ++k) s_rowptr[t + k * BLOCK_THREADS] = f.rp[k];
+      for (uint32_t i = t + RP * BLOCK_THREADS; i <= d.nrows; i += BLOCK_THREADS)
         s_rowptr[i] = P.row_ptr[d.r0 + i];
       __syncthreads();
     }
