@@ -347,40 +347,15 @@ DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row
     // would bloat the kernel far beyond the instruction cache.)
     double pot[SMALL_CARD];
     double m = -1e300;
-    if (WMODE == W_TERMS) {
-      // staged terms: all row pointers first, then the k-th term of EVERY row together (the
-      // rows are independent sums; each stays sequential in k) -- SMALL_CARD LDS reads in
-      // flight instead of a dependent pointer + term read per value
-      uint32_t rp[SMALL_CARD + 1];
+    uint32_t es = T.rowptr[row0 - T.row_bias];
 #pragma unroll
-      for (uint32_t d = 0; d <= SMALL_CARD; ++d) rp[d] = T.rowptr[row0 + umin(d, card) - T.row_bias];
-      uint32_t maxlen = 0;
-#pragma unroll
-      for (uint32_t d = 0; d < SMALL_CARD; ++d) { pot[d] = 0.0; maxlen = rp[d + 1] - rp[d] > maxlen ? rp[d + 1] - rp[d] : maxlen; }
-      const EdgeTerms *terms = (const EdgeTerms *)T.edges;
-      for (uint32_t k = 0; k < maxlen; ++k) {
-        double t1[SMALL_CARD];
-#pragma unroll
-        for (uint32_t d = 0; d < SMALL_CARD; ++d) t1[d] = terms[umin(rp[d] + k, rp[SMALL_CARD] - 1) - T.edge_bias].t1;
-#pragma unroll
-        for (uint32_t d = 0; d < SMALL_CARD; ++d) pot[d] += (rp[d] + k < rp[d + 1]) ? t1[d] : 0.0;
-      }
-#pragma unroll
-      for (uint32_t d = 0; d < SMALL_CARD; ++d) {
-        if (d >= card) pot[d] = -1e300;
+    for (uint32_t d = 0; d < SMALL_CARD; ++d) {
+      pot[d] = -1e300;
+      if (d < card) {
+        const uint32_t ee = T.rowptr[row0 + d + 1 - T.row_bias];
+        pot[d] = range_potential<WMODE, SIMPLE>(P, T, es, ee, assign, me, d);
+        es = ee;
         m = pot[d] > m ? pot[d] : m;
-      }
-    } else {
-      uint32_t es = T.rowptr[row0 - T.row_bias];
-#pragma unroll
-      for (uint32_t d = 0; d < SMALL_CARD; ++d) {
-        pot[d] = -1e300;
-        if (d < card) {
-          const uint32_t ee = T.rowptr[row0 + d + 1 - T.row_bias];
-          pot[d] = range_potential<WMODE, SIMPLE>(P, T, es, ee, assign, me, d);
-          es = ee;
-          m = pot[d] > m ? pot[d] : m;
-        }
       }
     }
     float ex[SMALL_CARD];
@@ -1061,8 +1036,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
 // rcap + 1 = 1537 -- with RP = 7 all of them ride the prefetch instead of being loaded and
 // awaited while staging (config 4: 0.296 -> 0.246 ms); boolean graphs keep 2 (the extra
 // loads cost config 3's repeated inference 15 %).
+// (3 workgroups per CU also when learning: pull-gradient tiles stage 16-byte terms only)
 template <bool LEARN, int K, bool TAB = false, int RP = (int)ROWPTR_UNROLL>
-__global__ void __launch_bounds__(BLOCK_THREADS, LEARN ? 2 : 3) sweep8_kernel(const KernelParams P) {
+__global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep8_kernel(const KernelParams P) {
   static_assert(!(LEARN && TAB), "the terms table serves inference sweeps only");
   DWX_DYN_LDS(dyn_lds);
   uint32_t *s_rowptr = (uint32_t *)dyn_lds;
