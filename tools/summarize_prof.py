@@ -17,6 +17,10 @@ def short(name):
         return "sweep8_kernel<LEARN=false>"
     if "pull_grad_kernel" in name:
         return "pull_grad_kernel"
+    if "pull_ell_kernel" in name:
+        return "pull_ell_kernel"
+    if "fold_partials_kernel" in name:
+        return "fold_partials_kernel"
     if "sweep_kernel<true" in name or "sweep_kernelILb1" in name:
         return "sweep_kernel<LEARN=true>"
     if "sweep_kernel<false" in name or "sweep_kernelILb0" in name:
