@@ -116,6 +116,8 @@ struct dwx_sampler {
   bool all_pull = false;
   size_t lds_learn_pull = 0;
   unsigned persistent_blocks_pull = 1;   // REC8 learning kernel at lds_learn_pull
+  size_t lds_tab = 0;                    // inference on the 8-byte terms table: 8 bytes staged per record
+  unsigned persistent_blocks_tab = 1;
   EdgeRec8 *d_edges8 = nullptr;
   double *d_row_truth = nullptr, *d_edge_fval64 = nullptr;
   EdgeRec *d_edges = nullptr;
@@ -199,9 +201,9 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   const bool rec8 = s->rec8;
   const bool tab8 = rec8 && !LEARN && P.edge_terms;   // inference on the 8-byte terms table
   const bool slim = LEARN && rec8 && s->all_pull && !(P.flags & OPT_NO_PULL);
-  const unsigned grid = std::min<unsigned>(t1 - t0, slim ? s->persistent_blocks_pull :
+  const unsigned grid = std::min<unsigned>(t1 - t0, tab8 ? s->persistent_blocks_tab : slim ? s->persistent_blocks_pull :
                                            (rec8 ? s->persistent_blocks8 : s->persistent_blocks)[LEARN ? 1 : 0]);
-  const size_t lds = slim ? s->lds_learn_pull : s->lds_bytes[LEARN ? 1 : 0];
+  const size_t lds = tab8 ? s->lds_tab : slim ? s->lds_learn_pull : s->lds_bytes[LEARN ? 1 : 0];
   constexpr int RPC = (int)ROWPTR_UNROLL_CAT;
   if (rec8 && s->rp_cat) {
     if (tab8) rt::launch(sweep8_kernel<false, 6, true, RPC>, grid, BLOCK_THREADS, lds, s->stream, P);
@@ -1102,15 +1104,20 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
         s->persistent_blocks8[1] = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_bytes[1]);
         s->persistent_blocks_pull = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_learn_pull);
       };
+      s->lds_tab = P.lds_edge_off + (size_t)s->stage_k * BLOCK_THREADS * 8;
+      auto prepare_tab = [&](auto tab) {
+        rt::allow_dynamic_lds(tab, s->lds_tab);
+        s->persistent_blocks_tab = rt::resident_blocks(tab, BLOCK_THREADS, s->lds_tab);
+      };
       if (s->rp_cat) {
         constexpr int RPC = (int)ROWPTR_UNROLL_CAT;
         prepare8(sweep8_kernel<false, 6, false, RPC>, sweep8_kernel<true, 6, false, RPC>);
-        rt::allow_dynamic_lds(sweep8_kernel<false, 6, true, RPC>, s->lds_bytes[0]);
+        prepare_tab(sweep8_kernel<false, 6, true, RPC>);
       } else
       switch (s->stage_k) {
-        case 3: prepare8(sweep8_kernel<false, 3>, sweep8_kernel<true, 3>); rt::allow_dynamic_lds(sweep8_kernel<false, 3, true>, s->lds_bytes[0]); break;
-        case 6: prepare8(sweep8_kernel<false, 6>, sweep8_kernel<true, 6>); rt::allow_dynamic_lds(sweep8_kernel<false, 6, true>, s->lds_bytes[0]); break;
-        default: prepare8(sweep8_kernel<false, 12>, sweep8_kernel<true, 12>); rt::allow_dynamic_lds(sweep8_kernel<false, 12, true>, s->lds_bytes[0]); break;
+        case 3: prepare8(sweep8_kernel<false, 3>, sweep8_kernel<true, 3>); prepare_tab(sweep8_kernel<false, 3, true>); break;
+        case 6: prepare8(sweep8_kernel<false, 6>, sweep8_kernel<true, 6>); prepare_tab(sweep8_kernel<false, 6, true>); break;
+        default: prepare8(sweep8_kernel<false, 12>, sweep8_kernel<true, 12>); prepare_tab(sweep8_kernel<false, 12, true>); break;
       }
     }
     rt::stream_sync(st);

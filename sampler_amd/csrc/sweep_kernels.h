@@ -182,7 +182,9 @@ DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const Vi
 //              (inference kernel: no extra LDS)
 //   W_TERMS    (inference, SIMPLE tiles) the staging pass replaced each record by its
 //              two potential terms (w*(s1*f), w*(s0*f)); the row walk only adds
-enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3 };
+//   W_TERMS8   (inference on the 8-byte terms table) the table's entries as they are: w * f with
+//              the two sign codes in its lowest mantissa bits; the row walk decodes and adds
+enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4 };
 
 struct alignas(16) EdgeTerms { double t1, t0; };
 // Table entry of a record of a TILE_INLINE2 tile (build_terms_kernel), overlaying an EdgeRec:
@@ -202,6 +204,16 @@ DWX_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 #define DWX_WALK_BATCH 5
 #endif
 constexpr uint32_t WALK_BATCH = DWX_WALK_BATCH;   // staged terms read per step of a row walk
+
+// entry of the 8-byte terms table (build_terms8_kernel): the f64 product w * f with sign(hit) + 1
+// in bits 0-1 and sign(miss) + 1 in bits 2-3 of its mantissa (always zero in such a product)
+DWX_DEV double terms8_pick(unsigned long long u, uint32_t code) {
+  const unsigned long long v = u & ~15ull;
+  double wf; __builtin_memcpy(&wf, &v, 8);
+  return code == 1u ? 0.0 : (code == 0u ? -wf : wf);
+}
+DWX_DEV double terms8_hit(unsigned long long u) { return terms8_pick(u, (uint32_t)u & 3u); }
+DWX_DEV double terms8_miss(unsigned long long u) { return terms8_pick(u, ((uint32_t)u >> 2) & 3u); }
 
 struct TileView {
   const uint32_t *rowptr;  // indexed by (row - row_bias)
@@ -249,6 +261,18 @@ template <int WMODE, bool SIMPLE>
 DWX_DEV double range_potential(const KernelParams &P, const TileView &T, uint32_t es, uint32_t ee,
                                const uint32_t *assign, uint32_t me, uint32_t proposal) {
   double pot = 0.0;
+  if (WMODE == W_TERMS8) {
+    const unsigned long long *tab = (const unsigned long long *)T.edges;
+    if (ee - es == 1u) return pot + terms8_hit(tab[es - T.edge_bias]);
+    for (uint32_t e = es; e < ee; e += WALK_BATCH) {
+      unsigned long long u[WALK_BATCH];
+#pragma unroll
+      for (uint32_t k = 0; k < WALK_BATCH; ++k) u[k] = tab[umin(e + k, ee - 1) - T.edge_bias];
+#pragma unroll
+      for (uint32_t k = 0; k < WALK_BATCH; ++k) pot += (e + k < ee) ? terms8_hit(u[k]) : 0.0;
+    }
+    return pot;
+  }
   if (WMODE == W_TERMS) {
     // WALK_BATCH LDS reads in flight per step instead of one dependent read per record; the
     // additions stay sequential and in row order (a slot past the end re-reads the last
@@ -286,6 +310,21 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
                              const uint32_t *assign, uint32_t me, double &pp, double &pn) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   pp = 0.0; pn = 0.0;
+  if (WMODE == W_TERMS8) {
+    const unsigned long long *tab = (const unsigned long long *)T.edges;
+    for (uint32_t e = es; e < ee; e += WALK_BATCH) {
+      unsigned long long u[WALK_BATCH];
+#pragma unroll
+      for (uint32_t k = 0; k < WALK_BATCH; ++k) u[k] = tab[umin(e + k, ee - 1) - T.edge_bias];
+#pragma unroll
+      for (uint32_t k = 0; k < WALK_BATCH; ++k) {
+        const bool in = e + k < ee;
+        pp += in ? terms8_hit(u[k]) : 0.0;
+        pn += in ? terms8_miss(u[k]) : 0.0;
+      }
+    }
+    return;
+  }
   if (WMODE == W_TERMS) {
     const EdgeTerms *terms = (const EdgeTerms *)T.edges;   // batched as in range_potential
     for (uint32_t e = es; e < ee; e += WALK_BATCH) {
@@ -675,8 +714,6 @@ DWX_DEV float rec8_signed(uint32_t code, float f) {   // code = sign + 1
   const uint32_t b = float_to_bits(f);
   return bits_to_float(code == 1u ? 0u : (code == 0u ? (b ^ 0x80000000u) : b));
 }
-// one potential term from a table entry: code = sign + 1 (as in EdgeRec8), wf = w * f
-DWX_DEV double terms8_signed(uint32_t code, double wf) { return code == 1u ? 0.0 : (code == 0u ? -wf : wf); }
 DWX_DEV EdgeRec expand_record(const EdgeRec8 &c) {
   EdgeRec r;
   r.wid = c.key & REC8_WID_MASK;
@@ -1038,7 +1075,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) swe
 // loads cost config 3's repeated inference 15 %).
 // (3 workgroups per CU also when learning: pull-gradient tiles stage 16-byte terms only)
 template <bool LEARN, int K, bool TAB = false, int RP = (int)ROWPTR_UNROLL>
-__global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep8_kernel(const KernelParams P) {
+__global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : 3) sweep8_kernel(const KernelParams P) {
   static_assert(!(LEARN && TAB), "the terms table serves inference sweeps only");
   DWX_DYN_LDS(dyn_lds);
   uint32_t *s_rowptr = (uint32_t *)dyn_lds;
@@ -1076,16 +1113,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep8_kernel(const KernelPa
       // ... and this lane's uniforms while the gathers are in flight
       philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
       if (TAB) {
-        EdgeTerms *s_terms = (EdgeTerms *)s_edges;
+        // the table's entries go to LDS as they are (8 bytes per record: half the staging
+        // area of the other modes, one more workgroup per CU); the row walk decodes them
+        EdgeRec8 *s_tab = (EdgeRec8 *)s_edges;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const uint32_t lo = f.rec[k].key, hi = float_to_bits(f.rec[k].f);
-          const double wf = u32x2_to_double(lo & ~15u, hi);
-          EdgeTerms tt;
-          tt.t1 = terms8_signed(lo & 3u, wf);
-          tt.t0 = terms8_signed((lo >> 2) & 3u, wf);
-          s_terms[t + k * BLOCK_THREADS] = tt;
-        }
+        for (int k = 0; k < K; ++k) s_tab[t + k * BLOCK_THREADS] = f.rec[k];
       } else if (!LEARN || pull) {
         // the two potential terms of every record, edge-parallel and straight-line:
         // t1 = w * (sign(hit) * f), t0 = w * (sign(miss) * f) -- the products of
@@ -1130,7 +1162,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 3) sweep8_kernel(const KernelPa
       if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
         delta = process_variable<LEARN, W_TERMS, true>(P, T, d.v0 + t, pre, A, B, true);
       else
-        process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B, false);
+        process_variable<LEARN, LEARN ? W_ARRAY : (TAB ? W_TERMS8 : W_TERMS), true>(P, T, d.v0 + t, pre, A, B, false);
     }
     if (pull) {
       const unsigned long long nz = DWX_BALLOT(delta != 0), ng = DWX_BALLOT(delta < 0);
