@@ -69,6 +69,14 @@ T *upload(const std::vector<T> &v, rt::stream_t s, size_t pad = 0) {
 }
 
 template <class T>
+T *upload(const RawArray<T> &v, rt::stream_t s, size_t pad = 0) {
+  T *d = (T *)rt::dmalloc((v.size() + pad) * sizeof(T));
+  rt::h2d(d, v.data(), v.size() * sizeof(T), s);
+  if (pad) rt::dmemset(d + v.size(), 0, pad * sizeof(T), s);
+  return d;
+}
+
+template <class T>
 T *upload_raw(const T *h, size_t n, rt::stream_t s) {
   T *d = (T *)rt::dmalloc(n * sizeof(T));
   rt::h2d(d, h, n * sizeof(T), s);
@@ -1009,7 +1017,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     if (!c.row_truth.empty()) s->d_row_truth = upload(c.row_truth, st);
     if (!c.edge_fval64.empty()) s->d_edge_fval64 = upload(c.edge_fval64, st);
     s->d_edges = upload(c.edges, st, 1);
-    s->rec8 = !c.edges8.empty();
+    s->rec8 = c.edges8.size() != 0;
     if (s->rec8) s->d_edges8 = upload(c.edges8, st, 1);
     s->d_vifs = upload(c.vifs, st);
     // InferenceResult init (src/inference_result.cc:24-42): both chains start at the
@@ -1053,7 +1061,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     if (c.ecap > MAX_ECAP) throw std::invalid_argument("tile_edges exceeds the staging capacity");
     s->stage_k = c.ecap <= 3 * BLOCK_THREADS ? 3 : (c.ecap <= 6 * BLOCK_THREADS ? 6 : 12);
     const size_t slots = (size_t)s->stage_k * BLOCK_THREADS;
-    s->rp_cat = !c.edges8.empty() && c.has_categorical && s->stage_k == 6;
+    s->rp_cat = c.edges8.size() != 0 && c.has_categorical && s->stage_k == 6;
     const size_t nrp = std::max<size_t>(c.rcap + 1, (s->rp_cat ? ROWPTR_UNROLL_CAT : ROWPTR_UNROLL) * BLOCK_THREADS);
     size_t off = (nrp * 4 + 15) & ~(size_t)15;
     P.lds_pot_off = c.has_categorical ? (uint32_t)off : 0u;

@@ -184,7 +184,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     phase("domains, value numbering");
     // ---- factors: dense predicates + per-variable back-refs
     //      (src/binary_format.cc:128-190) ----
-    std::vector<uint32_t> edge_dense(E);
+    RawArray<uint32_t> edge_dense(E);   // (every entry is written by the parallel pass below)
     parallel_ranges(F, nth, [&](uint64_t fb, uint64_t fe) {
       for (uint64_t f = fb; f < fe; ++f) {
         uint64_t lo = d.fac_edge_offset[f], hi = d.fac_edge_offset[f + 1];
@@ -245,7 +245,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     for (uint64_t r = 0; r < R; ++r) g.ref_row_ptr[r + 1] = g.ref_row_ptr[r] + row_len[r];
     g.NIdx = g.ref_row_ptr[R];
     if (g.NIdx >= kUnset) throw LimitError("index entries exceed 2^32-1");
-    g.ref_fidx.resize(g.NIdx);
+    g.ref_fidx.reset(g.NIdx);
     parallel_ranges(V, nth, [&](uint64_t vb, uint64_t ve) {
       for (uint64_t v = vb; v < ve; ++v) {
         uint64_t src = start[v], dst = g.ref_row_ptr[g.ref_var_val_base[v]];
@@ -337,12 +337,31 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
 
     phase("device rows");
     // ---- vifs of factors with arity >= 2 ----
-    std::vector<uint32_t> vif_base(F, 0);
+    // (parallel prefix sum over the factors: per-part totals, then per-part fills)
+    RawArray<uint32_t> vif_base(F);
     uint64_t nvif = 0;
-    for (uint64_t f = 0; f < F; ++f) {
-      uint64_t a = d.fac_edge_offset[f + 1] - d.fac_edge_offset[f];
-      if (a >= 2) { vif_base[f] = (uint32_t)nvif; nvif += a; }
+    {
+      const uint32_t T = std::max(1u, nth);
+      std::vector<uint64_t> part(T + 1, 0);
+      parallel_parts(F, T, [&](uint32_t t, uint64_t fb, uint64_t fe) {
+        uint64_t n = 0;
+        for (uint64_t f = fb; f < fe; ++f) {
+          const uint64_t a = d.fac_edge_offset[f + 1] - d.fac_edge_offset[f];
+          if (a >= 2) n += a;
+        }
+        part[t + 1] = n;
+      });
+      for (uint32_t t = 0; t < T; ++t) part[t + 1] += part[t];
+      nvif = part[T];
       if (nvif >= kUnset) throw LimitError("vif entries exceed 2^32-1");
+      parallel_parts(F, T, [&](uint32_t t, uint64_t fb, uint64_t fe) {
+        uint64_t n = part[t];
+        for (uint64_t f = fb; f < fe; ++f) {
+          const uint64_t a = d.fac_edge_offset[f + 1] - d.fac_edge_offset[f];
+          vif_base[f] = a >= 2 ? (uint32_t)n : 0u;
+          if (a >= 2) n += a;
+        }
+      });
     }
     g.NVif = nvif;
     g.vifs.resize(nvif + 2);   // + 2 padding entries: branch-free pair loads of non-binary records
@@ -357,7 +376,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
 
     phase("vifs");
     // ---- edge records, variable-major in device order ----
-    g.edges.resize(g.NIdx);
+    g.edges.reset(g.NIdx);
     std::atomic<bool> need64{false};
     parallel_ranges(Vo, nth, [&](uint64_t pb, uint64_t pe) {
       for (uint64_t p = pb; p < pe; ++p) {
@@ -515,7 +534,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       for (size_t i = 0; i < g.tiles.size() && all_simple; ++i) all_simple = (g.tiles[i].flags & TILE_SIMPLE) != 0;
       g.edges8.clear();
       if (all_simple) {
-        g.edges8.resize(g.NIdx);
+        g.edges8.reset(g.NIdx);
         parallel_ranges(g.NIdx, nth, [&](uint64_t eb, uint64_t ee) {
           for (uint64_t e = eb; e < ee; ++e) {
             const EdgeRec &r = g.edges[e];

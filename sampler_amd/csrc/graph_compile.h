@@ -16,6 +16,7 @@
 
 #include "../../include/dwx.h"
 #include "device_types.h"
+#include "host_parallel.h"
 
 namespace dwx {
 
@@ -35,7 +36,7 @@ struct CompiledGraph {
   std::vector<uint64_t> ref_var_val_base;  // [V]
   std::vector<uint64_t> value_sparse;      // [R]   values[].value
   std::vector<uint64_t> ref_row_ptr;       // [R+1] into ref_fidx
-  std::vector<uint32_t> ref_fidx;          // [NIdx] factor ids, reference order
+  RawArray<uint32_t> ref_fidx;             // [NIdx] factor ids, reference order
 
   // ---- device order ----
   std::vector<uint32_t> perm;      // [V] position -> original variable id
@@ -45,8 +46,8 @@ struct CompiledGraph {
   std::vector<uint32_t> v_row;     // [V+1]
   std::vector<uint32_t> row_ptr;   // [R+1]
   std::vector<double> row_truth;   // [R] or empty
-  std::vector<EdgeRec> edges;      // [NIdx]
-  std::vector<EdgeRec8> edges8;    // [NIdx] when every tile is TILE_SIMPLE (and W < 2^27), else empty
+  RawArray<EdgeRec> edges;         // [NIdx] (uninitialised storage: first touch inside the parallel fill)
+  RawArray<EdgeRec8> edges8;       // [NIdx] when every tile is TILE_SIMPLE (and W < 2^27), else empty
   std::vector<double> edge_fval64; // [NIdx] or empty
   std::vector<VifRec> vifs;        // [NVif]
   std::vector<uint32_t> tile_v;       // [n_tiles+1]
