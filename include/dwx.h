@@ -146,6 +146,11 @@ int dwx_graph_get_index(const dwx_graph *g, uint64_t *index_base, uint64_t *inde
  * (src/gibbs_sampler.cc:5-18) incl. the InferenceResult it owns
  * (src/inference_result.cc:24-42). */
 int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler **out);
+/* Optional: pay the HIP runtime's start-up (context creation on `device`) now -- e.g. on a
+ * helper thread while dwx_graph_create, which is host-only, runs.  dwx_sampler_create does
+ * the same on its own if this was never called.  (No reference counterpart: the reference
+ * has no device.) */
+int dwx_device_init(int32_t device);
 void dwx_sampler_destroy(dwx_sampler *s);
 
 /* GibbsSampler::sample(i_epoch) (src/gibbs_sampler.cc:20-25): one inference sweep. */

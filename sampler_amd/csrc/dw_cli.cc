@@ -551,6 +551,10 @@ int gibbs(const CmdLine &args) {
       if (timing) std::cerr << "[dw timing] " << what << ": " << t - t_phase << " s" << std::endl;
       t_phase = t;
     };
+    // the HIP runtime starts up (0.2 s) on a helper thread while the files are read and the
+    // graph is compiled; a failure there is reported by dwx_sampler_create
+    std::thread hip_start([&]() { (void)dwx_device_init(args.device); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } hip_start_joiner{hip_start};
     LoadedGraph lg;
     read_meta(args.fg_file, lg);
     std::cout << "Factor graph to load:\t#V=" << lg.n_variables << " #F=" << lg.n_factors
@@ -590,6 +594,7 @@ int gibbs(const CmdLine &args) {
     o.reg_param = args.reg_param;
     o.seed = args.seed;
     o.step_cap = args.step_cap;
+    hip_start.join();
     ok(dwx_sampler_create(graph, &o, &sampler));
     phase("dwx_sampler_create (upload, gradient incidence list, curvature estimate)");
 
@@ -719,8 +724,10 @@ int gibbs(const CmdLine &args) {
     std::cerr << "dw: " << e.what() << std::endl;
     exit_code = 1;
   }
+  const double t_down = now();
   dwx_sampler_destroy(sampler);
   dwx_graph_destroy(graph);
+  if (getenv("DWX_TIMING")) std::cerr << "[dw timing] teardown (device + graph): " << now() - t_down << " s" << std::endl;
   return exit_code;
 }
 

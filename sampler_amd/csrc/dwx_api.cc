@@ -1164,6 +1164,13 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
   return DWX_OK;
 }
 
+int dwx_device_init(int32_t device) {
+  return guarded([&]() {
+    rt::init_device(device);
+    rt::dfree(rt::dmalloc(16));   // forces the context
+  });
+}
+
 void dwx_sampler_destroy(dwx_sampler *s) {
   if (!s) return;
   try {
@@ -1331,17 +1338,21 @@ int dwx_get_tallies(dwx_sampler *s, uint64_t *tallies, uint64_t *nsamples) {
     const CompiledGraph &c = *s->cg;
     rt::set_device(s->device);
     if (tallies) {
-      std::vector<uint32_t> t(c.R);
+      RawArray<uint32_t> t(c.R);
       rt::d2h(t.data(), s->d_tally, c.R * 4, s->stream);
       rt::stream_sync(s->stream);
-      for (uint64_t p = 0; p < c.Vo; ++p) {
-        const uint64_t rb = c.ref_var_val_base[c.perm[p]];
-        for (uint32_t r = c.v_row[p]; r < c.v_row[p + 1]; ++r) tallies[rb + (r - c.v_row[p])] = t[r];
-      }
+      parallel_ranges(c.Vo, host_threads(), [&](uint64_t pb, uint64_t pe) {
+        for (uint64_t p = pb; p < pe; ++p) {
+          const uint64_t rb = c.ref_var_val_base[c.perm[p]];
+          for (uint32_t r = c.v_row[p]; r < c.v_row[p + 1]; ++r) tallies[rb + (r - c.v_row[p])] = t[r];
+        }
+      });
     }
     if (nsamples)  // agg_nsamples: +1 per inference sweep for every sampled variable
-      for (uint64_t v = 0; v < c.V; ++v)
-        nsamples[v] = (v < c.Vo && (!c.var_is_evid[v] || s->opts.sample_evidence)) ? s->infer_sweeps : 0;
+      parallel_ranges(c.V, host_threads(), [&](uint64_t vb, uint64_t ve) {
+        for (uint64_t v = vb; v < ve; ++v)
+          nsamples[v] = (v < c.Vo && (!c.var_is_evid[v] || s->opts.sample_evidence)) ? s->infer_sweeps : 0;
+      });
   });
 }
 

@@ -24,7 +24,7 @@ SYMBOLS = [
     "dwx_last_error", "dwx_version", "dwx_default_options",
     "dwx_graph_create", "dwx_graph_destroy", "dwx_graph_get_info", "dwx_graph_get_schedule",
     "dwx_graph_get_values", "dwx_graph_get_positions", "dwx_graph_get_index",
-    "dwx_sampler_create", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
+    "dwx_sampler_create", "dwx_device_init", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
     "dwx_wait", "dwx_sgd_plan", "dwx_sgd_curvature", "dwx_sgd_plan_rows", "dwx_sgd_get_chunks", "dwx_sgd_accumulate_async",
     "dwx_sgd_apply_async", "dwx_sgd_finish",
     "dwx_get_weights", "dwx_set_weights", "dwx_average_weights_async",
