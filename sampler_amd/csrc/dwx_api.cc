@@ -575,8 +575,10 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
           L->d_bp_qtab = upload(qtab, s->stream);
           L->d_bp_partial = (long long *)rt::dmalloc(max_blocks * Wp * 8);
           L->bp_deltas = (uint32_t)dvals.size(); L->bp_wp = (uint32_t)Wp;
-          rt::allow_dynamic_lds(pull_ell_kernel<1>, BP_LDS_BYTES);
-          rt::allow_dynamic_lds(pull_ell_kernel<2>, BP_LDS_BYTES);
+          rt::allow_dynamic_lds(pull_ell_kernel<1, false>, BP_LDS_BYTES);
+          rt::allow_dynamic_lds(pull_ell_kernel<2, false>, BP_LDS_BYTES);
+          rt::allow_dynamic_lds(pull_ell_kernel<1, true>, BP_LDS_BYTES);
+          rt::allow_dynamic_lds(pull_ell_kernel<2, true>, BP_LDS_BYTES);
           rt::stream_sync(s->stream);
           by_w.clear(); by_c.clear();
           src = &kept;
@@ -827,14 +829,14 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
     const dwx_sampler::Level::BlockTable &bt = L.bp[split ? chunk : 0];
     if (bt.blocks) {
       const unsigned grid = bt.blocks * bt.parts;
-      if (bt.depth == 2)
-        rt::launch(pull_ell_kernel<2>, grid, BP_THREADS, BP_LDS_BYTES, s->stream, (const U32x4 *)bt.d_ell,
+      auto go = [&](auto kernel) {
+        rt::launch(kernel, grid, BP_THREADS, BP_LDS_BYTES, s->stream, (const U32x4 *)bt.d_ell,
                    (const uint32_t *)bt.d_tile0, bt.parts, (const long long *)L.d_bp_qtab, L.bp_deltas, L.bp_wp,
                    (const unsigned long long *)s->d_delta, L.d_bp_partial);
-      else
-        rt::launch(pull_ell_kernel<1>, grid, BP_THREADS, BP_LDS_BYTES, s->stream, (const U32x4 *)bt.d_ell,
-                   (const uint32_t *)bt.d_tile0, bt.parts, (const long long *)L.d_bp_qtab, L.bp_deltas, L.bp_wp,
-                   (const unsigned long long *)s->d_delta, L.d_bp_partial);
+      };
+      const bool uni = L.bp_deltas == 1;
+      if (bt.depth == 2) { if (uni) go(pull_ell_kernel<2, true>); else go(pull_ell_kernel<2, false>); }
+      else { if (uni) go(pull_ell_kernel<1, true>); else go(pull_ell_kernel<1, false>); }
       const uint32_t W = (uint32_t)s->cg->W;
       rt::launch(fold_partials_kernel, std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 4096u), BLOCK_THREADS, 0,
                  s->stream, (const long long *)L.d_bp_partial, bt.blocks, L.bp_wp, W, s->d_grad);

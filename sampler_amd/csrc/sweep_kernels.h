@@ -1350,7 +1350,9 @@ pull_grad_kernel(const uint32_t *inc_wid, const uint32_t *inc_slot, const float 
 // streams its share of b's rows -- coalesced 16-byte loads, independent iterations, no
 // barrier -- and stores one partial sum per weight; fold_partials_kernel adds the blocks'
 // partials into grad.  Integer sums: the result equals pull_grad_kernel's.
-template <int DEPTH>
+// UNIFORM: every record delta of the graph is the same (one feature value, one factor
+// function -- the usual case): its step comes in as an argument instead of an LDS table.
+template <int DEPTH, bool UNIFORM>
 __global__ void __launch_bounds__(BP_THREADS)
 pull_ell_kernel(const U32x4 *ell, const uint32_t *block_tile0, uint32_t parts, const long long *qtab,
                 uint32_t n_deltas, uint32_t Wp, const unsigned long long *delta, long long *partial) {
@@ -1364,7 +1366,10 @@ pull_ell_kernel(const U32x4 *ell, const uint32_t *block_tile0, uint32_t parts, c
   const uint32_t b = blockIdx.x / parts, part = blockIdx.x % parts;
   const DeltaPair *src = (const DeltaPair *)delta + (size_t)block_tile0[b] * 4;   // (padded allocation)
   for (uint32_t i = tid; i < PAIRS; i += BP_THREADS) s_delta[i] = src[i];
-  for (uint32_t i = tid; i < BP_DELTA_SLOTS; i += BP_THREADS) s_q[i] = i < n_deltas ? qtab[i] : 0;
+  if (!UNIFORM)
+    for (uint32_t i = tid; i < BP_DELTA_SLOTS; i += BP_THREADS) s_q[i] = i < n_deltas ? qtab[i] : 0;
+  const long long q0 = qtab[0];
+  const uint32_t *s_words = (const uint32_t *)s_delta;
   __syncthreads();
   // this part's weights: whole groups of BP_THREADS
   const uint32_t groups = Wp / BP_THREADS, per = (groups + parts - 1) / parts;
@@ -1380,12 +1385,16 @@ pull_ell_kernel(const U32x4 *ell, const uint32_t *block_tile0, uint32_t parts, c
       const U32x4 row = rows[(size_t)dd * Wp + w];
 #pragma unroll
       for (uint32_t k = 0; k < BP_ROW; ++k) {
-        // branch-free: an empty entry decodes to the block's last slot and to a zero step
+        // branch-free: an empty entry decodes to the block's last slot and to a zero step.
+        // Only the two 32-bit words that hold the owner's bits are read (a ballot pair is
+        // {nz lo, nz hi, ng lo, ng hi}), and no step table when all deltas are equal.
         const uint32_t e = row.v[k];
         const uint32_t slot = e & BP_SLOT_MASK;
-        const DeltaPair dp = s_delta[slot >> 6];
-        const long long q = s_q[(e >> BP_SLOT_BITS) & (BP_DELTA_SLOTS - 1)];
-        const bool nz = (dp.nz >> (slot & 63u)) & 1ull, ng = (dp.ng >> (slot & 63u)) & 1ull;
+        const uint32_t word = (slot >> 6) * 4u + ((slot >> 5) & 1u);
+        const uint32_t nzw = s_words[word], ngw = s_words[word + 2u];
+        const bool valid = UNIFORM ? (e != BP_EMPTY) : true;
+        const long long q = UNIFORM ? q0 : s_q[(e >> BP_SLOT_BITS) & (BP_DELTA_SLOTS - 1)];
+        const bool nz = valid && ((nzw >> (slot & 31u)) & 1u), ng = (ngw >> (slot & 31u)) & 1u;
         acc += nz ? (ng ? -q : q) : 0;
       }
     }
