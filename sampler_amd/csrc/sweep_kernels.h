@@ -204,6 +204,10 @@ DWX_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 #define DWX_WALK_BATCH 5
 #endif
 constexpr uint32_t WALK_BATCH = DWX_WALK_BATCH;   // staged terms read per step of a row walk
+#ifndef DWX_LEARN_BATCH
+#define DWX_LEARN_BATCH 4
+#endif
+constexpr uint32_t LEARN_BATCH = DWX_LEARN_BATCH; // staged 32-byte learning records read per step
 
 // entry of the 8-byte terms table (build_terms8_kernel): the f64 product w * f with sign(hit) + 1
 // in bits 0-1 and sign(miss) + 1 in bits 2-3 of its mantissa (always zero in such a product)
@@ -637,11 +641,19 @@ DWX_DEV void learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr
   const bool noise_aware = P.flags & OPT_NOISE_AWARE;
   const uint32_t es = rowptr[pre.row0 - row_bias], ee = rowptr[pre.row0 + 1 - row_bias];
   double ppf = 0.0, pnf = 0.0, ppe = 0.0, pne = 0.0;
-  for (uint32_t e = es; e < ee; ++e) {
-    const LearnRec r = recs[e - edge_bias];
-    const double w = (double)r.w;
-    ppf += w * (double)r.sf1; pnf += w * (double)r.sf0;
-    ppe += w * (double)r.se1; pne += w * (double)r.se0;
+  // LEARN_BATCH staged records per step (all LDS reads in flight); sums stay sequential and in
+  // row order, a slot past the end adds +0.0 (cannot change a running sum)
+  for (uint32_t e = es; e < ee; e += LEARN_BATCH) {
+    LearnRec r[LEARN_BATCH];
+#pragma unroll
+    for (uint32_t u = 0; u < LEARN_BATCH; ++u) r[u] = recs[umin(e + u, ee - 1) - edge_bias];
+#pragma unroll
+    for (uint32_t u = 0; u < LEARN_BATCH; ++u) {
+      const bool in = e + u < ee;
+      const double w = (double)r[u].w;
+      ppf += in ? w * (double)r[u].sf1 : 0.0; pnf += in ? w * (double)r[u].sf0 : 0.0;
+      ppe += in ? w * (double)r[u].se1 : 0.0; pne += in ? w * (double)r[u].se0 : 0.0;
+    }
   }
   const uint32_t p_free = bool_draw(A, ppf, pnf);
   P.assign_free[p] = p_free;
