@@ -89,6 +89,13 @@ def test_block_pull(lib, monkeypatch, block_tiles, depth_hint):
     run_parity(lib, raw, n_learn=4, n_infer=2, stepsize=0.02, step_cap=0.0, compile_opts=dict(tile_vars=16))
     run_parity(lib, raw, n_learn=3, n_infer=1, stepsize=0.02, step_cap=0.0, learn_non_evidence=True,
                compile_opts=dict(tile_vars=16, no_compact_records=1))
+    # mixed graph: pull-gradient tiles next to tiles with binary factors and categorical
+    # variables (those scatter their gradient), several colours, an oversized variable
+    raw = random_graph(8, V=1500, F=9000, W=1300, p_cat=0.3)
+    run_parity(lib, raw, n_learn=4, n_infer=2, stepsize=0.05, step_cap=0.0, learn_non_evidence=True,
+               compile_opts=dict(tile_vars=32))
+    run_parity(lib, raw, n_learn=3, n_infer=1, stepsize=0.05, step_cap=0.0,
+               compile_opts=dict(tile_vars=8, tile_edges=40, tile_rows=12))
 
 
 def test_small_tiles_and_giant_variable(lib):
