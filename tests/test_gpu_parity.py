@@ -102,6 +102,25 @@ def test_cfg2_full_size_closed_form(lib):
     assert np.array_equal(s2.tallies()[0], s.tallies()[0])
 
 
+def test_cfg3_full_size_exact_against_oracle(lib):
+    """The bench's own workload at full size (config 3: 10 M variables, 100 M factors, 1 M
+    weights): two learning sweeps (sweep8_kernel, block pull, apply) and two inference sweeps
+    (weight gathers, then the 8-byte terms table) -- assignments of both chains and tallies
+    bit for bit, weights to 1e-12, against the oracle."""
+    raw = synthetic.cfg3(10_000_000, n_weights=1_000_000, seed=1234)
+    s, o = run_parity(lib, raw, n_learn=2, n_infer=2, stepsize=0.001, decay=0.95, check_index=False)
+    assert s.sgd_plan(0.001)[0] == 1                      # un-split sweeps, as in bench.py
+    assert np.abs(s.weights).max() > 0
+
+
+def test_cfg2_cfg4_full_size_exact_against_oracle(lib):
+    """BASELINE configs 2 (1 M boolean x 10 ISTRUE) and 4 (5 M categorical, domain 8) at full
+    size, inference only, three sweeps each (gathers, table build, table): bit for bit."""
+    run_parity(lib, synthetic.cfg2(1_000_000, seed=1234), n_learn=0, n_infer=3, check_index=False)
+    run_parity(lib, synthetic.cfg4(5_000_000, card=8, seed=1234, learn=False), n_learn=0, n_infer=3,
+               check_index=False)
+
+
 def test_cfg4_closed_form(lib):
     raw = synthetic.cfg4(200_000, card=8, seed=1234, learn=False)
     s = dwx.GibbsSampler(dwx.Graph(raw, lib=lib), seed=5)
