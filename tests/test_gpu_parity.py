@@ -113,6 +113,14 @@ def test_cfg3_full_size_exact_against_oracle(lib):
     assert np.abs(s.weights).max() > 0
 
 
+def test_cfg3b_full_size_exact_against_oracle(lib):
+    """Config 3b at full size (10 M variables, 6 unary + 4 pairwise EQUAL factors each, two
+    colours: the shape of config 5b's shards): one learning and two inference sweeps, exact."""
+    raw = synthetic.cfg3b(10_000_000, n_weights=1_000_000, seed=1234)
+    s, _ = run_parity(lib, raw, n_learn=1, n_infer=2, stepsize=0.001, check_index=False)
+    assert s.graph.info.num_colors >= 2
+
+
 def test_cfg2_cfg4_full_size_exact_against_oracle(lib):
     """BASELINE configs 2 (1 M boolean x 10 ISTRUE) and 4 (5 M categorical, domain 8) at full
     size, inference only, three sweeps each (gathers, table build, table): bit for bit."""
