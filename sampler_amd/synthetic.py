@@ -103,6 +103,42 @@ def cfg3b(V=10_000_000, n_weights=None, seed=1234, offsets=None):
         w_initial_value=np.zeros(W), w_is_fixed=np.zeros(W, np.uint8))
 
 
+def cfg3c(V=10_000_000, n_weights=None, seed=1234):
+    """Config 3c (not in BASELINE.json; times the generic path): per variable 6 unary ISTRUE +
+    2 ternary IMPLY_NATURAL factors (v+1 and v+7 imply v; v+101 and v+211 imply v):
+    F = 8 V, E = 12 V; every variable sits in 6 ternary factors."""
+    from .rawgraph import FUNC_IMPLY_NATURAL
+    W = n_weights or max(1, V // 10)
+    rng = _rng(seed, 0)
+    bodies = [(1, 7), (101, 211)]
+    nu, nt = 6, len(bodies)
+    k = nu + nt
+    F = V * k
+    arity = np.tile(np.array([1] * nu + [3] * nt, np.uint64), V)
+    off = np.zeros(F + 1, np.uint64)
+    np.cumsum(arity, out=off[1:])
+    E = int(off[-1])
+    func = np.tile(np.array([FUNC_ISTRUE] * nu + [FUNC_IMPLY_NATURAL] * nt, np.uint16), V)
+    edge_vid = np.empty(E, np.uint64)
+    v = np.arange(V, dtype=np.uint64)
+    ev = edge_vid.reshape(V, nu + 3 * nt)
+    for j in range(nu):
+        ev[:, j] = v
+    for j, (a, b) in enumerate(bodies):
+        ev[:, nu + 3 * j] = (v + np.uint64(a)) % np.uint64(V)
+        ev[:, nu + 3 * j + 1] = (v + np.uint64(b)) % np.uint64(V)
+        ev[:, nu + 3 * j + 2] = v          # head
+    is_evid = rng.random(V) < 0.5
+    val = (rng.random(V) < 0.7) & is_evid
+    return RawGraph(
+        var_role=is_evid.astype(np.uint8), var_init_value=val.astype(np.uint64),
+        var_dtype=np.full(V, DTYPE_BOOLEAN, np.uint16), var_cardinality=np.full(V, 2, np.uint64),
+        fac_func=func, fac_edge_offset=off,
+        fac_weight_id=rng.integers(0, W, size=F, dtype=np.uint64),
+        fac_feature_value=np.ones(F), edge_vid=edge_vid, edge_equal_to=np.ones(E, np.uint64),
+        w_initial_value=np.zeros(W), w_is_fixed=np.zeros(W, np.uint8))
+
+
 def cfg4(V=5_000_000, card=8, seed=1234, learn=False, shard=0):
     """Config 4: V categorical variables of cardinality `card` (implicit dense domain),
     one unary AND_CATEGORICAL factor per (v, d) with weight id d (the

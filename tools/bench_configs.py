@@ -68,6 +68,8 @@ if __name__ == "__main__":
         run("cfg3", synthetic.cfg3(int(10_000_000 * sc), n_weights=int(1_000_000 * sc)), 10, 20, reg_param=0.01)
     if "cfg3b" in todo:
         run("cfg3b", synthetic.cfg3b(int(10_000_000 * sc), n_weights=int(1_000_000 * sc)), 10, 20, reg_param=0.01)
+    if "cfg3c" in todo:   # (not a BASELINE config: ternary factors, the generic path)
+        run("cfg3c", synthetic.cfg3c(int(10_000_000 * sc), n_weights=int(1_000_000 * sc)), 5, 10, reg_param=0.01)
     if "cfg4" in todo:
         run("cfg4", synthetic.cfg4(int(5_000_000 * sc), card=8, learn=False), 0, 20)
     if "cfg4learn" in todo:
