@@ -171,6 +171,68 @@ DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const Vi
   }
 }
 
+// Both proposals of a boolean owner in ONE walk over the factor's variables (the generic
+// path's row walk needs sign(proposal = 1) and sign(proposal = 0) of every record: walking
+// twice loads every vif entry and every neighbour assignment twice).  Same case analysis as
+// factor_sign; s1 / s0 = the sign under proposal 1 / 0.
+DWX_DEV void factor_sign2(uint32_t func, uint32_t arity, uint32_t aux, const VifRec *vifs,
+                          const uint32_t *assign, uint32_t me, double &s1, double &s0) {
+  if (arity == 1) { s1 = unary_sign(func, 1u == aux); s0 = unary_sign(func, 0u == aux); return; }
+  const VifRec *v = vifs + aux;
+  // satisfied bits of position i under the two proposals
+  auto sat2 = [&](uint32_t i, bool &a1, bool &a0) {
+    const VifRec vf = v[i];
+    if (vf.vid == me) { a1 = vf.equal_to == 1u; a0 = vf.equal_to == 0u; }
+    else { a1 = a0 = assign[vf.vid] == vf.equal_to; }
+  };
+  switch (func) {
+    case FUNC_AND: case FUNC_ISTRUE: case FUNC_AND_CATEGORICAL: {
+      bool all1 = true, all0 = true;
+      for (uint32_t i = 0; i < arity && (all1 || all0); ++i) { bool a1, a0; sat2(i, a1, a0); all1 &= a1; all0 &= a0; }
+      const double no = func == FUNC_AND_CATEGORICAL ? 0.0 : -1.0;
+      s1 = all1 ? 1.0 : no; s0 = all0 ? 1.0 : no;
+      return;
+    }
+    case FUNC_OR: {
+      bool any1 = false, any0 = false;
+      for (uint32_t i = 0; i < arity && !(any1 && any0); ++i) { bool a1, a0; sat2(i, a1, a0); any1 |= a1; any0 |= a0; }
+      s1 = any1 ? 1.0 : -1.0; s0 = any0 ? 1.0 : -1.0;
+      return;
+    }
+    case FUNC_EQUAL: {
+      bool f1, f0, eq1 = true, eq0 = true;
+      sat2(0, f1, f0);
+      for (uint32_t i = 1; i < arity && (eq1 || eq0); ++i) { bool a1, a0; sat2(i, a1, a0); eq1 &= a1 == f1; eq0 &= a0 == f0; }
+      s1 = eq1 ? 1.0 : -1.0; s0 = eq0 ? 1.0 : -1.0;
+      return;
+    }
+    case FUNC_IMPLY_MLN: case FUNC_IMPLY_NATURAL: {
+      bool body1 = true, body0 = true;
+      for (uint32_t i = 0; i + 1 < arity; ++i) { bool a1, a0; sat2(i, a1, a0); body1 &= a1; body0 &= a0; }
+      bool h1, h0;
+      sat2(arity - 1, h1, h0);
+      if (func == FUNC_IMPLY_MLN) { s1 = !body1 ? 1.0 : (h1 ? 1.0 : 0.0); s0 = !body0 ? 1.0 : (h0 ? 1.0 : 0.0); }
+      else { s1 = !body1 ? 0.0 : (h1 ? 1.0 : -1.0); s0 = !body0 ? 0.0 : (h0 ? 1.0 : -1.0); }
+      return;
+    }
+    default: {  // LINEAR, RATIO, LOGICAL (src/factor.h:244-296)
+      bool h1, h0;
+      sat2(arity - 1, h1, h0);
+      double r1 = (func == FUNC_RATIO) ? 1.0 : 0.0, r0 = r1;
+      for (uint32_t i = 0; i + 1 < arity; ++i) {
+        bool a1, a0;
+        sat2(i, a1, a0);
+        r1 += ((!a1) || h1) ? 1.0 : 0.0;
+        r0 += ((!a0) || h0) ? 1.0 : 0.0;
+      }
+      if (func == FUNC_LINEAR) { s1 = r1; s0 = r0; }
+      else if (func == FUNC_RATIO) { s1 = log2(r1); s0 = log2(r0); }
+      else { s1 = r1 > 0.0 ? 1.0 : 0.0; s0 = r0 > 0.0 ? 1.0 : 0.0; }
+      return;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- tile view
 // Where a lane reads its row pointers / edge records / weights / potential scratch
 // from: the LDS-staged tile (normal) or HBM directly (a variable too big for a tile).
@@ -347,8 +409,17 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     const double w = edge_weight<WMODE>(P, T, er, e);
-    pp += w * edge_term<SIMPLE>(P, er, e, assign, me, 1u, true);
-    pn += w * edge_term<SIMPLE>(P, er, e, assign, me, 0u, false);
+    if (SIMPLE || (er.packed & EDGE_PRESIGNED)) {
+      pp += w * (double)er.fval;
+      pn += w * (double)bits_to_float(er.aux);
+    } else {
+      // one walk over the factor for both proposals (same products, same order)
+      const double fv = (er.packed & EDGE_F64_FLAG) ? P.edge_fval64[e] : (double)er.fval;
+      double s1, s0;
+      factor_sign2(edge_func(er), edge_arity(er), er.aux, P.vifs, assign, me, s1, s0);
+      pp += w * (s1 * fv);
+      pn += w * (s0 * fv);
+    }
   }
 }
 
