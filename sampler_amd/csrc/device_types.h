@@ -140,6 +140,10 @@ constexpr uint32_t PULL_RUN = DWX_PULL_RUN;                  // incidence entrie
 constexpr uint32_t BP_THREADS = 1024;
 constexpr uint32_t BP_TILES = 2048;               // tiles per variable block: 128 KiB of ballot pairs
 constexpr uint32_t BP_ROW = 4;                    // entries per 16-byte row
+#ifndef DWX_BP_UNROLL
+#define DWX_BP_UNROLL 4
+#endif
+constexpr uint32_t BP_UNROLL = DWX_BP_UNROLL;     // weight groups in flight per lane
 constexpr uint32_t BP_SLOT_BITS = 19, BP_SLOT_MASK = (1u << BP_SLOT_BITS) - 1;
 constexpr uint32_t BP_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t BP_DELTA_SLOTS = 4096, BP_MAX_DELTAS = BP_DELTA_SLOTS - 1;   // (the last slot stays 0: BP_EMPTY decodes to it)

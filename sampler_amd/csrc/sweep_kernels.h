@@ -1437,8 +1437,8 @@ pull_grad_kernel(const uint32_t *inc_wid, const uint32_t *inc_slot, const float 
 // function -- the usual case): its step comes in as an argument instead of an LDS table.
 template <int DEPTH, bool UNIFORM>
 __global__ void __launch_bounds__(BP_THREADS)
-pull_ell_kernel(const U32x4 *ell, const uint32_t *block_tile0, uint32_t parts, const long long *qtab,
-                uint32_t n_deltas, uint32_t Wp, const unsigned long long *delta, long long *partial) {
+pull_ell_kernel(const U32x4 *__restrict__ ell, const uint32_t *block_tile0, uint32_t parts, const long long *qtab,
+                uint32_t n_deltas, uint32_t Wp, const unsigned long long *delta, long long *__restrict__ partial) {
   DWX_DYN_LDS(dyn_lds);
   DeltaPair *s_delta = (DeltaPair *)dyn_lds;
   constexpr uint32_t PAIRS = BP_TILES * 4;                 // ballot pairs per block
@@ -1457,31 +1457,41 @@ pull_ell_kernel(const U32x4 *ell, const uint32_t *block_tile0, uint32_t parts, c
   // this part's weights: whole groups of BP_THREADS
   const uint32_t groups = Wp / BP_THREADS, per = (groups + parts - 1) / parts;
   const uint32_t g0 = part * per, g1 = g0 + per < groups ? g0 + per : groups;
-  const U32x4 *rows = ell + (size_t)b * DEPTH * Wp;
-  long long *out = partial + (size_t)b * Wp;
-#pragma unroll 4
-  for (uint32_t g = g0; g < g1; ++g) {
-    const uint32_t w = g * BP_THREADS + tid;
-    long long acc = 0;
+  const U32x4 *__restrict__ rows = ell + (size_t)b * DEPTH * Wp;
+  long long *__restrict__ out = partial + (size_t)b * Wp;
+  // BP_UNROLL groups per step: all their row loads are issued before the first is used (the
+  // compiler does not hoist them over the stores on its own); past the end the last group is
+  // loaded again and not stored
+  for (uint32_t g = g0; g < g1; g += BP_UNROLL) {
+    U32x4 row[BP_UNROLL][DEPTH];
 #pragma unroll
-    for (int dd = 0; dd < DEPTH; ++dd) {
-      const U32x4 row = rows[(size_t)dd * Wp + w];
+    for (uint32_t u = 0; u < BP_UNROLL; ++u) {
+      const uint32_t w = umin(g + u, g1 - 1) * BP_THREADS + tid;
 #pragma unroll
-      for (uint32_t k = 0; k < BP_ROW; ++k) {
-        // branch-free: an empty entry decodes to the block's last slot and to a zero step.
-        // Only the two 32-bit words that hold the owner's bits are read (a ballot pair is
-        // {nz lo, nz hi, ng lo, ng hi}), and no step table when all deltas are equal.
-        const uint32_t e = row.v[k];
-        const uint32_t slot = e & BP_SLOT_MASK;
-        const uint32_t word = (slot >> 6) * 4u + ((slot >> 5) & 1u);
-        const uint32_t nzw = s_words[word], ngw = s_words[word + 2u];
-        const bool valid = UNIFORM ? (e != BP_EMPTY) : true;
-        const long long q = UNIFORM ? q0 : s_q[(e >> BP_SLOT_BITS) & (BP_DELTA_SLOTS - 1)];
-        const bool nz = valid && ((nzw >> (slot & 31u)) & 1u), ng = (ngw >> (slot & 31u)) & 1u;
-        acc += nz ? (ng ? -q : q) : 0;
-      }
+      for (int dd = 0; dd < DEPTH; ++dd) row[u][dd] = rows[(size_t)dd * Wp + w];
     }
-    out[w] = acc;
+#pragma unroll
+    for (uint32_t u = 0; u < BP_UNROLL; ++u) {
+      long long acc = 0;
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) {
+#pragma unroll
+        for (uint32_t k = 0; k < BP_ROW; ++k) {
+          // branch-free: an empty entry decodes to the block's last slot and adds zero.
+          // Only the two 32-bit words that hold the owner's bits are read (a ballot pair is
+          // {nz lo, nz hi, ng lo, ng hi}), and no step table when all deltas are equal.
+          const uint32_t e = row[u][dd].v[k];
+          const uint32_t slot = e & BP_SLOT_MASK;
+          const uint32_t word = (slot >> 6) * 4u + ((slot >> 5) & 1u);
+          const uint32_t nzw = s_words[word], ngw = s_words[word + 2u];
+          const long long q = UNIFORM ? q0 : s_q[(e >> BP_SLOT_BITS) & (BP_DELTA_SLOTS - 1)];
+          const uint32_t nz = (nzw >> (slot & 31u)) & (e != BP_EMPTY ? 1u : 0u), ng = (ngw >> (slot & 31u)) & 1u;
+          const long long t = ng ? -q : q;
+          acc += nz ? t : 0;
+        }
+      }
+      if (g + u < g1) out[(g + u) * BP_THREADS + tid] = acc;
+    }
   }
 }
 
