@@ -171,63 +171,101 @@ DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const Vi
   }
 }
 
-// Both proposals of a boolean owner in ONE walk over the factor's variables (the generic
-// path's row walk needs sign(proposal = 1) and sign(proposal = 0) of every record: walking
-// twice loads every vif entry and every neighbour assignment twice).  Same case analysis as
-// factor_sign; s1 / s0 = the sign under proposal 1 / 0.
-DWX_DEV void factor_sign2(uint32_t func, uint32_t arity, uint32_t aux, const VifRec *vifs,
-                          const uint32_t *assign, uint32_t me, double &s1, double &s0) {
-  if (arity == 1) { s1 = unary_sign(func, 1u == aux); s0 = unary_sign(func, 0u == aux); return; }
+// NS evaluations of one factor in ONE walk over its variables.  Scenario j: the sampled
+// variable takes prop[j], every other variable its assignment on chain arr[j].  The generic
+// path needs several per record -- both proposals of a boolean owner; both chains when
+// learning; (evidence chain, evidence value) and (free chain, free sample) for the gradient --
+// and walking once per evaluation loads every vif entry and neighbour assignment again.
+// Same case analysis as factor_sign; s[j] = the sign in scenario j.
+template <int NS>
+DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const VifRec *vifs, uint32_t me,
+                          const uint32_t *const (&arr)[NS], const uint32_t (&prop)[NS], double (&s)[NS]) {
+  if (arity == 1) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) s[j] = unary_sign(func, prop[j] == aux);
+    return;
+  }
   const VifRec *v = vifs + aux;
-  // satisfied bits of position i under the two proposals
-  auto sat2 = [&](uint32_t i, bool &a1, bool &a0) {
+  // satisfied bits of position i in every scenario (scenarios on the same chain share the load)
+  auto sat = [&](uint32_t i, bool (&a)[NS]) {
     const VifRec vf = v[i];
-    if (vf.vid == me) { a1 = vf.equal_to == 1u; a0 = vf.equal_to == 0u; }
-    else { a1 = a0 = assign[vf.vid] == vf.equal_to; }
+    const bool mine = vf.vid == me;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) a[j] = (mine ? prop[j] : arr[j][vf.vid]) == vf.equal_to;
   };
+  bool a[NS];
   switch (func) {
     case FUNC_AND: case FUNC_ISTRUE: case FUNC_AND_CATEGORICAL: {
-      bool all1 = true, all0 = true;
-      for (uint32_t i = 0; i < arity && (all1 || all0); ++i) { bool a1, a0; sat2(i, a1, a0); all1 &= a1; all0 &= a0; }
+      bool all[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) all[j] = true;
+      for (uint32_t i = 0; i < arity; ++i) {
+        sat(i, a);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) all[j] &= a[j];
+      }
       const double no = func == FUNC_AND_CATEGORICAL ? 0.0 : -1.0;
-      s1 = all1 ? 1.0 : no; s0 = all0 ? 1.0 : no;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) s[j] = all[j] ? 1.0 : no;
       return;
     }
     case FUNC_OR: {
-      bool any1 = false, any0 = false;
-      for (uint32_t i = 0; i < arity && !(any1 && any0); ++i) { bool a1, a0; sat2(i, a1, a0); any1 |= a1; any0 |= a0; }
-      s1 = any1 ? 1.0 : -1.0; s0 = any0 ? 1.0 : -1.0;
+      bool any[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) any[j] = false;
+      for (uint32_t i = 0; i < arity; ++i) {
+        sat(i, a);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) any[j] |= a[j];
+      }
+#pragma unroll
+      for (int j = 0; j < NS; ++j) s[j] = any[j] ? 1.0 : -1.0;
       return;
     }
     case FUNC_EQUAL: {
-      bool f1, f0, eq1 = true, eq0 = true;
-      sat2(0, f1, f0);
-      for (uint32_t i = 1; i < arity && (eq1 || eq0); ++i) { bool a1, a0; sat2(i, a1, a0); eq1 &= a1 == f1; eq0 &= a0 == f0; }
-      s1 = eq1 ? 1.0 : -1.0; s0 = eq0 ? 1.0 : -1.0;
+      bool first[NS], eq[NS];
+      sat(0, first);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) eq[j] = true;
+      for (uint32_t i = 1; i < arity; ++i) {
+        sat(i, a);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) eq[j] &= a[j] == first[j];
+      }
+#pragma unroll
+      for (int j = 0; j < NS; ++j) s[j] = eq[j] ? 1.0 : -1.0;
       return;
     }
     case FUNC_IMPLY_MLN: case FUNC_IMPLY_NATURAL: {
-      bool body1 = true, body0 = true;
-      for (uint32_t i = 0; i + 1 < arity; ++i) { bool a1, a0; sat2(i, a1, a0); body1 &= a1; body0 &= a0; }
-      bool h1, h0;
-      sat2(arity - 1, h1, h0);
-      if (func == FUNC_IMPLY_MLN) { s1 = !body1 ? 1.0 : (h1 ? 1.0 : 0.0); s0 = !body0 ? 1.0 : (h0 ? 1.0 : 0.0); }
-      else { s1 = !body1 ? 0.0 : (h1 ? 1.0 : -1.0); s0 = !body0 ? 0.0 : (h0 ? 1.0 : -1.0); }
+      bool body[NS], head[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) body[j] = true;
+      for (uint32_t i = 0; i + 1 < arity; ++i) {
+        sat(i, a);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) body[j] &= a[j];
+      }
+      sat(arity - 1, head);
+#pragma unroll
+      for (int j = 0; j < NS; ++j)
+        s[j] = func == FUNC_IMPLY_MLN ? (!body[j] ? 1.0 : (head[j] ? 1.0 : 0.0))
+                                      : (!body[j] ? 0.0 : (head[j] ? 1.0 : -1.0));
       return;
     }
     default: {  // LINEAR, RATIO, LOGICAL (src/factor.h:244-296)
-      bool h1, h0;
-      sat2(arity - 1, h1, h0);
-      double r1 = (func == FUNC_RATIO) ? 1.0 : 0.0, r0 = r1;
+      bool head[NS];
+      sat(arity - 1, head);
+      double r[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) r[j] = (func == FUNC_RATIO) ? 1.0 : 0.0;
       for (uint32_t i = 0; i + 1 < arity; ++i) {
-        bool a1, a0;
-        sat2(i, a1, a0);
-        r1 += ((!a1) || h1) ? 1.0 : 0.0;
-        r0 += ((!a0) || h0) ? 1.0 : 0.0;
+        sat(i, a);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) r[j] += ((!a[j]) || head[j]) ? 1.0 : 0.0;
       }
-      if (func == FUNC_LINEAR) { s1 = r1; s0 = r0; }
-      else if (func == FUNC_RATIO) { s1 = log2(r1); s0 = log2(r0); }
-      else { s1 = r1 > 0.0 ? 1.0 : 0.0; s0 = r0 > 0.0 ? 1.0 : 0.0; }
+#pragma unroll
+      for (int j = 0; j < NS; ++j)
+        s[j] = func == FUNC_LINEAR ? r[j] : (func == FUNC_RATIO ? log2(r[j]) : (r[j] > 0.0 ? 1.0 : 0.0));
       return;
     }
   }
@@ -415,10 +453,37 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
     } else {
       // one walk over the factor for both proposals (same products, same order)
       const double fv = (er.packed & EDGE_F64_FLAG) ? P.edge_fval64[e] : (double)er.fval;
-      double s1, s0;
-      factor_sign2(edge_func(er), edge_arity(er), er.aux, P.vifs, assign, me, s1, s0);
-      pp += w * (s1 * fv);
-      pn += w * (s0 * fv);
+      const uint32_t *const arr[2] = {assign, assign};
+      const uint32_t prop[2] = {1u, 0u};
+      double sg[2];
+      factor_signs<2>(edge_func(er), edge_arity(er), er.aux, P.vifs, me, arr, prop, sg);
+      pp += w * (sg[0] * fv);
+      pn += w * (sg[1] * fv);
+    }
+  }
+}
+
+// learning, generic path: the potentials of BOTH chains of a boolean variable in one walk
+// (same sums, same order as two calls of bool_potentials)
+template <int WMODE>
+DWX_DEV void bool_potentials_both(const KernelParams &P, const TileView &T, uint32_t row, uint32_t me,
+                                  double &ppf, double &pnf, double &ppe, double &pne) {
+  const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
+  ppf = 0.0; pnf = 0.0; ppe = 0.0; pne = 0.0;
+  for (uint32_t e = es; e < ee; ++e) {
+    const EdgeRec er = T.edges[e - T.edge_bias];
+    const double w = edge_weight<WMODE>(P, T, er, e);
+    if (er.packed & EDGE_PRESIGNED) {
+      const double h = w * (double)er.fval, m = w * (double)bits_to_float(er.aux);
+      ppf += h; pnf += m; ppe += h; pne += m;
+    } else {
+      const double fv = (er.packed & EDGE_F64_FLAG) ? P.edge_fval64[e] : (double)er.fval;
+      const uint32_t *const arr[4] = {P.assign_free, P.assign_free, P.assign_evid, P.assign_evid};
+      const uint32_t prop[4] = {1u, 0u, 1u, 0u};
+      double sg[4];
+      factor_signs<4>(edge_func(er), edge_arity(er), er.aux, P.vifs, me, arr, prop, sg);
+      ppf += w * (sg[0] * fv); pnf += w * (sg[1] * fv);
+      ppe += w * (sg[2] * fv); pne += w * (sg[3] * fv);
     }
   }
 }
@@ -567,8 +632,19 @@ DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uin
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     if (er.packed & EDGE_FIXED_FLAG) continue;   // weights_isfixed (src/factor_graph.cc:247)
-    const double pot_evid = edge_term<SIMPLE>(P, er, e, P.assign_evid, me, evid_value, evid_value == hit_value);
-    const double pot_free = edge_term<SIMPLE>(P, er, e, P.assign_free, me, free_value, free_value == hit_value);
+    double pot_evid, pot_free;
+    if (SIMPLE || (er.packed & EDGE_PRESIGNED)) {
+      pot_evid = edge_term<true>(P, er, e, P.assign_evid, me, evid_value, evid_value == hit_value);
+      pot_free = edge_term<true>(P, er, e, P.assign_free, me, free_value, free_value == hit_value);
+    } else {   // one walk over the factor for both evaluations
+      const double fv = (er.packed & EDGE_F64_FLAG) ? P.edge_fval64[e] : (double)er.fval;
+      const uint32_t *const arr[2] = {P.assign_evid, P.assign_free};
+      const uint32_t prop[2] = {evid_value, free_value};
+      double sg[2];
+      factor_signs<2>(edge_func(er), edge_arity(er), er.aux, P.vifs, me, arr, prop, sg);
+      pot_evid = sg[0] * fv;
+      pot_free = sg[1] * fv;
+    }
     const double g = pot_free - pot_evid;
     const long long gi = llrint(FIX_SCALE * (t * g));
     const long long ti = count_t ? llrint(FIX_SCALE * t) : 0;
@@ -634,8 +710,12 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
   // free chain
   uint32_t p_free;
   double pp_f = 0.0, pn_f = 0.0;
+  // (generic path: if the evidence chain will be drawn too, its potentials come from the same walk)
+  const bool both = !SIMPLE && !is_cat && !(!noise_aware && is_evid) && !(noise_aware && has_truth);
+  double pp_e = 0.0, pn_e = 0.0;
   if (!is_cat) {
-    bool_potentials<WMODE, SIMPLE>(P, T, row0, P.assign_free, p, pp_f, pn_f);
+    if (both) bool_potentials_both<WMODE>(P, T, row0, p, pp_f, pn_f, pp_e, pn_e);
+    else bool_potentials<WMODE, SIMPLE>(P, T, row0, P.assign_free, p, pp_f, pn_f);
     p_free = bool_draw(A, pp_f, pn_f);
   } else {
     p_free = cat_draw<WMODE, SIMPLE>(P, T, row0, card, P.assign_free, p, A);
@@ -654,10 +734,9 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
       if (sum >= B) { p_evid = i; break; }
     }
   } else if (!is_cat) {
-    double pp = pp_f, pn = pn_f;
     // unary factors do not read neighbours: both chains see the same potentials
     // (same records, same weights, same order => bit-identical sums)
-    if (!SIMPLE) bool_potentials<WMODE, SIMPLE>(P, T, row0, P.assign_evid, p, pp, pn);
+    const double pp = SIMPLE ? pp_f : pp_e, pn = SIMPLE ? pn_f : pn_e;
     p_evid = bool_draw(B, pp, pn);
   } else {
     p_evid = cat_draw<WMODE, SIMPLE>(P, T, row0, card, P.assign_evid, p, B);
