@@ -86,6 +86,7 @@ class Library:
         L.dwx_graph_get_index.argtypes = [vp, vp, vp, vp]
         L.dwx_graph_get_positions.argtypes = [vp, vp, u64, vp]
         L.dwx_sampler_create.argtypes = [vp, vp, vp]
+        L.dwx_device_init.argtypes = [C.c_int32]
         L.dwx_sampler_destroy.argtypes = [vp]; L.dwx_sampler_destroy.restype = None
         L.dwx_sample_async.argtypes = [vp]
         L.dwx_sample_sgd_async.argtypes = [vp, dbl]

@@ -69,3 +69,18 @@ def test_empty_graph():
                    np.zeros(1, np.uint64), z8, zf, z8, z8, zf, np.zeros(0, np.uint8))
     g = dwx.Graph(raw)
     assert g.info.num_variables == 0 and g.info.num_tiles == 0
+
+
+def test_device_init_without_gpu_fails_loudly():
+    """dwx_device_init (the optional early HIP start-up) reports the missing device through the
+    usual error channel instead of crashing; on a GPU box it succeeds (tests/test_gpu_parity.py
+    runs everything after it)."""
+    import torch
+    lib = dwx.default_library()
+    rc = lib.L.dwx_device_init(0)
+    if torch.cuda.is_available():
+        assert rc == 0
+        assert lib.L.dwx_device_init(10_000) != 0
+    else:
+        assert rc == dwx.DWX_E_DEVICE
+        assert b"HIP" in lib.L.dwx_last_error() or b"device" in lib.L.dwx_last_error()
