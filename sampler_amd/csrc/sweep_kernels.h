@@ -177,21 +177,45 @@ DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const Vi
 // learning; (evidence chain, evidence value) and (free chain, free sample) for the gradient --
 // and walking once per evaluation loads every vif entry and neighbour assignment again.
 // Same case analysis as factor_sign; s[j] = the sign in scenario j.
+//
+// Src says where position i's entry and a neighbour's value come from: memory (VifsInMemory:
+// any arity, a loop) or registers filled by an earlier, batched load phase (VifsPreloaded:
+// arity <= GEN_ARITY, loops unrolled so that every register index is static).
+constexpr uint32_t GEN_ARITY = 3;   // positions of a factor the batched generic walk preloads
+#ifndef DWX_GEN_BATCH
+#define DWX_GEN_BATCH 1
+#endif
+constexpr uint32_t GEN_BATCH = DWX_GEN_BATCH;   // records per step of the batched generic walk
+
 template <int NS>
-DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const VifRec *vifs, uint32_t me,
-                          const uint32_t *const (&arr)[NS], const uint32_t (&prop)[NS], double (&s)[NS]) {
-  if (arity == 1) {
-#pragma unroll
-    for (int j = 0; j < NS; ++j) s[j] = unary_sign(func, prop[j] == aux);
-    return;
-  }
-  const VifRec *v = vifs + aux;
-  // satisfied bits of position i in every scenario (scenarios on the same chain share the load)
+struct VifsInMemory {
+  static constexpr uint32_t MAXA = 0;
+  const VifRec *v;
+  const uint32_t *const (&arr)[NS];
+  DWX_DEV VifRec vif(uint32_t i) const { return v[i]; }
+  DWX_DEV uint32_t value(int j, uint32_t, uint32_t vid) const { return arr[j][vid]; }
+};
+// (one chain per scenario pair is enough for the preloaded form: chain[j] selects the value row)
+template <int NS, int NCHAIN>
+struct VifsPreloaded {
+  static constexpr uint32_t MAXA = GEN_ARITY;
+  const VifRec (&vf)[GEN_ARITY];
+  const uint32_t (&val)[NCHAIN][GEN_ARITY];
+  const int (&chain)[NS];
+  DWX_DEV VifRec vif(uint32_t i) const { return vf[i]; }
+  DWX_DEV uint32_t value(int j, uint32_t i, uint32_t) const { return val[chain[j]][i]; }
+};
+
+template <int NS, class Src>
+DWX_DEV void factor_signs_from(uint32_t func, uint32_t arity, const Src &src, uint32_t me,
+                               const uint32_t (&prop)[NS], double (&s)[NS]) {
+  constexpr uint32_t MAXA = Src::MAXA;
+  const uint32_t n = MAXA ? MAXA : arity;   // (MAXA: constant trip count, positions past the arity skipped)
   auto sat = [&](uint32_t i, bool (&a)[NS]) {
-    const VifRec vf = v[i];
+    const VifRec vf = src.vif(i);
     const bool mine = vf.vid == me;
 #pragma unroll
-    for (int j = 0; j < NS; ++j) a[j] = (mine ? prop[j] : arr[j][vf.vid]) == vf.equal_to;
+    for (int j = 0; j < NS; ++j) a[j] = (mine ? prop[j] : src.value(j, i, vf.vid)) == vf.equal_to;
   };
   bool a[NS];
   switch (func) {
@@ -199,7 +223,9 @@ DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const Vif
       bool all[NS];
 #pragma unroll
       for (int j = 0; j < NS; ++j) all[j] = true;
-      for (uint32_t i = 0; i < arity; ++i) {
+#pragma unroll
+      for (uint32_t i = 0; i < n; ++i) {
+        if (MAXA && i >= arity) continue;
         sat(i, a);
 #pragma unroll
         for (int j = 0; j < NS; ++j) all[j] &= a[j];
@@ -213,7 +239,9 @@ DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const Vif
       bool any[NS];
 #pragma unroll
       for (int j = 0; j < NS; ++j) any[j] = false;
-      for (uint32_t i = 0; i < arity; ++i) {
+#pragma unroll
+      for (uint32_t i = 0; i < n; ++i) {
+        if (MAXA && i >= arity) continue;
         sat(i, a);
 #pragma unroll
         for (int j = 0; j < NS; ++j) any[j] |= a[j];
@@ -227,7 +255,9 @@ DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const Vif
       sat(0, first);
 #pragma unroll
       for (int j = 0; j < NS; ++j) eq[j] = true;
-      for (uint32_t i = 1; i < arity; ++i) {
+#pragma unroll
+      for (uint32_t i = 1; i < (MAXA ? MAXA : arity); ++i) {
+        if (MAXA && i >= arity) continue;
         sat(i, a);
 #pragma unroll
         for (int j = 0; j < NS; ++j) eq[j] &= a[j] == first[j];
@@ -239,13 +269,15 @@ DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const Vif
     case FUNC_IMPLY_MLN: case FUNC_IMPLY_NATURAL: {
       bool body[NS], head[NS];
 #pragma unroll
-      for (int j = 0; j < NS; ++j) body[j] = true;
-      for (uint32_t i = 0; i + 1 < arity; ++i) {
-        sat(i, a);
+      for (int j = 0; j < NS; ++j) { body[j] = true; head[j] = false; }
 #pragma unroll
-        for (int j = 0; j < NS; ++j) body[j] &= a[j];
+      for (uint32_t i = 0; i < n; ++i) {
+        if (MAXA && i >= arity) continue;
+        sat(i, a);
+        const bool is_head = i + 1 == arity;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { if (is_head) head[j] = a[j]; else body[j] &= a[j]; }
       }
-      sat(arity - 1, head);
 #pragma unroll
       for (int j = 0; j < NS; ++j)
         s[j] = func == FUNC_IMPLY_MLN ? (!body[j] ? 1.0 : (head[j] ? 1.0 : 0.0))
@@ -254,11 +286,25 @@ DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const Vif
     }
     default: {  // LINEAR, RATIO, LOGICAL (src/factor.h:244-296)
       bool head[NS];
-      sat(arity - 1, head);
+      if (MAXA) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) head[j] = false;
+#pragma unroll
+        for (uint32_t i = 0; i < MAXA; ++i) {
+          if (i + 1 != arity) continue;
+          sat(i, a);
+#pragma unroll
+          for (int j = 0; j < NS; ++j) head[j] = a[j];
+        }
+      } else {
+        sat(arity - 1, head);
+      }
       double r[NS];
 #pragma unroll
       for (int j = 0; j < NS; ++j) r[j] = (func == FUNC_RATIO) ? 1.0 : 0.0;
-      for (uint32_t i = 0; i + 1 < arity; ++i) {
+#pragma unroll
+      for (uint32_t i = 0; i < n; ++i) {
+        if (i + 1 >= arity) continue;
         sat(i, a);
 #pragma unroll
         for (int j = 0; j < NS; ++j) r[j] += ((!a[j]) || head[j]) ? 1.0 : 0.0;
@@ -269,6 +315,18 @@ DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const Vif
       return;
     }
   }
+}
+
+template <int NS>
+DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const VifRec *vifs, uint32_t me,
+                          const uint32_t *const (&arr)[NS], const uint32_t (&prop)[NS], double (&s)[NS]) {
+  if (arity == 1) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) s[j] = unary_sign(func, prop[j] == aux);
+    return;
+  }
+  const VifsInMemory<NS> src{vifs + aux, arr};
+  factor_signs_from<NS>(func, arity, src, me, prop, s);
 }
 
 // ---------------------------------------------------------------- tile view
@@ -334,6 +392,35 @@ DWX_DEV uint32_t edge_arity(const EdgeRec &e) { return (e.packed >> EDGE_ARITY_S
 DWX_DEV uint32_t edge_owner_lane(const EdgeRec &e) { return e.packed >> EDGE_OWNER_SHIFT; }
 DWX_DEV float bits_to_float(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 DWX_DEV uint32_t float_to_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+
+// The signs of one generic record (arity >= 2) in NS scenarios over NCHAIN chains: its first
+// GEN_ARITY positions are loaded together (entries, then assignments on every chain), wider
+// factors walk memory.  chain[j] = which of chains[] scenario j reads.
+template <int NS, int NCHAIN>
+DWX_DEV void record_signs(const KernelParams &P, const EdgeRec &er, uint32_t me,
+                          const uint32_t *const (&chains)[NCHAIN], const int (&chain)[NS],
+                          const uint32_t (&prop)[NS], double (&s)[NS]) {
+  const uint32_t func = edge_func(er), ar = edge_arity(er);
+  if (ar <= GEN_ARITY) {
+    VifRec vf[GEN_ARITY];
+    uint32_t val[NCHAIN][GEN_ARITY];
+#pragma unroll
+    for (uint32_t i = 0; i < GEN_ARITY; ++i) vf[i] = P.vifs[er.aux + umin(i, ar - 1u)];
+#pragma unroll
+    for (int c = 0; c < NCHAIN; ++c)
+#pragma unroll
+      for (uint32_t i = 0; i < GEN_ARITY; ++i) val[c][i] = chains[c][vf[i].vid];
+    const VifsPreloaded<NS, NCHAIN> src{vf, val, chain};
+    factor_signs_from<NS>(func, ar, src, me, prop, s);
+  } else {
+    const uint32_t *arr[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) arr[j] = chains[chain[j]];
+    const uint32_t *const (&carr)[NS] = arr;
+    const VifsInMemory<NS> src{P.vifs + er.aux, carr};
+    factor_signs_from<NS>(func, ar, src, me, prop, s);
+  }
+}
 
 // SIMPLE (a per-tile, workgroup-uniform property, TILE_SIMPLE): every record is a
 // unary factor with an f32-exact feature value.  The SIMPLE variants below contain no
@@ -444,19 +531,60 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
     }
     return;
   }
-  for (uint32_t e = es; e < ee; ++e) {
-    const EdgeRec er = T.edges[e - T.edge_bias];
-    const double w = edge_weight<WMODE>(P, T, er, e);
-    if (SIMPLE || (er.packed & EDGE_PRESIGNED)) {
+  if (SIMPLE) {
+    for (uint32_t e = es; e < ee; ++e) {
+      const EdgeRec er = T.edges[e - T.edge_bias];
+      const double w = edge_weight<WMODE>(P, T, er, e);
       pp += w * (double)er.fval;
       pn += w * (double)bits_to_float(er.aux);
-    } else {
-      // one walk over the factor for both proposals (same products, same order)
-      const double fv = (er.packed & EDGE_F64_FLAG) ? P.edge_fval64[e] : (double)er.fval;
-      const uint32_t *const arr[2] = {assign, assign};
-      const uint32_t prop[2] = {1u, 0u};
+    }
+    return;
+  }
+  // Generic records, GEN_BATCH per step in three phases, so that the loads of a phase are all
+  // in flight together: the records' first GEN_ARITY vif entries (clamped inside the factor;
+  // a pre-signed record reads entry 0), then those variables' assignments, then the
+  // arithmetic -- in row order, one product per record and proposal, as before.  A factor
+  // wider than GEN_ARITY walks memory as it always did.
+  const uint32_t prop[2] = {1u, 0u};
+  for (uint32_t e0 = es; e0 < ee; e0 += GEN_BATCH) {
+    EdgeRec er[GEN_BATCH];
+    VifRec vf[GEN_BATCH][GEN_ARITY];
+    uint32_t val[GEN_BATCH][1][GEN_ARITY];
+#pragma unroll
+    for (uint32_t u = 0; u < GEN_BATCH; ++u) {
+      er[u] = T.edges[umin(e0 + u, ee - 1) - T.edge_bias];
+      const bool generic = !(er[u].packed & EDGE_PRESIGNED);
+      const uint32_t ar = generic ? edge_arity(er[u]) : 1u, base = (generic && ar >= 2u) ? er[u].aux : 0u;
+#pragma unroll
+      for (uint32_t i = 0; i < GEN_ARITY; ++i) vf[u][i] = P.vifs[base + umin(i, ar - 1u)];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < GEN_BATCH; ++u)
+#pragma unroll
+      for (uint32_t i = 0; i < GEN_ARITY; ++i) val[u][0][i] = assign[vf[u][i].vid];
+#pragma unroll
+    for (uint32_t u = 0; u < GEN_BATCH; ++u) {
+      const uint32_t e = e0 + u;
+      if (e >= ee) continue;
+      const double w = edge_weight<WMODE>(P, T, er[u], e);
+      if (er[u].packed & EDGE_PRESIGNED) {
+        pp += w * (double)er[u].fval;
+        pn += w * (double)bits_to_float(er[u].aux);
+        continue;
+      }
+      const double fv = (er[u].packed & EDGE_F64_FLAG) ? P.edge_fval64[e] : (double)er[u].fval;
+      const uint32_t func = edge_func(er[u]), ar = edge_arity(er[u]);
       double sg[2];
-      factor_signs<2>(edge_func(er), edge_arity(er), er.aux, P.vifs, me, arr, prop, sg);
+      if (ar == 1u) {
+        sg[0] = unary_sign(func, 1u == er[u].aux); sg[1] = unary_sign(func, 0u == er[u].aux);
+      } else if (ar <= GEN_ARITY) {
+        const int chain[2] = {0, 0};
+        const VifsPreloaded<2, 1> src{vf[u], val[u], chain};
+        factor_signs_from<2>(func, ar, src, me, prop, sg);
+      } else {
+        const uint32_t *const arr[2] = {assign, assign};
+        factor_signs<2>(func, ar, er[u].aux, P.vifs, me, arr, prop, sg);
+      }
       pp += w * (sg[0] * fv);
       pn += w * (sg[1] * fv);
     }
@@ -478,10 +606,16 @@ DWX_DEV void bool_potentials_both(const KernelParams &P, const TileView &T, uint
       ppf += h; pnf += m; ppe += h; pne += m;
     } else {
       const double fv = (er.packed & EDGE_F64_FLAG) ? P.edge_fval64[e] : (double)er.fval;
-      const uint32_t *const arr[4] = {P.assign_free, P.assign_free, P.assign_evid, P.assign_evid};
       const uint32_t prop[4] = {1u, 0u, 1u, 0u};
       double sg[4];
-      factor_signs<4>(edge_func(er), edge_arity(er), er.aux, P.vifs, me, arr, prop, sg);
+      if (edge_arity(er) == 1u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sg[j] = unary_sign(edge_func(er), prop[j] == er.aux);
+      } else {
+        const uint32_t *const chains[2] = {P.assign_free, P.assign_evid};
+        const int chain[4] = {0, 0, 1, 1};
+        record_signs<4, 2>(P, er, me, chains, chain, prop, sg);
+      }
       ppf += w * (sg[0] * fv); pnf += w * (sg[1] * fv);
       ppe += w * (sg[2] * fv); pne += w * (sg[3] * fv);
     }
@@ -638,10 +772,15 @@ DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uin
       pot_free = edge_term<true>(P, er, e, P.assign_free, me, free_value, free_value == hit_value);
     } else {   // one walk over the factor for both evaluations
       const double fv = (er.packed & EDGE_F64_FLAG) ? P.edge_fval64[e] : (double)er.fval;
-      const uint32_t *const arr[2] = {P.assign_evid, P.assign_free};
       const uint32_t prop[2] = {evid_value, free_value};
       double sg[2];
-      factor_signs<2>(edge_func(er), edge_arity(er), er.aux, P.vifs, me, arr, prop, sg);
+      if (edge_arity(er) == 1u) {
+        sg[0] = unary_sign(edge_func(er), prop[0] == er.aux); sg[1] = unary_sign(edge_func(er), prop[1] == er.aux);
+      } else {
+        const uint32_t *const chains[2] = {P.assign_evid, P.assign_free};
+        const int chain[2] = {0, 1};
+        record_signs<2, 2>(P, er, me, chains, chain, prop, sg);
+      }
       pot_evid = sg[0] * fv;
       pot_free = sg[1] * fv;
     }
@@ -957,7 +1096,7 @@ DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t
 template <bool LEARN, int K, bool WIDE = false>
 // (the learning kernel's LDS footprint admits 2 workgroups per CU at K = 12: give the
 // register allocator the matching budget instead of spilling at the 3-per-CU limit)
-__global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? 1 : (LEARN ? 2 : 3)) sweep_kernel(const KernelParams P) {
+__global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEARN ? (K <= 6 ? 3 : 2) : 3)) sweep_kernel(const KernelParams P) {
   DWX_DYN_LDS(dyn_lds);
   uint32_t *s_rowptr = (uint32_t *)dyn_lds;
   double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
