@@ -435,7 +435,14 @@ DWX_DEV double edge_term(const KernelParams &P, const EdgeRec &er, uint32_t idx,
   if (SIMPLE || (er.packed & EDGE_PRESIGNED))
     return (double)(hit ? er.fval : bits_to_float(er.aux));
   const double fv = (er.packed & EDGE_F64_FLAG) ? P.edge_fval64[idx] : (double)er.fval;
-  return factor_sign(edge_func(er), edge_arity(er), er.aux, P.vifs, assign, me, proposal) * fv;
+  if (edge_arity(er) == 1u) return unary_sign(edge_func(er), proposal == er.aux) * fv;
+  // (the factor's positions are loaded together, not one dependent load after the other)
+  const uint32_t *const chains[1] = {assign};
+  const int chain[1] = {0};
+  const uint32_t prop[1] = {proposal};
+  double sg[1];
+  record_signs<1, 1>(P, er, me, chains, chain, prop, sg);
+  return sg[0] * fv;
 }
 
 template <int WMODE>
