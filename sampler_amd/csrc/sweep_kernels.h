@@ -1367,7 +1367,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
       const unsigned long long nz = DWX_BALLOT(delta != 0), ng = DWX_BALLOT(delta < 0);
       if ((t & 63u) == 0) {
         unsigned long long *w = P.delta + ((size_t)tile * 4 + (t >> 6)) * 2;
-        w[0] = nz; w[1] = ng;
+        DWX_NT_STORE(nz, &w[0]); DWX_NT_STORE(ng, &w[1]);
       }
     }
     if (!has_next) break;
@@ -1501,7 +1501,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : 3) sweep8_kernel(cons
       const unsigned long long nz = DWX_BALLOT(delta != 0), ng = DWX_BALLOT(delta < 0);
       if ((t & 63u) == 0) {
         unsigned long long *wd = P.delta + ((size_t)tile * 4 + (t >> 6)) * 2;
-        wd[0] = nz; wd[1] = ng;
+        DWX_NT_STORE(nz, &wd[0]); DWX_NT_STORE(ng, &wd[1]);
       }
     }
     if (!has_next) break;
@@ -1683,6 +1683,19 @@ pull_grad_kernel(const uint32_t *inc_wid, const uint32_t *inc_slot, const float 
 // streams its share of b's rows -- coalesced 16-byte loads, independent iterations, no
 // barrier -- and stores one partial sum per weight; fold_partials_kernel adds the blocks'
 // partials into grad.  Integer sums: the result equals pull_grad_kernel's.
+// a 16-byte row, read once per sweep: non-temporal
+#ifndef DWX_LOAD_ROW_NT
+typedef uint32_t dwx_row_u32x4 __attribute__((ext_vector_type(4)));
+DWX_DEV U32x4 load_row_nt(const U32x4 *p) {
+  const dwx_row_u32x4 v = __builtin_nontemporal_load((const dwx_row_u32x4 *)p);
+  U32x4 r;
+  r.v[0] = v.x; r.v[1] = v.y; r.v[2] = v.z; r.v[3] = v.w;
+  return r;
+}
+#else
+DWX_DEV U32x4 load_row_nt(const U32x4 *p) { return *p; }
+#endif
+
 // UNIFORM: every record delta of the graph is the same (one feature value, one factor
 // function -- the usual case): its step comes in as an argument instead of an LDS table.
 template <int DEPTH, bool UNIFORM>
@@ -1718,7 +1731,7 @@ pull_ell_kernel(const U32x4 *__restrict__ ell, const uint32_t *block_tile0, uint
     for (uint32_t u = 0; u < BP_UNROLL; ++u) {
       const uint32_t w = umin(g + u, g1 - 1) * BP_THREADS + tid;
 #pragma unroll
-      for (int dd = 0; dd < DEPTH; ++dd) row[u][dd] = rows[(size_t)dd * Wp + w];
+      for (int dd = 0; dd < DEPTH; ++dd) row[u][dd] = load_row_nt(&rows[(size_t)dd * Wp + w]);
     }
 #pragma unroll
     for (uint32_t u = 0; u < BP_UNROLL; ++u) {
@@ -1740,7 +1753,7 @@ pull_ell_kernel(const U32x4 *__restrict__ ell, const uint32_t *block_tile0, uint
           acc += nz ? t : 0;
         }
       }
-      if (g + u < g1) out[(g + u) * BP_THREADS + tid] = acc;
+      if (g + u < g1) DWX_NT_STORE(acc, &out[(g + u) * BP_THREADS + tid]);
     }
   }
 }

@@ -48,6 +48,7 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::functi
 #define DWX_BALLOT(pred) (::emu::ballot(pred))
 #define DWX_UNIFORM(x) (x)
 #define DWX_NT_LOAD(p) (*(p))
+#define DWX_LOAD_ROW_NT 1
 #define DWX_NT_STORE(v, p) (*(p) = (v))
 
 inline void __syncthreads() { ::emu::syncthreads(); }
