@@ -106,7 +106,8 @@ typedef struct dwx_options {
   int32_t reserved;
   double reg_param;            /* -b / --reg_param                                     */
   double step_cap;             /* bound on stepsize x R of one SGD mini-batch (see
-                                  dwx_sgd_plan); <= 0: never split a sweep; default 1.0 */
+                                  dwx_sgd_plan); <= 0: never split a sweep; default 1.5
+                                  (dwx_default_options)                                 */
   uint64_t seed;               /* Philox key                                           */
   uint64_t var_id_offset;      /* added to local variable ids in the Philox counter: the
                                   global id of this shard's variable 0 (multi-GPU)     */
@@ -166,17 +167,26 @@ int dwx_wait(dwx_sampler *s);
  * InferenceResult::merge_gradients_from, src/inference_result.cc:57-62).
  *
  * The reference applies every factor's SGD update immediately; the device accumulates a
- * mini-batch and applies it in one step.  dwx_sgd_plan sizes the mini-batches for the
- * given step size: with R = the (estimated) largest eigenvalue of a batch's curvature in
- * weight space (how strongly all updates of one batch interact), every colour launch is cut
- * into `batches` runs of tiles carrying equal SGD work, batches = the first power of two
- * >= stepsize * R(1) / step_cap with stepsize * R(batches) <= step_cap, i.e. as many
- * pieces as keep one batched step inside the region where it tracks the sequential
- * updates (1 for configs 2-3 of BASELINE.json at their quoted step; dozens for heavily
- * tied weights with a large step; never more than 64 -- beyond that the step is shortened,
- * see effective_stepsize).  force_batches != 0 overrides (all ranks of a multi-GPU
- * run must use the same value).  A plan is a list of chunks (consecutive device-order runs
- * of variables, never crossing a colour; n_chunks <= batches * colours -- tiles that learn
+ * mini-batch and applies it in one step.  Two things keep that step faithful to the
+ * reference's sequential updates:
+ *  (1) the step of every weight SATURATES at the inverse of its own curvature bound h[w]
+ *      (dwx_sgd_apply_async: w -= (1 - exp(-c stepsize)) / c * (G + reg T w), c = h[w] + reg T
+ *      -- the end point of the gradient flow the T sequential updates follow).  A weight tied
+ *      to millions of factors can therefore never overshoot, whatever the step size; a weight
+ *      with few factors takes the reference's own step.  h is a static table (Gershgorin row
+ *      sums of the batch's curvature), part of DWX_BUF_TSTATIC*.
+ *  (2) dwx_sgd_plan sizes the mini-batches for the given step size: with R = the (estimated)
+ *      largest eigenvalue of a batch's curvature in weight space (how strongly all updates of
+ *      one batch interact), every colour launch is cut into `batches` runs of tiles carrying
+ *      equal SGD work, batches = the first power of two >= stepsize * R(1) / step_cap with
+ *      stepsize * R(batches) <= step_cap (1 for configs 2-3 of BASELINE.json at their quoted
+ *      step; dozens for heavily tied weights with a large step; never more than 64).  Inside a
+ *      batch all draws see the weights of its start, so the cut decides how closely the run
+ *      follows the reference from epoch to epoch -- not whether it is stable.
+ * effective_stepsize reports the SMALLEST step any weight takes under the plan (== stepsize
+ * unless a weight's bound saturates it).  force_batches != 0 overrides the cut (all ranks of a
+ * multi-GPU run must use the same value).  A plan is a list of chunks (consecutive device-order
+ * runs of variables, never crossing a colour; n_chunks <= batches * colours -- tiles that learn
  * nothing ride along with a neighbour); with batches == 1 the update is applied once after
  * the last chunk, otherwise after every chunk.
  *   dwx_sgd_plan -> n_chunks;  for c in chunks: dwx_sgd_accumulate_async(c) [+ collective,
@@ -191,6 +201,12 @@ int dwx_sgd_curvature(dwx_sampler *s, uint32_t batches, double *lambda);
  * beyond this rank's own chunks are zero), so that all ranks can sum equally sized tables
  * and every rank can apply the update of a chunk it idles through. */
 int dwx_sgd_plan_rows(dwx_sampler *s, uint32_t n_rows);
+/* Multi-GPU only: run the CURRENT split plan with per-record gradient atomics and dynamic
+ * update counts (the T half of DWX_BUF_GRAD) although this rank has per-chunk tables --
+ * because some other rank has none (its chunk count exceeds the table limit) and all ranks
+ * must put the same vector through the collective.  No effect on an un-split plan; reset by
+ * the next dwx_sgd_plan. */
+int dwx_sgd_plan_force_dynamic(dwx_sampler *s, int on);
 /* chunk_off[n_chunks+1]: chunk c covers positions [chunk_off[c], chunk_off[c+1]) of the
  * schedule order (dwx_graph_get_schedule). */
 int dwx_sgd_get_chunks(dwx_sampler *s, uint64_t *chunk_off);
@@ -230,10 +246,11 @@ enum {
   DWX_BUF_ASSIGN_FREE = 2,  /* uint32[V] in device order                           */
   DWX_BUF_ASSIGN_EVID = 3,  /* uint32[V] in device order                           */
   DWX_BUF_TALLIES = 4,      /* uint32[num_values] in device order                  */
-  DWX_BUF_TSTATIC = 5,      /* int64[W]: per-sweep update counts of boolean variables
-                               (fixed point, static); a multi-GPU driver sums it
-                               across shards once after create                     */
-  DWX_BUF_TSTATIC_PLAN = 6  /* int64[rows][W]: the same counts per chunk of the current
+  DWX_BUF_TSTATIC = 5,      /* int64[2W]: per-sweep update counts T[W] of boolean variables
+                               (fixed point 2^-30), then the curvature bounds h[W] of
+                               all variables (fixed point 2^-10); static; a multi-GPU
+                               driver sums it across shards once after create      */
+  DWX_BUF_TSTATIC_PLAN = 6  /* int64[rows][2W]: the same pair per chunk of the current
                                SPLIT plan (valid between dwx_sgd_plan and dwx_sgd_finish;
                                null / 0 bytes when the plan counts dynamically).  A
                                multi-GPU driver calls dwx_sgd_plan_rows(n_chunks of the

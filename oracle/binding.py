@@ -64,9 +64,11 @@ def lib():
         L.orc_logadd.restype = dbl; L.orc_logadd.argtypes = [dbl, dbl]
         L.orc_erand48.restype = dbl; L.orc_erand48.argtypes = [vp]
         L.orc_sched_sample.argtypes = [vp, vp, u64, u64]
-        L.orc_sched_sample_sgd.argtypes = [vp, vp, u64, u64, dbl, dbl]
+        L.orc_sched_sample_sgd.argtypes = [vp, vp, u64, u64, dbl]
         L.orc_sched_accumulate.argtypes = [vp, vp, u64, u64]
-        L.orc_sched_apply.argtypes = [vp, dbl, dbl]
+        L.orc_sched_apply.argtypes = [vp, dbl]
+        L.orc_sched_apply_h.argtypes = [vp, dbl, vp]
+        L.orc_sched_curvature.argtypes = [vp, vp, vp]
         L.orc_grad.restype = vp; L.orc_grad.argtypes = [vp]
         L.orc_set_var_id_offset.argtypes = [vp, u64]
         L.orc_set_sampling_weight_f32.argtypes = [vp, i32]
@@ -198,22 +200,34 @@ class Oracle:
         s = self._sched(order, launch_off)
         self.L.orc_sched_sample(self.h, C.addressof(s), seed, sweep)
 
-    def sched_sample_sgd(self, order, launch_off, seed, sweep, stepsize, step_cap=1.0):
+    def sched_sample_sgd(self, order, launch_off, seed, sweep, stepsize):
         self.L.orc_set_sampling_weight_f32(self.h, 1)
         s = self._sched(order, launch_off)
-        self.L.orc_sched_sample_sgd(self.h, C.addressof(s), seed, sweep, stepsize, step_cap)
+        self.L.orc_sched_sample_sgd(self.h, C.addressof(s), seed, sweep, stepsize)
 
     def sched_accumulate(self, order, launch_off, seed, sweep):
         self.L.orc_set_sampling_weight_f32(self.h, 1)
         s = self._sched(order, launch_off)
         self.L.orc_sched_accumulate(self.h, C.addressof(s), seed, sweep)
 
-    def sched_apply(self, stepsize, step_cap=1.0):
-        self.L.orc_sched_apply(self.h, stepsize, step_cap)
+    def sched_apply(self, stepsize, hess=None):
+        """hess: int64[W] curvature bounds to use instead of the accumulated ones."""
+        if hess is None:
+            self.L.orc_sched_apply(self.h, stepsize)
+        else:
+            hess = np.ascontiguousarray(hess, np.int64)
+            self.L.orc_sched_apply_h(self.h, stepsize, hess.ctypes.data)
+
+    def sched_curvature(self, order):
+        order = np.ascontiguousarray(order, np.uint64)
+        s = self._sched(order, np.array([0, len(order)], np.uint64))
+        out = np.zeros(self.W, np.int64)
+        self.L.orc_sched_curvature(self.h, C.addressof(s), out.ctypes.data)
+        return out
 
     @property
     def grad(self):
-        return _view(self.L.orc_grad(self.h), 2 * self.W, np.int64)
+        return _view(self.L.orc_grad(self.h), 3 * self.W, np.int64)   # [G | T | H]
 
     def set_var_id_offset(self, off):
         self.L.orc_set_var_id_offset(self.h, off)

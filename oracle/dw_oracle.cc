@@ -114,7 +114,7 @@ struct orc_sampler {
   // exported columns
   std::vector<uint64_t> c_var_val_base, c_value_sparse, c_index_base, c_index_len, c_assign_dense;
   // schedule-mode accumulators
-  std::vector<int64_t> GT;   // G[W] then T[W]
+  std::vector<int64_t> GT;   // G[W], T[W], then H[W] (curvature bounds, schedule mode)
   uint64_t vid_offset = 0;
   bool f32w = false;  // schedule mode: potentials use the weight rounded to f32 (device's sampling copy)
 
@@ -294,6 +294,53 @@ struct orc_sampler {
     }
   }
 
+  // ---- schedule mode only: curvature bound of a variable's SGD updates, per factor ----
+  // Restates the device's static table (sampler_amd/csrc/dwx_api.cc
+  // for_each_record_bound): delta of a factor = how far it can move the variable's potential
+  // between two of its values -- |sign(hit) - sign(miss)| |f| at arity 1 (the sign functions of
+  // src/factor.h:112-299 with one satisfied bit), 2 |f| (arity - 1) beyond; a boolean variable
+  // bounds factor r by 1/4 delta_r * (sum of its row's deltas), a categorical one by
+  // 1/2 delta_r * (largest sum of deltas of one of its value rows).  Fixed weights: 0.
+  static double unary_sign_of(int func, bool sat) {
+    switch (func) {
+      case F_AND: case F_ISTRUE: case F_OR: case F_IMPLY_NATURAL: return sat ? 1.0 : -1.0;
+      case F_EQUAL: return 1.0;
+      default: return sat ? 1.0 : 0.0;
+    }
+  }
+  double factor_delta(const Factor &f, const Var &var) const {
+    if (weights_isfixed[f.weight_id]) return 0.0;
+    if (f.num_vars <= 1) {
+      const uint64_t eq = vifs[f.vif_base].dense_equal_to;
+      const double hit = unary_sign_of(f.func, !var.is_bool || eq == 1);
+      const double miss = unary_sign_of(f.func, var.is_bool && eq == 0);
+      return std::fabs(hit - miss) * std::fabs(f.feature_value);
+    }
+    return 2.0 * std::fabs(f.feature_value) * (double)(f.num_vars - 1);
+  }
+  template <class Fn>
+  void curvature_bounds(uint64_t vid, Fn &&fn) const {
+    const Var &var = vars[vid];
+    const uint64_t rows = var.is_bool ? 1 : var.cardinality;
+    double S = 0.0;
+    for (uint64_t d = 0; d < rows; ++d) {
+      const Value &vv = values[var.var_val_base + d];
+      double sr = 0.0;
+      for (uint64_t j = 0; j < vv.index_len; ++j) sr += factor_delta(factors[factor_index[vv.index_base + j]], var);
+      S = var.is_bool ? S + sr : std::max(S, sr);
+    }
+    if (S == 0.0) return;
+    const double kappa = var.is_bool ? 0.25 : 0.5;
+    for (uint64_t d = 0; d < rows; ++d) {
+      const Value &vv = values[var.var_val_base + d];
+      for (uint64_t j = 0; j < vv.index_len; ++j) {
+        const Factor &f = factors[factor_index[vv.index_base + j]];
+        const double dl = factor_delta(f, var);
+        if (dl != 0.0) fn(f.weight_id, kappa * dl * S);
+      }
+    }
+  }
+
   bool sgd_triggers(const Var &var) const {  // src/gibbs_sampler.h:144-146 (negated)
     return opts.learn_non_evidence || ((!opts.noise_aware && var.is_evid) ||
                                        (opts.noise_aware && has_truthiness(var)));
@@ -424,7 +471,7 @@ extern "C" orc_sampler *orc_create(const orc_graph_desc *d, const orc_opts *opts
       s->a_free[v] = s->a_evid[v] = s->vars[v].is_evid ? s->vars[v].assignment_dense : 0;
     s->tallies.assign(nval, 0);
     s->nsamples.assign(s->V, 0);
-    s->GT.assign(2 * s->W, 0);
+    s->GT.assign(3 * s->W, 0);
     // exported columns
     s->c_var_val_base.resize(s->V); s->c_assign_dense.resize(s->V);
     for (uint64_t v = 0; v < s->V; ++v) {
@@ -607,6 +654,7 @@ extern "C" void orc_philox_uniforms(uint64_t seed, uint64_t vid, uint64_t sweep,
 // ---------------------------------------------------------------------------
 namespace {
 constexpr double kFixScale = 1073741824.0;  // 2^30
+constexpr double kHessScale = 1024.0;       // 2^10 (curvature bounds)
 struct OneShot {   // hands out the pre-drawn uniform
   double r;
   double operator()() { return r; }
@@ -648,7 +696,7 @@ extern "C" void orc_sched_sample(orc_sampler *s, const orc_schedule *sch, uint64
 extern "C" void orc_sched_accumulate(orc_sampler *s, const orc_schedule *sch, uint64_t seed,
                                      uint64_t sweep) {
   std::vector<double> buf;
-  int64_t *G = s->GT.data(), *T = s->GT.data() + s->W;
+  int64_t *G = s->GT.data(), *T = s->GT.data() + s->W, *H = s->GT.data() + 2 * s->W;
   for (uint64_t i = 0; i < sch->n_order; ++i) {
     uint64_t vid = sch->order[i];
     double A, B;
@@ -662,28 +710,49 @@ extern "C" void orc_sched_accumulate(orc_sampler *s, const orc_schedule *sch, ui
       G[wid] += llrint(kFixScale * (t * g));
       T[wid] += llrint(kFixScale * t);
     });
+    s->curvature_bounds(vid, [H](uint64_t wid, double bound) { H[wid] += llrint(kHessScale * bound); });
   }
 }
 
-extern "C" void orc_sched_apply(orc_sampler *s, double stepsize, double step_cap) {
-  int64_t *G = s->GT.data(), *T = s->GT.data() + s->W;
+// The device's batched update (apply_kernel, sampler_amd/csrc/sweep_kernels.h): the end point
+// of the gradient flow the reference's T sequential updates of a weight follow over the batch,
+// with the gradient linearised with slope h:  w -= s (G + reg T w),
+// s = (1 - exp(-c stepsize)) / c, c = h + reg T  (-> the reference's own step for c stepsize
+// << 1).  L1 keeps the reference's form, only the gradient step saturates.
+// hess != null: use these bounds instead of the accumulated ones (the device's fallback for
+// plans without per-chunk tables applies every chunk with the WHOLE sweep's bounds)
+extern "C" void orc_sched_apply_h(orc_sampler *s, double stepsize, const int64_t *hess);
+extern "C" void orc_sched_apply(orc_sampler *s, double stepsize) { orc_sched_apply_h(s, stepsize, nullptr); }
+// out[W] = the curvature bounds of the SGD-triggering variables of the schedule (fixed point)
+extern "C" void orc_sched_curvature(orc_sampler *s, const orc_schedule *sch, int64_t *out) {
+  for (uint64_t w = 0; w < s->W; ++w) out[w] = 0;
+  for (uint64_t i = 0; i < sch->n_order; ++i) {
+    const uint64_t vid = sch->order[i];
+    if (!s->sgd_triggers(s->vars[vid])) continue;
+    s->curvature_bounds(vid, [out](uint64_t wid, double bound) { out[wid] += llrint(kHessScale * bound); });
+  }
+}
+extern "C" void orc_sched_apply_h(orc_sampler *s, double stepsize, const int64_t *hess) {
+  int64_t *G = s->GT.data(), *T = s->GT.data() + s->W, *H = s->GT.data() + 2 * s->W;
+  auto step = [stepsize](double c) { return c > 0.0 ? -expm1(-c * stepsize) / c : stepsize; };
   for (uint64_t w = 0; w < s->W; ++w) {
-    const int64_t g = G[w], t = T[w];
-    G[w] = 0; T[w] = 0;
+    const int64_t g = G[w], t = T[w], h = hess ? hess[w] : H[w];
+    G[w] = 0; T[w] = 0; H[w] = 0;
     if (s->weights_isfixed[w] || t == 0) continue;
-    double Tt = (double)t / kFixScale, Gg = (double)g / kFixScale;
-    double eta = stepsize;
-    if (step_cap > 0 && eta * Tt > step_cap) eta = step_cap / Tt;
+    const double Tt = (double)t / kFixScale, Gg = (double)g / kFixScale, hh = (double)h / kHessScale;
     double x = s->weight_values[w];
-    if (s->opts.regularization == 1) x *= pow(1.0 / (1.0 + s->opts.reg_param * eta), Tt);
-    else x += s->opts.reg_param * Tt * (x < 0);
-    x -= eta * Gg;
+    if (s->opts.regularization == 1) {
+      x -= step(hh + s->opts.reg_param * Tt) * (Gg + s->opts.reg_param * Tt * x);
+    } else {
+      x += s->opts.reg_param * Tt * (x < 0);
+      x -= step(hh) * Gg;
+    }
     s->weight_values[w] = x;
   }
 }
 
 extern "C" void orc_sched_sample_sgd(orc_sampler *s, const orc_schedule *sch, uint64_t seed,
-                                     uint64_t sweep, double stepsize, double step_cap) {
+                                     uint64_t sweep, double stepsize) {
   orc_sched_accumulate(s, sch, seed, sweep);
-  orc_sched_apply(s, stepsize, step_cap);
+  orc_sched_apply(s, stepsize);
 }

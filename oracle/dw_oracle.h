@@ -119,11 +119,16 @@ typedef struct orc_schedule {
 
 void orc_sched_sample(orc_sampler *s, const orc_schedule *sch, uint64_t seed, uint64_t sweep);
 void orc_sched_sample_sgd(orc_sampler *s, const orc_schedule *sch, uint64_t seed, uint64_t sweep,
-                          double stepsize, double step_cap);
-/* the two halves of orc_sched_sample_sgd: sample + accumulate G,T; then apply + clear */
+                          double stepsize);
+/* the two halves of orc_sched_sample_sgd: sample + accumulate G, T and the curvature bounds
+ * H of the visited variables; then the saturating update (see orc_sched_apply) + clear */
 void orc_sched_accumulate(orc_sampler *s, const orc_schedule *sch, uint64_t seed, uint64_t sweep);
-void orc_sched_apply(orc_sampler *s, double stepsize, double step_cap);
-/* int64[2W]: fixed-point gradient sums G[W] then update counts T[W] */
+void orc_sched_apply(orc_sampler *s, double stepsize);
+/* the same with explicit curvature bounds (int64[W], fixed point 2^-10) instead of the
+ * accumulated ones; orc_sched_curvature computes them for a list of variables */
+void orc_sched_apply_h(orc_sampler *s, double stepsize, const int64_t *hess);
+void orc_sched_curvature(orc_sampler *s, const orc_schedule *sch, int64_t *out);
+/* int64[3W]: fixed-point gradient sums G[W], update counts T[W], curvature bounds H[W] */
 int64_t *orc_grad(orc_sampler *s);
 /* global id of local variable 0: added to ids in the Philox counter (shards) */
 void orc_set_var_id_offset(orc_sampler *s, uint64_t off);

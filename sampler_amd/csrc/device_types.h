@@ -119,6 +119,10 @@ constexpr uint32_t OPT_DYNAMIC_T = 1u << 5;
 constexpr uint32_t OPT_NO_PULL = 1u << 6;
 
 constexpr double FIX_SCALE = 1073741824.0;  // 2^30: gradient fixed-point scale
+// Per-weight curvature bounds h[w] (apply_kernel's saturating step) are summed in fixed point
+// too -- order-independent, all-reducible -- at a coarser scale: a bound needs no more, and
+// hubs with 10^5 records reach 10^10.
+constexpr double H_SCALE = 1024.0;          // 2^10
 constexpr double LINEAR_ZERO_THRESHOLD = 0.000001;  // src/common.h:15
 
 constexpr uint32_t BLOCK_THREADS = 256;

@@ -371,7 +371,9 @@ bool parse_piece(const Mapped &m, const std::string &path, const Piece &pc, Load
       if (speculative) return false;
       throw std::runtime_error(path + ": truncated factor record");
     }
-    if (f >= g.n_factors || arity > g.n_edges - e) return false;   // more than the meta file announced
+    // more than the meta file announced (e may already be past n_edges in a speculative piece:
+    // test it before the subtraction, which would wrap)
+    if (f >= g.n_factors || e > g.n_edges || arity > g.n_edges - e) return false;
     g.fac_func[f] = func;
     g.fac_edge_offset[f] = e;
     for (uint64_t i = 0; i < arity; ++i, off += 16, ++e) {
@@ -409,7 +411,11 @@ void load_factors(const std::vector<std::string> &files, LoadedGraph &g) {
           const uint64_t k = std::min(kPiece, n - r);
           pieces.push_back({(size_t)(r * rs), k, f_base + r, e_base + r * a0, (size_t)((r + k) * rs)});
         }
-        std::atomic<bool> ok{n <= g.n_factors - f_base};
+        // the pieces write fac_*[f_base + r] and edge_*[e_base + r * a0 ...]: reject before any
+        // thread starts if the meta file announced fewer factors or edges than this file holds
+        // (the general path below then reports which count is off)
+        std::atomic<bool> ok{f_base <= g.n_factors && n <= g.n_factors - f_base && e_base <= g.n_edges &&
+                             (a0 == 0 || n <= (g.n_edges - e_base) / a0)};
         if (ok)
           dwx::parallel_ranges(pieces.size(), nth, [&](uint64_t b, uint64_t e) {
             for (uint64_t i = b; i < e && ok; ++i)

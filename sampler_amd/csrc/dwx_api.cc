@@ -150,8 +150,9 @@ struct dwx_sampler {
     uint32_t *d_inc_wid = nullptr, *d_inc_slot = nullptr;
     float *d_inc_d = nullptr;
     std::vector<uint32_t> inc_begin, inc_end;   // per chunk, entries (multiples of PULL_RUN)
-    long long *d_t_static = nullptr;
+    long long *d_t_static = nullptr;   // [rows][T[W] | h[W]]: static update counts, curvature bounds
     uint32_t rows = 0;
+    double c_max = 0.0, t_max = 0.0;   // largest h and largest static T of any (chunk, weight)
     // block pull (pull_ell_kernel; graphs with many weights): per group of the tables (the
     // un-split sweep, or each chunk of a split one) entry rows per (variable block, weight);
     // d_inc_* then only holds what did not fit a row.  blocks == 0: the group pulls its list.
@@ -171,6 +172,7 @@ struct dwx_sampler {
   };
   std::map<uint32_t, std::unique_ptr<Level>> levels;
   Level *plan_level = nullptr;        // level of the current plan
+  bool plan_force_dynamic = false;    // dwx_sgd_plan_force_dynamic (multi-GPU agreement)
   uint32_t cur_chunk = 0;             // last chunk handed to dwx_sgd_accumulate_async
   uint8_t *d_w_fixed = nullptr;
   long long *d_grad = nullptr;
@@ -331,6 +333,64 @@ bool triggers_sgd(const dwx_options &o, uint32_t meta) {
          (o.noise_aware && (meta & VM_TRUTHINESS));
 }
 
+// How far one record can move its owner's potential between two of the owner's values, the
+// building block of every curvature bound below: |sign(hit) - sign(miss)| * |f| for a unary
+// factor (src/factor.h:112-299 at arity 1; boolean owner: hit = "1 satisfies the predicate",
+// miss = "0 does"; categorical owner: the record sits in the row of the value that satisfies
+// it), 2 |f| (arity - 1) for wider ones (a sign spans [-1, 1]; LINEAR counts up to arity - 1).
+// Fixed weights do not move: 0.  The oracle restates this (orc_sched_accumulate).
+double host_unary_sign(uint32_t func, bool sat) {
+  switch (func) {
+    case FUNC_AND: case FUNC_ISTRUE: case FUNC_OR: case FUNC_IMPLY_NATURAL: return sat ? 1.0 : -1.0;
+    case FUNC_EQUAL: return 1.0;
+    default: return sat ? 1.0 : 0.0;
+  }
+}
+double record_delta(const CompiledGraph &c, uint32_t e, bool owner_is_cat) {
+  const EdgeRec &r = c.edges[e];
+  if (r.packed & EDGE_FIXED_FLAG) return 0.0;
+  if (r.packed & EDGE_PRESIGNED) {
+    float miss;
+    std::memcpy(&miss, &r.aux, 4);
+    return std::fabs((double)r.fval - (double)miss);
+  }
+  const double f = (r.packed & EDGE_F64_FLAG) ? c.edge_fval64[e] : (double)r.fval;
+  const uint32_t ar = (r.packed & EDGE_INLINE2) ? 2u : ((r.packed >> EDGE_ARITY_SHIFT) & EDGE_ARITY_MASK);
+  if (ar <= 1u) {
+    const uint32_t fn = r.packed & EDGE_FUNC_MASK;
+    const double hit = host_unary_sign(fn, owner_is_cat || r.aux == 1u);
+    const double miss = host_unary_sign(fn, !owner_is_cat && r.aux == 0u);
+    return std::fabs(hit - miss) * std::fabs(f);
+  }
+  return 2.0 * std::fabs(f) * (double)(ar - 1u);
+}
+
+// Gershgorin bound of one variable's share of the batch curvature, per record: the variable's
+// SGD gradient over the weights has Jacobian kappa * d d^T for a boolean variable (logistic:
+// kappa = p (1 - p) <= 1/4, d = the records' deltas) and J^T (diag(p) - p p^T) J for a
+// categorical one (softmax over its value rows; absolute row sums of diag(p) - p p^T are
+// 2 p (1 - p) <= 1/2).  Row sum of |H| for weight w: sum over w's records r of
+//   1/4 * d_r * (sum of the row's deltas)              boolean
+//   1/2 * d_r * (largest sum of deltas of a value row) categorical.
+// fn(e, bound) is called for every record with a non-zero bound.
+template <class Fn>
+void for_each_record_bound(const CompiledGraph &c, uint32_t p, Fn &&fn) {
+  const uint32_t m = c.v_meta[p];
+  const bool cat = m & VM_CATEGORICAL;
+  double S = 0.0;
+  for (uint32_t r = c.v_row[p]; r < c.v_row[p + 1]; ++r) {
+    double sr = 0.0;
+    for (uint32_t e = c.row_ptr[r]; e < c.row_ptr[r + 1]; ++e) sr += record_delta(c, e, cat);
+    S = cat ? std::max(S, sr) : S + sr;
+  }
+  if (S == 0.0) return;
+  const double kappa = cat ? 0.5 : 0.25;
+  for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p + 1]]; ++e) {
+    const double d = record_delta(c, e, cat);
+    if (d != 0.0) fn(e, kappa * d * S);
+  }
+}
+
 // Everything a plan level needs to run its chunks without per-record atomics: per chunk,
 // (a) the static update counts of its boolean variables -- a boolean variable that triggers
 // SGD visits every factor of its row once with t = 1 (src/factor_graph.cc:265-273),
@@ -354,7 +414,7 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
   // per-record atomics and dynamic counts
   uint32_t table_chunks = 4 * MAX_PLAN_BATCHES;
   if (const char *e = getenv("DWX_PLAN_TABLE_CHUNKS")) table_chunks = (uint32_t)std::max(1L, atol(e));   // test hook
-  L->fast = nc >= 1 && nc <= table_chunks && (uint64_t)nc * c.W * 8 <= ((uint64_t)2 << 30);
+  L->fast = nc >= 1 && nc <= table_chunks && (uint64_t)nc * c.W * 16 <= ((uint64_t)2 << 30);
   if (batches == 1) L->fast = true;
   if (L->fast && c.W) {
     // groups of the tables: the chunks of a split sweep (an update follows each of them); ONE
@@ -367,24 +427,44 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
     std::vector<uint32_t> chunk_of(c.tiles.size(), 0);
     for (uint32_t k = 0; k < nc; ++k)
       for (uint32_t t = groups[k].t0; t < groups[k].t1; ++t) chunk_of[t] = k;
-    // (a) static counts, one row per group (rows are disjoint: groups in parallel)
+    // (a) static tables, one row pair per group (rows are disjoint: groups in parallel): the
+    // update counts T of boolean variables and the curvature bounds h of all variables
+    // (apply_kernel's saturating step); row k = [T[W] | h[W]]
     L->rows = nc;
-    RawArray<long long> ts((size_t)nc * c.W);
-    parallel_ranges((uint64_t)nc * c.W, nth, [&](uint64_t b, uint64_t e) { std::fill(ts.data() + b, ts.data() + e, 0LL); });
+    RawArray<long long> ts((size_t)nc * 2 * c.W);
+    parallel_ranges((uint64_t)nc * 2 * c.W, nth, [&](uint64_t b, uint64_t e) { std::fill(ts.data() + b, ts.data() + e, 0LL); });
     const long long one = (long long)FIX_SCALE;
     parallel_ranges(nc, std::min(nth, nc), [&](uint64_t kb, uint64_t ke) {
       for (uint64_t k = kb; k < ke; ++k) {
-        long long *row = ts.data() + k * c.W;
+        long long *row = ts.data() + k * 2 * c.W, *hrow = row + c.W;
         const uint32_t p0 = c.tile_v[groups[k].t0], p1 = c.tile_v[groups[k].t1];
         for (uint32_t p = p0; p < p1; ++p) {
           const uint32_t m = c.v_meta[p];
-          if ((m & VM_CATEGORICAL) || !triggers_sgd(o, m)) continue;
+          if (!triggers_sgd(o, m)) continue;
+          for_each_record_bound(c, p, [&](uint32_t e, double bound) {
+            hrow[c.edges[e].wid] += std::llrint(H_SCALE * bound);
+          });
+          if (m & VM_CATEGORICAL) continue;   // (their counts depend on the samples: dynamic)
           for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p] + 1]; ++e)
             if (!c.w_fixed[c.edges[e].wid]) row[c.edges[e].wid] += one;
         }
       }
     }, 2);
-    L->d_t_static = upload_raw(ts.data(), (size_t)nc * c.W, s->stream);
+    {
+      const uint32_t T = std::max(1u, std::min(nth, 16u));
+      std::vector<double> hm(T, 0.0), tm(T, 0.0);
+      parallel_parts((uint64_t)nc * c.W, T, [&](uint32_t t, uint64_t b, uint64_t e) {
+        long long h = 0, tt = 0;
+        for (uint64_t i = b; i < e; ++i) {
+          const uint64_t k = i / c.W, w = i % c.W;
+          tt = std::max(tt, ts[k * 2 * c.W + w]);
+          h = std::max(h, ts[(k * 2 + 1) * c.W + w]);
+        }
+        hm[t] = (double)h / H_SCALE; tm[t] = (double)tt / FIX_SCALE;
+      }, 0);
+      for (uint32_t t = 0; t < T; ++t) { L->c_max = std::max(L->c_max, hm[t]); L->t_max = std::max(L->t_max, tm[t]); }
+    }
+    L->d_t_static = upload_raw(ts.data(), (size_t)nc * 2 * c.W, s->stream);
     // (b) incidence list
     struct Inc { uint32_t wid, slot; float d; uint32_t chunk; };
     RawArray<Inc> by_w, by_c;
@@ -639,18 +719,7 @@ double row_sum_bound(dwx_sampler *s, uint32_t batches) {
   std::vector<uint8_t> seen(c.W, 0);
   std::vector<uint32_t> touched;
   double lam_max = 0.0;
-  auto rec_d = [&](uint32_t e) -> double {
-    const EdgeRec &r = c.edges[e];
-    if (r.packed & EDGE_FIXED_FLAG) return 0.0;
-    if (r.packed & EDGE_PRESIGNED) {
-      float miss;
-      std::memcpy(&miss, &r.aux, 4);
-      return std::fabs((double)r.fval - (double)miss);
-    }
-    const double f = (r.packed & EDGE_F64_FLAG) ? c.edge_fval64[e] : (double)r.fval;
-    const uint32_t ar = (r.packed & EDGE_INLINE2) ? 2u : ((r.packed >> EDGE_ARITY_SHIFT) & EDGE_ARITY_MASK);
-    return 2.0 * std::fabs(f) * std::max(1u, ar - 1);
-  };
+  auto rec_d = [&](uint32_t e, bool cat) -> double { return record_delta(c, e, cat); };
   auto triggers = [&](uint32_t m) {
     return s->opts.learn_non_evidence || (!s->opts.noise_aware && (m & VM_EVIDENCE)) ||
            (s->opts.noise_aware && (m & VM_TRUTHINESS));
@@ -680,9 +749,9 @@ double row_sum_bound(dwx_sampler *s, uint32_t batches) {
               const uint32_t e0 = c.row_ptr[c.v_row[p]], e1 = c.row_ptr[c.v_row[p + 1]];
               const double kappa = (m & VM_CATEGORICAL) ? 0.5 : 0.25;
               double dot = 0.0;
-              for (uint32_t e = e0; e < e1; ++e) dot += rec_d(e) * x[c.edges[e].wid];
+              for (uint32_t e = e0; e < e1; ++e) dot += rec_d(e, (m & VM_CATEGORICAL) != 0) * x[c.edges[e].wid];
               for (uint32_t e = e0; e < e1; ++e) {
-                const double d = rec_d(e);
+                const double d = rec_d(e, (m & VM_CATEGORICAL) != 0);
                 if (d == 0.0) continue;
                 yt[c.edges[e].wid] += kappa * d * dot;
                 if (iter == 0) dt[c.edges[e].wid] += kappa * d * d;
@@ -721,14 +790,14 @@ double row_sum_bound(dwx_sampler *s, uint32_t batches) {
           const double kappa = (m & VM_CATEGORICAL) ? 0.5 : 0.25;
           double dot = 0.0;
           for (uint32_t e = e0; e < e1; ++e) {
-            const double d = rec_d(e);
+            const double d = rec_d(e, (m & VM_CATEGORICAL) != 0);
             if (d == 0.0) continue;
             const uint32_t w = c.edges[e].wid;
             if (!seen[w]) { seen[w] = 1; touched.push_back(w); x[w] = 1.0; }
             dot += d * x[w];
           }
           for (uint32_t e = e0; e < e1; ++e) {
-            const double d = rec_d(e);
+            const double d = rec_d(e, (m & VM_CATEGORICAL) != 0);
             if (d == 0.0) continue;
             y[c.edges[e].wid] += kappa * d * dot;
             if (iter == 0) diag[c.edges[e].wid] += kappa * d * d;   // (lower bound of H_ww)
@@ -756,15 +825,14 @@ void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
   uint32_t max_tiles = 1;
   for (size_t l = 0; l + 1 < c.launch_off.size(); ++l)
     max_tiles = std::max(max_tiles, c.launch_tile[l + 1] - c.launch_tile[l]);
-  // No plan cuts finer than MAX_PLAN_BATCHES: beyond that the step is shortened instead.  The
-  // iteration then runs at the edge of its stability region -- near-Newton steps along the
-  // stiffest direction -- and still reaches the optimum the sequential updates reach (a
-  // handful of weights tied to millions of factors would otherwise turn every sweep into
-  // thousands of one-tile launches).
+  // No plan cuts finer than MAX_PLAN_BATCHES.  Stability does not depend on the cut: every
+  // weight's step saturates at the inverse of its own curvature bound (apply_kernel), so a batch
+  // can never overshoot.  The cut decides how closely the batches follow the reference's
+  // sequential updates: inside a batch all draws see the weights of its start.
   max_tiles = std::min(max_tiles, MAX_PLAN_BATCHES);
   const double cap = s->opts.step_cap;
   uint32_t B = 1;
-  double eta = stepsize;
+  const double eta = stepsize;
   if (force_batches) {
     B = std::min(force_batches, max_tiles);
   } else if (cap > 0 && stepsize > 0) {
@@ -773,11 +841,6 @@ void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
     while (B < max_tiles && (double)B < need) B *= 2;
     while (B < max_tiles && stepsize * row_sum_bound(s, B) > cap) B *= 2;
     B = std::min(B, max_tiles);
-  }
-  if (cap > 0 && stepsize > 0) {
-    // even one tile per batch is too coarse for this step: shrink the step instead
-    const double R = row_sum_bound(s, B);
-    if (stepsize * R > cap && (force_batches == 0 || B >= max_tiles)) eta = cap / R;
   }
   s->plan_batches = B;
   s->plan_eta = eta;
@@ -794,7 +857,18 @@ void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
   s->plan_level = build_level(s, B);
   s->plan_chunks = s->plan_level->chunks;
   s->cur_chunk = 0;
+  s->plan_force_dynamic = false;
   s->plan_valid = true;
+}
+
+// The smallest step any weight takes under the current plan: stepsize saturated by the largest
+// curvature bound (+ regularisation pull) of the plan's tables -- what `effective_stepsize`
+// reports (== stepsize for weights with few factors; ~1/h for heavily tied ones).
+double plan_min_step(dwx_sampler *s) {
+  const dwx_sampler::Level *L = s->plan_level;
+  if (!L || L->c_max <= 0.0 || s->plan_eta <= 0.0) return s->plan_eta;
+  const double c = L->c_max + (s->opts.regularization == 1 ? s->opts.reg_param * L->t_max : 0.0);
+  return -std::expm1(-c * s->plan_eta) / c;
 }
 
 // accumulate the gradient of one chunk of the plan (sampling both chains on the way)
@@ -807,7 +881,8 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
   const dwx_sampler::Level &L = *s->plan_level;
   const bool split = s->plan_batches > 1;
   // a split sweep without per-chunk tables falls back to per-record atomics and counts
-  if (split && !L.fast) P.flags |= OPT_DYNAMIC_T | OPT_NO_PULL;
+  const bool fast = L.fast && !(split && s->plan_force_dynamic);
+  if (split && !fast) P.flags |= OPT_DYNAMIC_T | OPT_NO_PULL;
   TimedSpan sp{};
   if (s->timing) {
     sp.a = rt::event_create(); sp.b = rt::event_create(); sp.c = rt::event_create(); sp.kind = 1;
@@ -819,13 +894,13 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
   // the pull-based gradient of the TILE_PULL tiles: un-split sweeps once, after the last
   // chunk (= colour launch), over the whole list; split sweeps per chunk over its part
   uint32_t pb = 0, pe = 0;
-  if (L.fast && !L.inc_end.empty()) {
+  if (fast && !L.inc_end.empty()) {
     if (!split) { if (chunk + 1 == s->plan_chunks.size()) { pb = L.inc_begin.front(); pe = L.inc_end.back(); } }
     else { pb = L.inc_begin[chunk]; pe = L.inc_end[chunk]; }
   }
   // block pull of the same group as the list below: the whole sweep (un-split, after the
   // last colour launch) or this chunk
-  if (L.fast && !L.bp.empty() && (split || chunk + 1 == s->plan_chunks.size())) {
+  if (fast && !L.bp.empty() && (split || chunk + 1 == s->plan_chunks.size())) {
     const dwx_sampler::Level::BlockTable &bt = L.bp[split ? chunk : 0];
     if (bt.blocks) {
       const unsigned grid = bt.blocks * bt.parts;
@@ -865,16 +940,23 @@ void enqueue_apply(dwx_sampler *s) {
   const uint32_t W = (uint32_t)s->cg->W;
   if (!W) return;
   const unsigned grid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 2048u);
-  // static update counts of what was just accumulated: row 0 of an un-split sweep, the
-  // chunk's row of a split one (none on the atomics fallback: counts are in the grad buffer)
+  // static tables of what was just accumulated: row pair 0 of an un-split sweep, the chunk's of
+  // a split one.  On the atomics fallback (a split plan without tables, or one a multi-GPU
+  // driver forced to count dynamically) the counts are in the grad buffer and the curvature
+  // bounds are those of the WHOLE sweep (level 1: >= any chunk's, so the step only saturates
+  // earlier)
   const dwx_sampler::Level *L = s->plan_level;
-  const long long *ts = nullptr;
-  if (L && L->fast && L->d_t_static) {
-    const uint32_t row = s->plan_batches > 1 ? s->cur_chunk : 0u;
-    if (row < L->rows) ts = L->d_t_static + (size_t)row * W;
+  const bool split = s->plan_batches > 1;
+  const long long *ts = nullptr, *hs = nullptr;
+  if (L && L->fast && L->d_t_static && !(split && s->plan_force_dynamic)) {
+    const uint32_t row = split ? s->cur_chunk : 0u;
+    if (row < L->rows) { ts = L->d_t_static + (size_t)row * 2 * W; hs = ts + W; }
+  } else {
+    auto it = s->levels.find(1);
+    if (it != s->levels.end() && it->second->d_t_static) hs = it->second->d_t_static + W;
   }
   rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
-             (const uint8_t *)s->d_w_fixed, s->d_grad, ts, W, s->plan_eta, s->opts.reg_param,
+             (const uint8_t *)s->d_w_fixed, s->d_grad, ts, hs, W, s->plan_eta, s->opts.reg_param,
              (int)(s->opts.regularization == 1));
 }
 
@@ -1199,7 +1281,7 @@ int dwx_sgd_plan(dwx_sampler *s, double stepsize, uint32_t force_batches, uint32
     make_plan(s, stepsize, force_batches);
     if (batches) *batches = s->plan_batches;
     if (n_chunks) *n_chunks = (uint32_t)s->plan_chunks.size();
-    if (effective_stepsize) *effective_stepsize = s->plan_eta;
+    if (effective_stepsize) *effective_stepsize = plan_min_step(s);
   });
 }
 
@@ -1217,14 +1299,21 @@ int dwx_sgd_plan_rows(dwx_sampler *s, uint32_t n_rows) {
     const uint64_t W = s->cg->W;
     if (!L.fast || s->plan_batches <= 1 || n_rows <= L.rows || !W) return;
     rt::set_device(s->device);
-    long long *grown = (long long *)rt::dmalloc((size_t)n_rows * W * 8);
-    rt::dmemset(grown, 0, (size_t)n_rows * W * 8, s->stream);
-    rt::d2d(grown, L.d_t_static, (size_t)L.rows * W * 8, s->stream);
+    long long *grown = (long long *)rt::dmalloc((size_t)n_rows * 2 * W * 8);
+    rt::dmemset(grown, 0, (size_t)n_rows * 2 * W * 8, s->stream);
+    rt::d2d(grown, L.d_t_static, (size_t)L.rows * 2 * W * 8, s->stream);
     rt::stream_sync(s->stream);
     rt::dfree(L.d_t_static);
     L.d_t_static = grown;
     L.rows = n_rows;
   });
+}
+
+int dwx_sgd_plan_force_dynamic(dwx_sampler *s, int on) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  if (!s->plan_valid || !s->plan_level) return fail(DWX_E_INVALID, "no plan: call dwx_sgd_plan first");
+  s->plan_force_dynamic = on != 0;
+  return DWX_OK;
 }
 
 int dwx_sgd_get_chunks(dwx_sampler *s, uint64_t *chunk_off) {
@@ -1406,13 +1495,16 @@ int dwx_device_buffer(dwx_sampler *s, int which, void **dev_ptr, uint64_t *nbyte
     case DWX_BUF_TSTATIC: {
       auto it = s->levels.find(1);
       *dev_ptr = it == s->levels.end() ? nullptr : it->second->d_t_static;
-      *nbytes = c.W * 8;
+      *nbytes = c.W * 16;
       break;
     }
     case DWX_BUF_TSTATIC_PLAN:
       if (!s->plan_valid || !s->plan_level) return fail(DWX_E_INVALID, "no plan: call dwx_sgd_plan first");
-      *dev_ptr = s->plan_level->fast ? s->plan_level->d_t_static : nullptr;
-      *nbytes = s->plan_level->fast ? (uint64_t)s->plan_level->rows * c.W * 8 : 0;
+      {
+        const bool tables = s->plan_level->fast && !(s->plan_batches > 1 && s->plan_force_dynamic);
+        *dev_ptr = tables ? s->plan_level->d_t_static : nullptr;
+        *nbytes = tables ? (uint64_t)s->plan_level->rows * c.W * 16 : 0;
+      }
       break;
     default: return fail(DWX_E_INVALID, "unknown buffer id");
   }

@@ -1770,14 +1770,31 @@ fold_partials_kernel(const long long *partial, uint32_t n_blocks, uint32_t Wp, u
 }
 
 // Batched InferenceResult::update_weight (src/inference_result.h:66-85): apply one
-// mini-batch's accumulated gradient to every non-fixed weight that received updates,
-// then clear the accumulators.  T = dynamic counts (atomics) + static counts (boolean
-// variables of an un-split sweep, precomputed; null when the sweep is split).  `stepsize`
-// is the plan's effective step (dwx_sgd_plan).  Also refreshes the f32 sampling copy of
-// each weight it changes.
+// mini-batch's accumulated gradient to every non-fixed weight that received updates, then
+// clear the accumulators.  T = dynamic counts (atomics) + static counts (boolean variables,
+// precomputed per chunk; null when the plan counts dynamically).
+//
+// The reference applies its T updates of a weight one after the other, each seeing the
+// samples the previous ones already moved: over one batch the weight follows the flow
+//   dw/dtau = -(G(w) + reg * T * w),  tau in [0, stepsize]
+// and therefore never overshoots, however many factors share the weight.  One plain step
+// w -= stepsize * (G + reg T w) does (it diverges once stepsize * curvature > 2).  So the
+// batch is integrated instead: with G linearised around the current weight with slope h[w]
+// (t_hess: the batch's Gershgorin curvature bound of this weight), the flow's
+// end point is
+//   w - s * (G + reg T w),   s = (1 - exp(-c stepsize)) / c,   c = h[w] + reg T.
+// s -> stepsize for c stepsize << 1 (weights with few factors: the reference's own step, to
+// first order w / (1 + reg stepsize)^T - stepsize G), s -> 1 / c for heavily tied weights
+// (the flow has converged within the batch).  L1 (the reference adds reg * (w < 0) per
+// update, not scaled by the step) keeps its form; only the gradient step saturates.
+// Also refreshes the f32 sampling copy of each weight it changes.
+DWX_DEV double saturating_step(double c, double stepsize) {
+  return c > 0.0 ? -expm1(-c * stepsize) / c : stepsize;
+}
 __global__ void __launch_bounds__(BLOCK_THREADS)
 apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *grad,
-             const long long *t_static, uint32_t W, double stepsize, double reg_param, int l2) {
+             const long long *t_static, const long long *t_hess, uint32_t W, double stepsize,
+             double reg_param, int l2) {
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride) {
     const long long G = grad[i], Td = grad[W + i];
@@ -1785,10 +1802,14 @@ apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *gra
     const long long Tn = Td + (t_static ? t_static[i] : 0);
     if (w_fixed[i] || Tn == 0) continue;
     const double Tt = (double)Tn / FIX_SCALE, Gg = (double)G / FIX_SCALE;
+    const double h = t_hess ? (double)t_hess[i] / H_SCALE : 0.0;
     double x = weights[i];
-    if (l2) x *= pow(1.0 / (1.0 + reg_param * stepsize), Tt);
-    else x += reg_param * Tt * (x < 0 ? 1.0 : 0.0);
-    x -= stepsize * Gg;
+    if (l2) {
+      x -= saturating_step(h + reg_param * Tt, stepsize) * (Gg + reg_param * Tt * x);
+    } else {
+      x += reg_param * Tt * (x < 0 ? 1.0 : 0.0);
+      x -= saturating_step(h, stepsize) * Gg;
+    }
     weights[i] = x;
     w32[i] = (float)x;
   }

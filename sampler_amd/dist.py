@@ -41,17 +41,31 @@ class HipEngine:
         self._holder = _CudaArray(ptr, nbytes, "<i8", 8)
         self.grad = torch.as_tensor(self._holder, device=dev)
         # [G | T]: dynamic update counts T only exist for categorical variables (boolean
-        # counts are static, t_static), so an all-boolean graph reduces the G half only
-        W = sampler.W
-        self.grad_reduced = self.grad if sampler.graph.info.has_categorical else self.grad[:W]
+        # counts are static, t_static), so an all-boolean graph reduces the G half only.  That
+        # is a property of the WHOLE graph, not of this shard: agree() settles it (until then
+        # the full vector travels, which is always correct)
+        self.has_categorical = bool(sampler.graph.info.has_categorical)
+        self.grad_reduced = self.grad
         tp, tn = sampler.device_buffer(dwx.BUF_TSTATIC)
         self._tholder = _CudaArray(tp, tn, "<i8", 8)
         self.t_static = torch.as_tensor(self._tholder, device=dev)
         self.stream = torch.cuda.ExternalStream(sampler.stream(), device=dev)
         self._plan_batches, self._dynamic_counts, self._shared_levels = 1, False, set()
+        self._level_dynamic = {}      # batches -> agreed "some rank counts dynamically"
+
+    def agree(self, group=None):
+        """Once after create: what every rank must decide alike.  A shard without categorical
+        variables next to one with them (DeepDive numbers variables per relation: categoricals
+        are contiguous) would otherwise reduce W elements against the other's 2 W."""
+        t = torch.tensor([int(self.has_categorical)], dtype=torch.int32, device=self.grad.device)
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        self.has_categorical = bool(int(t[0]))
+        self.grad_reduced = self.grad if self.has_categorical else self.grad[:self.s.W]
 
     def allreduce_static_counts(self, group=None):
-        """Once after create: every rank only counted its own shard's boolean updates."""
+        """Once after create: every rank only counted its own shard's boolean updates and
+        curvature bounds ([T | h], both fixed point: the sum does not depend on the order)."""
         with torch.cuda.stream(self.stream):
             dist.all_reduce(self.t_static, op=dist.ReduceOp.SUM, group=group)
 
@@ -62,8 +76,28 @@ class HipEngine:
         # see share_plan_static_counts) or counts dynamically into the T half of the gradient
         # vector, which then has to travel with every all-reduce
         self._plan_batches = batches
-        self._dynamic_counts = batches > 1 and self.s.device_buffer(dwx.BUF_TSTATIC_PLAN)[1] == 0
+        self._local_dynamic = batches > 1 and self.s.device_buffer(dwx.BUF_TSTATIC_PLAN)[1] == 0
+        # (until agree_level ran for this batch count only this rank's view is known)
+        self._dynamic_counts = self._level_dynamic.get(batches, self._local_dynamic)
+        if batches > 1 and self._dynamic_counts and not self._local_dynamic:
+            self.s.sgd_plan_force_dynamic(True)    # another rank has no tables: count like it does
         return batches, n_chunks, eta
+
+    def agree_level(self, group=None):
+        """Once per batch count of a split plan, right after sgd_plan: ranks whose chunk counts
+        differ (other colourings) may disagree on whether the level has per-chunk tables; if ANY
+        rank counts dynamically, all do -- the all-reduced vector must be the same [G | T]
+        everywhere and the counts of dynamic ranks must reach the others."""
+        b = self._plan_batches
+        if b <= 1 or b in self._level_dynamic:
+            return
+        t = torch.tensor([int(self._local_dynamic)], dtype=torch.int32, device=self.grad.device)
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        self._level_dynamic[b] = bool(int(t[0]))
+        self._dynamic_counts = self._level_dynamic[b]
+        if self._dynamic_counts and not self._local_dynamic:
+            self.s.sgd_plan_force_dynamic(True)
 
     @property
     def step_cap(self):
@@ -235,6 +269,8 @@ class ShardedDimmWitted:
         self._level_chunks = {}    # batches -> chunk count of the slowest rank (agreed once)
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         if self.distributed:
+            if hasattr(self.e, "agree"):
+                self.e.agree(group)
             self.e.allreduce_static_counts(group)
         if self.halo is not None:
             self.halo.exchange(("free", "evid"))   # ghosts start from their owners' state
@@ -299,11 +335,9 @@ class ShardedDimmWitted:
                 batches *= 2
             while batches < limit and stepsize * self._global_curvature(batches, world) > cap:
                 batches *= 2
-            lam = self._global_curvature(batches, world)
-            if stepsize * lam > cap:
-                eta = cap / lam            # even the finest cut is too coarse: shrink the step
-        # this rank's plan with the common batch count; its own step bound cannot bind
-        # (local curvature <= global / world), so every rank applies the same eta
+        # this rank's plan with the common batch count.  The step itself is never shortened:
+        # every weight's step saturates at the inverse of its own (all-reduced) curvature bound
+        # (dwx_sgd_apply_async), identically on every rank
         if batches not in self._level_chunks:
             # first use of this batch count: agree on the slowest rank's chunk count and share
             # the static-count tables -- for this level AND the coarser ones the decaying step
@@ -321,6 +355,8 @@ class ShardedDimmWitted:
                         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
                         n_all = int(t[0])
                     self._level_chunks[b] = n_all
+                    if self.distributed and b > 1 and hasattr(self.e, "agree_level"):
+                        self.e.agree_level(self.group)
                     if self.distributed and b > 1 and hasattr(self.e, "share_plan_static_counts"):
                         self.e.share_plan_static_counts(n_all, self.group)
                 b //= 2

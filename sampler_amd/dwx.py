@@ -25,7 +25,7 @@ SYMBOLS = [
     "dwx_graph_create", "dwx_graph_destroy", "dwx_graph_get_info", "dwx_graph_get_schedule",
     "dwx_graph_get_values", "dwx_graph_get_positions", "dwx_graph_get_index",
     "dwx_sampler_create", "dwx_device_init", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
-    "dwx_wait", "dwx_sgd_plan", "dwx_sgd_curvature", "dwx_sgd_plan_rows", "dwx_sgd_get_chunks", "dwx_sgd_accumulate_async",
+    "dwx_wait", "dwx_sgd_plan", "dwx_sgd_curvature", "dwx_sgd_plan_rows", "dwx_sgd_plan_force_dynamic", "dwx_sgd_get_chunks", "dwx_sgd_accumulate_async",
     "dwx_sgd_apply_async", "dwx_sgd_finish",
     "dwx_get_weights", "dwx_set_weights", "dwx_average_weights_async",
     "dwx_clear_tallies", "dwx_get_tallies",
@@ -94,6 +94,7 @@ class Library:
         L.dwx_sgd_plan.argtypes = [vp, dbl, C.c_uint32, vp, vp, vp]
         L.dwx_sgd_plan_rows.argtypes = [vp, C.c_uint32]
         L.dwx_sgd_curvature.argtypes = [vp, C.c_uint32, vp]
+        L.dwx_sgd_plan_force_dynamic.argtypes = [vp, i32]
         L.dwx_sgd_get_chunks.argtypes = [vp, vp]
         L.dwx_sgd_accumulate_async.argtypes = [vp, C.c_uint32]
         L.dwx_sgd_apply_async.argtypes = [vp]
@@ -240,6 +241,9 @@ class GibbsSampler:
 
     def sgd_plan_rows(self, n_rows):
         self.lib.check(self.lib.L.dwx_sgd_plan_rows(self.h, int(n_rows)))
+
+    def sgd_plan_force_dynamic(self, on=True):
+        self.lib.check(self.lib.L.dwx_sgd_plan_force_dynamic(self.h, int(bool(on))))
 
     def sgd_chunks(self, n_chunks):
         off = np.zeros(n_chunks + 1, np.uint64)

@@ -139,6 +139,26 @@ def cfg3c(V=10_000_000, n_weights=None, seed=1234):
         w_initial_value=np.zeros(W), w_is_fixed=np.zeros(W, np.uint8))
 
 
+def tied(n_evid=100_000, n_query=1_000, n_weights=1, seed=7, p_one=(0.7, 0.3, 0.9, 0.5)):
+    """Heavily tied weights, the usual DeepDive shape (one weight per rule, many groundings):
+    boolean variables with ONE unary ISTRUE factor each on weight (v mod n_weights); the first
+    n_evid are evidence with value ~ Bernoulli(p_one[weight]), the rest query.  The maximum-
+    likelihood weight of rule j is logit(p_one[j]) / 2 (P(x = 1) = sigmoid(2 w))."""
+    V = n_evid + n_query
+    rng = _rng(seed, 0)
+    wid = (np.arange(V) % n_weights).astype(np.uint64)
+    p = np.asarray(p_one, float)[wid.astype(np.int64) % len(p_one)]
+    role = np.zeros(V, np.uint8); role[:n_evid] = 1
+    val = ((rng.random(V) < p) & (role == 1)).astype(np.uint64)
+    return RawGraph(
+        var_role=role, var_init_value=val,
+        var_dtype=np.full(V, DTYPE_BOOLEAN, np.uint16), var_cardinality=np.full(V, 2, np.uint64),
+        fac_func=np.full(V, FUNC_ISTRUE, np.uint16), fac_edge_offset=np.arange(V + 1, dtype=np.uint64),
+        fac_weight_id=wid, fac_feature_value=np.ones(V),
+        edge_vid=np.arange(V, dtype=np.uint64), edge_equal_to=np.ones(V, np.uint64),
+        w_initial_value=np.zeros(n_weights), w_is_fixed=np.zeros(n_weights, np.uint8))
+
+
 def cfg4(V=5_000_000, card=8, seed=1234, learn=False, shard=0):
     """Config 4: V categorical variables of cardinality `card` (implicit dense domain),
     one unary AND_CATEGORICAL factor per (v, d) with weight id d (the

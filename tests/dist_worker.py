@@ -74,7 +74,7 @@ class OracleEngine:
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
     def sgd_apply(self):
-        self.o.sched_apply(self.eta, 0.0)
+        self.o.sched_apply(self.eta)
 
     def sample(self):
         self.o.sched_sample(self.order, self.off, self.seed, self.sweep)

@@ -166,6 +166,69 @@ def synth_goldens():
               sort_keys=True)
 
 
+TIED_CASES = {
+    # name: (generator call, sampler flags, learning-epoch counts)
+    "tied_one": ("tied(100000, 1000, 1, seed=7)",
+                 ["--alpha", "0.01", "--diminish", "0.95", "--reg_param", "0.01"], [1, 2, 5, 20, 60]),
+    "tied_three": ("tied(60000, 600, 3, seed=8)",
+                   ["--alpha", "0.01", "--diminish", "0.95", "--reg_param", "0.01"], [1, 2, 5, 20, 60]),
+    "tied_cfg4learn": ("cfg4(20000, card=8, seed=1234, learn=True)",
+                       ["--alpha", "0.001", "--diminish", "0.95", "--reg_param", "0.01"], [1, 2, 5, 10]),
+    "tied_cfg4learn_bigstep": ("cfg4(20000, card=8, seed=1234, learn=True)",
+                               ["--alpha", "0.01", "--diminish", "0.95", "--reg_param", "0.01"], [1, 5, 10, 40]),
+}
+TIED_ROTATIONS = 6
+TIED_THREADS = 4
+
+
+def rotate_variables(g, shift):
+    """The same factor graph with variable ids rotated by `shift` (an isomorphic relabelling:
+    the model and its weights are unchanged, but the reference -- whose seeds come from an
+    un-seeded rand() and cannot be set -- now spends its random streams on other variables)."""
+    import numpy as np
+    from sampler_amd.rawgraph import RawGraph
+    V = g.num_variables
+    new_of_old = (np.arange(V, dtype=np.uint64) + np.uint64(shift)) % np.uint64(V)
+    old_of_new = np.empty(V, np.int64)
+    old_of_new[new_of_old.astype(np.int64)] = np.arange(V)
+    return RawGraph(
+        var_role=g.var_role[old_of_new], var_init_value=g.var_init_value[old_of_new],
+        var_dtype=g.var_dtype[old_of_new], var_cardinality=g.var_cardinality[old_of_new],
+        fac_func=g.fac_func, fac_edge_offset=g.fac_edge_offset, fac_weight_id=g.fac_weight_id,
+        fac_feature_value=g.fac_feature_value, edge_vid=new_of_old[g.edge_vid.astype(np.int64)],
+        edge_equal_to=g.edge_equal_to, w_initial_value=g.w_initial_value, w_is_fixed=g.w_is_fixed)
+
+
+def tied_goldens():
+    """Learned weights of the reference on graphs whose weights are tied to 10^4..10^5 factors
+    (one weight per rule, the DeepDive shape), at SEVERAL epoch counts, each on six rotations
+    of the variable ids: the reference's seeds cannot be set (un-seeded rand()), and runs that
+    differ only in the thread count share the stream of worker 0 -- relabelled graphs are the
+    same model with independent noise, i.e. the reference's run-to-run spread.  The device's
+    batched update is checked against that spread at equal epochs
+    (tests/test_tied_weights.py).  Data only: tests/golden/tied_weights.json."""
+    sys.path.insert(0, ROOT)
+    import json
+    from sampler_amd import synthetic, binary_format  # noqa: F401
+    out = {}
+    for name, (call, flags, epochs) in TIED_CASES.items():
+        g0 = eval("synthetic." + call)
+        runs = {str(L): [] for L in epochs}
+        for j in range(TIED_ROTATIONS):
+            g = rotate_variables(g0, j * (g0.num_variables // TIED_ROTATIONS) + 7919 * j)
+            with tempfile.TemporaryDirectory() as d:
+                binary_format.write_graph(g, d)
+                for L in epochs:
+                    with tempfile.TemporaryDirectory() as o:
+                        run_ref(d, ["-l", str(L), "-i", "0", "-t", str(TIED_THREADS), "-c", "1"] + flags, o)
+                        runs[str(L)].append([float(l.split()[1]) for l in
+                                             open(os.path.join(o, "inference_result.out.weights.text"))])
+        out[name] = {"generator": call, "flags": flags, "threads": TIED_THREADS,
+                     "rotations": TIED_ROTATIONS, "weights": runs}
+        print("golden:", name)
+    json.dump(out, open(os.path.join(HERE, "tied_weights.json"), "w"), indent=1, sort_keys=True)
+
+
 def codec_goldens():
     """The reference's text2bin codec fixtures (test/text2bin/: TSV inputs and xxd dumps of
     the expected big-endian bytes) -- data files of the reference's tests."""
@@ -191,3 +254,5 @@ if __name__ == "__main__":
     if "synth" in which:
         synth_goldens()
         print("golden: synthetic")
+    if "tied" in which:
+        tied_goldens()

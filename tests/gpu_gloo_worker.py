@@ -27,8 +27,9 @@ class RecordingEngine(HipEngine):
         self.record = []
 
     def sgd_plan(self, stepsize, force_batches=0):
-        self._last = super().sgd_plan(stepsize, force_batches)
-        return self._last
+        r = super().sgd_plan(stepsize, force_batches)
+        self._last = (r[0], r[1], stepsize)     # (the third value returned is a diagnostic: the
+        return r                                 #  smallest saturated step, not the step applied)
 
     def sgd_finish(self):
         batches, n_mine, eta = self._last

@@ -62,7 +62,7 @@ class OracleShardEngine:
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
     def sgd_apply(self):
-        self.o.sched_apply(self.eta, 0.0)
+        self.o.sched_apply(self.eta)
 
     def sample(self):
         self._prep()

@@ -42,14 +42,19 @@ def learn_sweep_both(s, o, order, seed, sweep, stepsize):
     """One learning sweep on the device and, mirrored, on the oracle: the device cuts a
     sweep into mini-batches (dwx_sgd_plan); the oracle follows the same chunk boundaries --
     accumulate over each chunk's variables, apply where the device applies."""
-    batches, n_chunks, eta = s.sgd_plan(stepsize)
+    batches, n_chunks, _ = s.sgd_plan(stepsize)
     chunk_off = s.sgd_chunks(n_chunks)
+    # a split plan without per-chunk tables (more chunks than the table limit) applies every
+    # chunk with the curvature bounds of the whole sweep
+    hess = None
+    if batches > 1 and s.device_buffer(dwx.BUF_TSTATIC_PLAN)[1] == 0:
+        hess = o.sched_curvature(order)
     s.sample_sgd(stepsize); s.wait()
     for c in range(n_chunks):
         sl = order[int(chunk_off[c]):int(chunk_off[c + 1])]
         o.sched_accumulate(sl, np.array([0, len(sl)], np.uint64), seed, sweep)
         if batches > 1 or c + 1 == n_chunks:
-            o.sched_apply(eta, 0.0)
+            o.sched_apply(stepsize, hess)
     return batches
 
 

@@ -19,7 +19,7 @@ from sampler_amd.dist import ReplicatedDimmWitted  # noqa: E402
 
 class ReplicaOracleEngine(OracleEngine):
     def sample_sgd(self, stepsize):
-        self.o.sched_sample_sgd(self.order, self.off, self.seed, self.sweep, stepsize, 0.0)
+        self.o.sched_sample_sgd(self.order, self.off, self.seed, self.sweep, stepsize)
         self.sweep += 1
 
     def clear_tallies(self):

@@ -68,7 +68,7 @@ def test_two_rank_sharded_learning_equals_single_process():
     off = np.array([0, union.num_variables], np.uint64)
     sweep, cur = 0, 0.05
     for _ in range(6):
-        o.sched_sample_sgd(order, off, 4242, sweep, cur, 0.0); sweep += 1; cur *= 0.9
+        o.sched_sample_sgd(order, off, 4242, sweep, cur); sweep += 1; cur *= 0.9
     o.clear_tallies()
     for _ in range(4):
         o.sched_sample(order, off, 4242, sweep); sweep += 1
@@ -131,7 +131,7 @@ def test_two_rank_split_sweeps_agree_on_the_plan_and_match_single_process():
             sl = np.concatenate(parts)
             o.sched_accumulate(sl, np.array([0, len(sl)], np.uint64), 4242, sweep)
             if split or c + 1 == n_chunks:
-                o.sched_apply(cur, 0.0)
+                o.sched_apply(cur)
         sweep += 1; cur *= 0.9
     assert 0 < n_split < 6                 # both regimes and the transition were exercised
     o.clear_tallies()
@@ -179,7 +179,7 @@ def test_two_rank_replicas_average_weights_like_n_datacopy():
     sweep, cur = 0, 0.05
     for _ in range(4):
         for r, o in enumerate(os_):
-            o.sched_sample_sgd(order, off, 900 + r, sweep, cur, 0.0)
+            o.sched_sample_sgd(order, off, 900 + r, sweep, cur)
         avg = np.where(fixed, os_[0].weights, (os_[0].weights + os_[1].weights) / 2)
         for o in os_:
             o.weights[:] = avg

@@ -113,6 +113,34 @@ def test_dw_argument_errors(dw_emu):
         assert r.returncode != 0 and "variable count" in r.stderr
 
 
+@pytest.mark.parametrize("asan", [False, True])
+def test_dw_loader_rejects_meta_with_too_few_edges_or_factors(dw_emu, asan):
+    """graph.meta announcing fewer edges / factors than the factor file holds: the parallel
+    fixed-stride parse must refuse before any piece writes past the columns (it
+    used to segfault with several host threads).  Run plain and under ASan/UBSan."""
+    from sampler_amd import synthetic
+    raw = synthetic.cfg3(30_000, n_weights=300, seed=5)        # 300 000 records: 5 pieces
+    binary = os.path.join(os.path.dirname(dw_emu), "dw_emu_asan") if asan else dw_emu
+    env = dict(os.environ, DWX_HOST_THREADS="8",
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    with tempfile.TemporaryDirectory() as d:
+        binary_format.write_graph(raw, d)
+        W, V, F, E = open(os.path.join(d, "graph.meta")).read().strip().split(",")[:4]
+        base = [binary, "bin2text", "-w", os.path.join(d, "graph.weights"), "-v", os.path.join(d, "graph.variables"),
+                "-f", os.path.join(d, "graph.factors"), "-o", d]
+        for meta, needle in (("%s,%s,%s,10" % (W, V, F), "edge count"),
+                             ("%s,%s,70000,%s" % (W, V, E), "factor count"),
+                             ("%s,%s,10,10" % (W, V), "count")):
+            m = os.path.join(d, "bad.meta")
+            open(m, "w").write(meta)
+            r = subprocess.run(base + ["-m", m], capture_output=True, text=True, env=env)
+            assert r.returncode == 1, (meta, r.returncode, r.stderr[-2000:])
+            assert needle in r.stderr and "!= meta" in r.stderr, r.stderr[-2000:]
+        # and the untouched meta still loads
+        r = subprocess.run(base + ["-m", os.path.join(d, "graph.meta")], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_product_dw_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -71,7 +71,7 @@ def test_two_ranks_share_one_gpu_over_gloo(stepsize):
             sl = np.concatenate(parts)
             o.sched_accumulate(sl, np.array([0, len(sl)], np.uint64), 4242, sweep)
             if batches > 1 or c + 1 == n_chunks:
-                o.sched_apply(eta, 0.0)
+                o.sched_apply(eta)
         sweep += 1
     np.testing.assert_allclose(res[0]["weights"], o.weights, rtol=1e-12, atol=1e-12)
     assert np.abs(o.weights).max() > 0

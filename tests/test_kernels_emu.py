@@ -212,7 +212,8 @@ def test_split_sweep_parity_and_heavy_tying_learns_like_the_reference(lib):
     batches, n_chunks, eta = s.sgd_plan(0.01)
     # (cuts balance the SGD work: the query tiles, which learn nothing, ride along with the
     # first evidence chunk, so there can be fewer chunks than requested batches)
-    assert batches >= 8 and 8 <= n_chunks <= batches and 0.005 < eta <= 0.01
+    # (eta: the smallest step any weight takes -- this much tying saturates it below 0.01)
+    assert batches >= 8 and 8 <= n_chunks <= batches and 0.002 < eta < 0.01
     assert s.sgd_plan(1e-5)[0] == 1                      # tiny step: no split
     dwx.DimmWitted(s, 30, 0, 0.01, 0.95).learn()
     ref = orc.Oracle(raw, reg_param=0.01)
@@ -221,9 +222,13 @@ def test_split_sweep_parity_and_heavy_tying_learns_like_the_reference(lib):
     w, wr = s.weights, ref.weights
     assert abs(w.mean() - wr.mean()) < 0.01 and abs(w.std() - wr.std()) < 0.015, (w.mean(), wr.mean())
     assert np.corrcoef(w, wr)[0, 1] > 0.6
-    # with splitting disabled (step_cap <= 0) the same run drifts far away
+    # with splitting disabled (step_cap <= 0) every sweep is one batch; the saturating step
+    # keeps even that stable (a plain batched step of this size learns mean weight 0.3)
     s1 = dwx.GibbsSampler(g, seed=5, reg_param=0.01, step_cap=0.0)
     assert s1.sgd_plan(0.01)[0] == 1
+    dwx.DimmWitted(s1, 30, 0, 0.01, 0.95).learn()
+    w1 = s1.weights
+    assert np.isfinite(w1).all() and abs(w1.mean() - wr.mean()) < 0.03, (w1.mean(), wr.mean())
 
 
 def test_replica_weight_averaging(lib):
@@ -276,7 +281,7 @@ def test_split_sweep_with_pull_tiles_and_static_counts(lib, monkeypatch):
                compile_opts=dict(tile_vars=64))
     run_parity(lib, random_graph(8, V=1500, F=9000, W=1300, p_cat=0.3), n_learn=4, n_infer=2, stepsize=0.2,
                learn_non_evidence=True, compile_opts=dict(tile_vars=32))
-    # never more than 64 batches per launch: beyond that the step is shortened
+    # never more than 64 batches per launch; an absurd step just saturates
     s2 = dwx.GibbsSampler(dwx.Graph(raw, lib=lib, tile_vars=16), seed=3)
     b2, n2, eta2 = s2.sgd_plan(5.0)
     assert b2 == 64 and n2 <= 64 and eta2 < 5.0
