@@ -56,7 +56,9 @@ typedef struct dwx_graph_desc {
   const uint16_t *fac_func;        /* FACTOR_FUNCTION_TYPE (src/common.h:35-48)   */
   const uint64_t *fac_edge_offset; /* [num_factors+1]                             */
   const uint64_t *fac_weight_id;
-  const double *fac_feature_value;
+  const double *fac_feature_value; /* finite; |value| <= 65536 on a learnable weight (DWX_E_LIMIT
+                                      beyond: gradients are summed in 2^-30 fixed point, int64);
+                                      |value| below ~5e-10 contributes no gradient            */
   const uint64_t *edge_vid;
   const uint64_t *edge_equal_to;   /* equalPredicate as in the file               */
   const double *w_initial_value;   /* indexed by weight id                        */
@@ -271,6 +273,13 @@ int dwx_kernel_time_reset(dwx_sampler *s, int enable);
 /* Test hook: evaluate one factor function on the device.  sat[i] = whether the
  * predicate of position i holds; mirrors test/factor_test.cc's truth tables. */
 int dwx_test_factor_sign(int device, int func, uint64_t arity, const uint8_t *sat, double *out);
+/* Test hook: the device's random number generator (the reference draws with erand48,
+ * src/gibbs_sampler.h:177,204,230; the device with the counter-based Philox4x32-10 of Salmon
+ * et al., SC'11).  out = philox(key, ctr), the raw block function (Random123's known-answer
+ * vectors apply); uniforms = the two 53-bit uniforms the sweep kernels draw for
+ * (seed = key, variable id = ctr[0..1], sweep = ctr[2..3]). */
+int dwx_test_philox(int device, const uint32_t key[2], const uint32_t ctr[4], uint32_t out[4],
+                    double uniforms[2]);
 
 #ifdef __cplusplus
 }

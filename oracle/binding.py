@@ -75,6 +75,7 @@ def lib():
         L.orc_sched_check_independent.restype = i32
         L.orc_sched_check_independent.argtypes = [vp, vp]
         L.orc_philox_uniforms.argtypes = [u64, u64, u64, vp]
+        L.orc_philox4x32_10.argtypes = [vp, vp]; L.orc_philox4x32_10.restype = None
         _lib = L
     return _lib
 
@@ -275,6 +276,14 @@ def factor_sign(func, sat):
 def erand48_seq(seed, n):
     x = (C.c_uint16 * 3)(*seed)
     return [lib().orc_erand48(C.addressof(x)) for _ in range(n)]
+
+
+def philox4x32_10(key, ctr):
+    """Raw Philox4x32-10 block: (key[2], ctr[4]) -> out[4] (uint32)."""
+    k = np.ascontiguousarray(key, np.uint32)
+    c = np.array(ctr, np.uint32)
+    lib().orc_philox4x32_10(k.ctypes.data, c.ctypes.data)
+    return c
 
 
 def philox_uniforms(seed, vid, sweep):

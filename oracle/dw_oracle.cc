@@ -645,6 +645,8 @@ extern "C" double orc_factor_sign(int func, uint64_t arity, const uint8_t *satbi
 }
 extern "C" double orc_logadd(double a, double b) { return logadd(a, b); }
 extern "C" double orc_erand48(uint16_t x[3]) { return erand48_step(x); }
+// raw block function, for the Random123 known-answer vectors (tests/test_philox_kat.py)
+extern "C" void orc_philox4x32_10(const uint32_t key[2], uint32_t ctr[4]) { philox4x32_10(key[0], key[1], ctr); }
 extern "C" void orc_philox_uniforms(uint64_t seed, uint64_t vid, uint64_t sweep, double out[2]) {
   philox_uniforms(seed, vid, sweep, out[0], out[1]);
 }

@@ -138,6 +138,8 @@ void orc_set_sampling_weight_f32(orc_sampler *s, int on);
 /* returns 1 if every launch of the schedule is an independent set */
 int orc_sched_check_independent(orc_sampler *s, const orc_schedule *sch);
 /* two uniforms in [0,1) from Philox4x32-10 (test hook) */
+/* Philox4x32-10 block function in place: ctr <- philox(key, ctr) (Random123 KATs) */
+void orc_philox4x32_10(const uint32_t key[2], uint32_t ctr[4]);
 void orc_philox_uniforms(uint64_t seed, uint64_t vid, uint64_t sweep, double out[2]);
 
 #ifdef __cplusplus

@@ -613,6 +613,11 @@ int gibbs(const CmdLine &args) {
     for (uint64_t e = 0; e < args.n_learning_epoch; ++e) {
       if (progress) std::cout << std::setprecision(3) << "LEARNING EPOCH " << e << "~" << e << "...." << std::flush;
       double t0 = now();
+      // the plan this sweep will run with (cached in the library; dwx_sample_sgd_async makes the
+      // same one): reported below whenever it differs from "one batch, the step as given"
+      uint32_t plan_batches = 1, plan_chunks = 1;
+      double plan_min_step = stepsize;
+      if (progress) ok(dwx_sgd_plan(sampler, stepsize, 0, &plan_batches, &plan_chunks, &plan_min_step));
       ok(dwx_sample_sgd_async(sampler, stepsize));
       ok(dwx_wait(sampler));
       double elapsed = now() - t0;
@@ -628,7 +633,12 @@ int gibbs(const CmdLine &args) {
         lmax /= stepsize;
         std::cout << std::setprecision(3) << "" << elapsed << " sec." << "," << V / elapsed
                   << " vars/sec." << ",stepsize=" << stepsize << ",lmax=" << lmax
-                  << ",l2=" << sqrt(l2) / stepsize << std::endl << std::setprecision(6);
+                  << ",l2=" << sqrt(l2) / stepsize;
+        // (this build's addition) mini-batches per sweep and the smallest step any weight took:
+        // heavily tied weights saturate below the requested step (include/dwx.h, dwx_sgd_plan)
+        if (plan_batches > 1 || plan_min_step < 0.999 * stepsize)
+          std::cout << ",batches=" << plan_batches << ",min_step=" << plan_min_step;
+        std::cout << std::endl << std::setprecision(6);
         prev = weights;
       }
       stepsize *= args.decay;

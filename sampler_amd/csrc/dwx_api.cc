@@ -1538,6 +1538,23 @@ int dwx_kernel_time(dwx_sampler *s, int kind, double *ms, uint64_t *launches, ui
   });
 }
 
+int dwx_test_philox(int device, const uint32_t key[2], const uint32_t ctr[4], uint32_t out[4], double uniforms[2]) {
+  if (!key || !ctr || !out || !uniforms) return fail(DWX_E_INVALID, "null argument");
+  return guarded([&]() {
+    rt::init_device(device);
+    rt::stream_t st = rt::stream_create();
+    uint32_t *dout = (uint32_t *)rt::dmalloc(8 * 4);
+    double *duni = (double *)rt::dmalloc(16);
+    rt::h2d(dout + 4, ctr, 16, st);     // (the counter again, for the uniforms' entry point)
+    rt::launch(test_philox_kernel, 1, 64, 0, st, key[0], key[1], ctr[0], ctr[1], ctr[2], ctr[3], dout, duni);
+    rt::d2h(out, dout, 16, st);
+    rt::d2h(uniforms, duni, 16, st);
+    rt::stream_sync(st);
+    rt::dfree(dout); rt::dfree(duni);
+    rt::stream_destroy(st);
+  });
+}
+
 int dwx_test_factor_sign(int device, int func, uint64_t arity, const uint8_t *sat, double *out) {
   if (!sat || !out || arity == 0 || arity > 4096) return fail(DWX_E_INVALID, "bad argument");
   return guarded([&]() {

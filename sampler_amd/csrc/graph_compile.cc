@@ -185,6 +185,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     // ---- factors: dense predicates + per-variable back-refs
     //      (src/binary_format.cc:128-190) ----
     RawArray<uint32_t> edge_dense(E);   // (every entry is written by the parallel pass below)
+    constexpr double kMaxLearnFeature = 65536.0;
     parallel_ranges(F, nth, [&](uint64_t fb, uint64_t fe) {
       for (uint64_t f = fb; f < fe; ++f) {
         uint64_t lo = d.fac_edge_offset[f], hi = d.fac_edge_offset[f + 1];
@@ -193,6 +194,17 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
         if (!known_func(d.fac_func[f]))
           throw std::runtime_error("Unsupported FACTOR_FUNCTION_TYPE = " + std::to_string(d.fac_func[f]));
         if (d.fac_weight_id[f] >= W) throw std::runtime_error("factor references unknown weight");
+        // the gradient of a learnable weight is summed in fixed point (2^-30, int64: exact,
+        // order-independent, all-reducible): a feature value beyond 2^16 could overflow the sum
+        // of a heavily tied weight, a non-finite one has no meaning at all
+        {
+          const double fv = d.fac_feature_value[f];
+          if (!(fv == fv) || fv > 1.7e308 || fv < -1.7e308)
+            throw std::runtime_error("feature value of factor " + std::to_string(f) + " is not finite");
+          if (!d.w_is_fixed[d.fac_weight_id[f]] && (fv > kMaxLearnFeature || fv < -kMaxLearnFeature))
+            throw LimitError("feature value of factor " + std::to_string(f) +
+                             " exceeds 65536 on a learnable weight (fixed-point gradient range)");
+        }
         for (uint64_t e = lo; e < hi; ++e) {
           const uint64_t vid = d.edge_vid[e];
           if (vid >= V) throw std::runtime_error("factor references unknown variable");

@@ -1895,6 +1895,19 @@ average_weights_kernel(double *weights, float *w32, const uint8_t *w_fixed, cons
   }
 }
 
+// test hook: the raw Philox4x32-10 block function and the two uniforms drawn from it, on the
+// device (Random123 known-answer vectors; tests/test_philox_kat.py)
+__global__ void test_philox_kernel(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                   uint32_t *out, double *uni) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    philox4x32_10(k0, k1, c0, c1, c2, c3);
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    // the same block through the sampler's own entry point: seed = key, counter = (vid, sweep)
+    philox_uniforms((uint64_t)k0 | ((uint64_t)k1 << 32), (uint64_t)out[4] | ((uint64_t)out[5] << 32),
+                    (uint64_t)out[6] | ((uint64_t)out[7] << 32), uni[0], uni[1]);
+  }
+}
+
 // test hook: one factor function evaluated on the device (test/factor_test.cc)
 __global__ void test_sign_kernel(uint32_t func, uint32_t arity, const VifRec *vifs,
                                  const uint32_t *assign, double *out) {

@@ -31,7 +31,7 @@ SYMBOLS = [
     "dwx_clear_tallies", "dwx_get_tallies",
     "dwx_get_assignments", "dwx_set_assignments", "dwx_get_sweep", "dwx_set_sweep",
     "dwx_device_buffer", "dwx_stream", "dwx_kernel_time", "dwx_kernel_time_reset",
-    "dwx_test_factor_sign",
+    "dwx_test_factor_sign", "dwx_test_philox",
 ]
 
 
@@ -111,10 +111,18 @@ class Library:
         L.dwx_kernel_time.argtypes = [vp, i32, vp, vp, vp]
         L.dwx_kernel_time_reset.argtypes = [vp, i32]
         L.dwx_test_factor_sign.argtypes = [i32, i32, u64, vp, vp]
+        L.dwx_test_philox.argtypes = [i32, vp, vp, vp, vp]
 
     def check(self, rc):
         if rc != DWX_OK:
             raise DwxError(rc, self.L.dwx_last_error().decode(errors="replace"))
+
+    def test_philox(self, key, ctr, device=0):
+        """-> (philox4x32-10(key, ctr) as uint32[4], the sweep kernels' two uniforms)."""
+        k, c = np.ascontiguousarray(key, np.uint32), np.ascontiguousarray(ctr, np.uint32)
+        out, uni = np.zeros(4, np.uint32), np.zeros(2, np.float64)
+        self.check(self.L.dwx_test_philox(device, k.ctypes.data, c.ctypes.data, out.ctypes.data, uni.ctypes.data))
+        return out, uni
 
     def test_factor_sign(self, func, sat, device=0):
         sat = np.ascontiguousarray(sat, np.uint8)

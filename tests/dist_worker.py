@@ -84,8 +84,17 @@ class OracleEngine:
         pass
 
 
-def shard_graph(total_vars, n_weights, rank, world, seed):
+def shard_graph(total_vars, n_weights, rank, world, seed, mixed=False):
+    """mixed: the odd ranks' blocks hold CATEGORICAL variables only (cardinality 8, one unary
+    factor per value on weights 0..7 of the shared table), the even ranks' boolean ones --
+    DeepDive numbers variables per relation, so a variable-block shard can easily have no
+    categorical variable while its neighbour has nothing else."""
     b, e = shard_range(total_vars, rank, world)
+    if mixed and rank % 2 == 1:
+        g = synthetic.cfg4(e - b, card=8, seed=seed, learn=True, shard=rank)
+        g.w_initial_value = np.zeros(n_weights)
+        g.w_is_fixed = np.zeros(n_weights, np.uint8)
+        return g, b
     return synthetic.cfg3(e - b, n_weights=n_weights, seed=seed, shard=rank), b
 
 
@@ -94,7 +103,7 @@ def main():
     out = sys.argv[1]
     total, W, seed = int(sys.argv[2]), int(sys.argv[3]), 4242
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    raw, begin = shard_graph(total, W, rank, world, 1234)
+    raw, begin = shard_graph(total, W, rank, world, 1234, mixed=os.environ.get("DWX_TEST_MIXED") == "1")
     split = os.environ.get("DWX_TEST_SPLIT_ABOVE")
     eng = OracleEngine(raw, seed, begin, 0.01, split_above=float(split) if split else None,
                        max_chunks=(4, 3)[rank % 2] if split else 1)

@@ -166,6 +166,28 @@ def synth_goldens():
               sort_keys=True)
 
 
+def synth_second_runs():
+    """A SECOND reference run (other thread count: other shards and seeds) of the learning
+    goldens, kept as ref_b.*: learned weights are noisy, so marginals produced by two
+    independent learn+infer runs differ per variable by more than Monte-Carlo error; the
+    distance between the reference's own two runs is the yardstick for this build's distance
+    to the reference (tests/ks_golden.py)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from sampler_amd import binary_format
+    import synth_cases
+    for name in ("synth_cfg3", "synth_cfg3b"):
+        dst = os.path.join(HERE, name)
+        args = open(os.path.join(dst, "dw-args")).read().split()
+        g = synth_cases.load(name)
+        with tempfile.TemporaryDirectory() as d, tempfile.TemporaryDirectory() as out:
+            binary_format.write_graph(g, d)
+            run_ref(d, args + ["-t", "3", "-c", "1"], out)
+            shutil.copy(os.path.join(out, "inference_result.out.weights.text"), os.path.join(dst, "ref_b.weights.text"))
+            shutil.copy(os.path.join(out, "inference_result.out.text"), os.path.join(dst, "ref_b.text"))
+        print("golden:", name, "second run")
+
+
 TIED_CASES = {
     # name: (generator call, sampler flags, learning-epoch counts)
     "tied_one": ("tied(100000, 1000, 1, seed=7)",
@@ -181,24 +203,6 @@ TIED_ROTATIONS = 6
 TIED_THREADS = 4
 
 
-def rotate_variables(g, shift):
-    """The same factor graph with variable ids rotated by `shift` (an isomorphic relabelling:
-    the model and its weights are unchanged, but the reference -- whose seeds come from an
-    un-seeded rand() and cannot be set -- now spends its random streams on other variables)."""
-    import numpy as np
-    from sampler_amd.rawgraph import RawGraph
-    V = g.num_variables
-    new_of_old = (np.arange(V, dtype=np.uint64) + np.uint64(shift)) % np.uint64(V)
-    old_of_new = np.empty(V, np.int64)
-    old_of_new[new_of_old.astype(np.int64)] = np.arange(V)
-    return RawGraph(
-        var_role=g.var_role[old_of_new], var_init_value=g.var_init_value[old_of_new],
-        var_dtype=g.var_dtype[old_of_new], var_cardinality=g.var_cardinality[old_of_new],
-        fac_func=g.fac_func, fac_edge_offset=g.fac_edge_offset, fac_weight_id=g.fac_weight_id,
-        fac_feature_value=g.fac_feature_value, edge_vid=new_of_old[g.edge_vid.astype(np.int64)],
-        edge_equal_to=g.edge_equal_to, w_initial_value=g.w_initial_value, w_is_fixed=g.w_is_fixed)
-
-
 def tied_goldens():
     """Learned weights of the reference on graphs whose weights are tied to 10^4..10^5 factors
     (one weight per rule, the DeepDive shape), at SEVERAL epoch counts, each on six rotations
@@ -210,12 +214,14 @@ def tied_goldens():
     sys.path.insert(0, ROOT)
     import json
     from sampler_amd import synthetic, binary_format  # noqa: F401
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth_cases import rotate_variables, tied_shift
     out = {}
     for name, (call, flags, epochs) in TIED_CASES.items():
         g0 = eval("synthetic." + call)
         runs = {str(L): [] for L in epochs}
         for j in range(TIED_ROTATIONS):
-            g = rotate_variables(g0, j * (g0.num_variables // TIED_ROTATIONS) + 7919 * j)
+            g = rotate_variables(g0, tied_shift(g0.num_variables, j, TIED_ROTATIONS))
             with tempfile.TemporaryDirectory() as d:
                 binary_format.write_graph(g, d)
                 for L in epochs:
@@ -254,5 +260,7 @@ if __name__ == "__main__":
     if "synth" in which:
         synth_goldens()
         print("golden: synthetic")
+    if "synth_b" in which:
+        synth_second_runs()
     if "tied" in which:
         tied_goldens()

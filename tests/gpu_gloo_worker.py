@@ -42,12 +42,17 @@ def main():
     out, total, W, stepsize = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    raw, begin = shard_graph(total, W, rank, world, 1234)
+    mixed = os.environ.get("DWX_TEST_MIXED") == "1"
+    raw, begin = shard_graph(total, W, rank, world, 1234, mixed=mixed)
     g = dwx.Graph(raw, tile_vars=(64, 32)[rank % 2])          # different tilings per rank
+    if mixed:      # the situation under test: this shard's own view differs from the graph's
+        assert bool(g.info.has_categorical) == (rank % 2 == 1)
     s = dwx.GibbsSampler(g, device=0, seed=4242, reg_param=0.01, var_id_offset=begin)
     eng = RecordingEngine(s)
     drv = ShardedDimmWitted(eng, n_learning_epoch=6, n_inference_epoch=3, stepsize=stepsize, decay=0.7)
     assert drv.distributed
+    if mixed:      # ... and the engines agreed on the whole graph's
+        assert eng.has_categorical and eng.grad_reduced.numel() == 2 * W
     drv.learn()
     s.clear_tallies()
     drv.inference()

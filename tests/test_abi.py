@@ -60,6 +60,20 @@ def test_malformed_graphs_are_rejected():
     raw.var_dtype[0] = 2
     with pytest.raises(dwx.DwxError):
         dwx.Graph(raw, lib=lib)
+    # feature values: finite; on a learnable weight within the fixed-point gradient range
+    raw = synthetic.cfg3(10, n_weights=2, seed=1)
+    raw.fac_feature_value[5] = float("nan")
+    with pytest.raises(dwx.DwxError) as e:
+        dwx.Graph(raw, lib=lib)
+    assert e.value.code == dwx.DWX_E_INVALID
+    raw = synthetic.cfg3(10, n_weights=2, seed=1)
+    raw.fac_feature_value[5] = 1e6
+    with pytest.raises(dwx.DwxError) as e:
+        dwx.Graph(raw, lib=lib)
+    assert e.value.code == dwx.DWX_E_LIMIT and "65536" in str(e.value)
+    raw = synthetic.cfg2(10, n_weights=2, seed=1)      # fixed weights: no gradient, no limit
+    raw.fac_feature_value[5] = 1e6
+    dwx.Graph(raw, lib=lib)
 
 
 def test_empty_graph():

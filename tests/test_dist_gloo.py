@@ -10,6 +10,7 @@ import sys
 import tempfile
 
 import numpy as np
+import pytest
 
 from oracle import binding as orc
 from sampler_amd.rawgraph import RawGraph
@@ -43,16 +44,21 @@ def _concat(shards):
                     w_is_fixed=shards[0].w_is_fixed, **cols)
 
 
-def test_two_rank_sharded_learning_equals_single_process():
+@pytest.mark.parametrize("mixed", [False, True])
+def test_two_rank_sharded_learning_equals_single_process(mixed):
+    """mixed: rank 1's block is all categorical, rank 0's all boolean (tests/dist_worker.py)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from dist_worker import shard_graph
+    from dist_worker import shard_graph as _shard_graph
+
+    def shard_graph(*a):
+        return _shard_graph(*a, mixed=mixed)
     total, W, world = 1200, 40, 2
     port = _free_port()
     with tempfile.TemporaryDirectory() as out:
         procs = []
         for r in range(world):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                       MASTER_PORT=str(port), LOCAL_RANK=str(r))
+                       MASTER_PORT=str(port), LOCAL_RANK=str(r), DWX_TEST_MIXED="1" if mixed else "0")
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"),
                                            out, str(total), str(W)], env=env))
         for p in procs:
@@ -74,11 +80,13 @@ def test_two_rank_sharded_learning_equals_single_process():
         o.sched_sample(order, off, 4242, sweep); sweep += 1
     assert np.array_equal(res[0]["weights"], o.weights)
     assert np.abs(o.weights).max() > 0
+    row0 = 0
     for r in range(world):
-        b = int(res[r]["begin"]); n = len(res[r]["free"])
+        b = int(res[r]["begin"]); n = len(res[r]["free"]); rows = len(res[r]["tallies"])
         assert np.array_equal(res[r]["free"], o.assignments("free")[b:b + n])
         assert np.array_equal(res[r]["evid"], o.assignments("evid")[b:b + n])
-        assert np.array_equal(res[r]["tallies"], o.tallies[b:b + n])
+        assert np.array_equal(res[r]["tallies"], o.tallies[row0:row0 + rows])
+        row0 += rows
 
 
 def test_shard_range_covers_everything():

@@ -20,13 +20,17 @@ def test_hip_engine_rccl_plumbing_world_size_1():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("stepsize", [0.0002, 0.05])
-def test_two_ranks_share_one_gpu_over_gloo(stepsize):
+@pytest.mark.parametrize("stepsize,mixed", [(0.0002, False), (0.05, False), (0.0002, True), (0.02, True)])
+def test_two_ranks_share_one_gpu_over_gloo(stepsize, mixed):
     """Two ranks of the sharded driver with the product engine (real kernels, raw device
     buffers, per-chunk static count tables shared across ranks, full or split sweeps) on one
     GPU over gloo.  Weights must be bit-identical on both ranks and equal to the CPU oracle
     replaying the same chunk sequence on the union graph; per-variable state must equal the
-    oracle's block.  stepsize 0.0002: un-split sweeps; 0.05: starts split and walks down."""
+    oracle's block.  stepsize 0.0002: un-split sweeps; 0.05: starts split and walks down.
+    mixed: rank 1's block is all categorical, rank 0's all boolean -- the ranks' own views of
+    "has categorical variables" differ, and both must still put the same [G | T] vector
+    through every collective (they used to issue W against 2 W elements)."""
+
     import tempfile
 
     import numpy as np
@@ -35,13 +39,14 @@ def test_two_ranks_share_one_gpu_over_gloo(stepsize):
     from dist_worker import shard_graph
     from oracle import binding as orc
     from test_dist_gloo import _concat, _free_port
-    total, W, world = 40_000, 1500, 2
+    total, W, world = (12_000 if mixed else 40_000), 1500, 2
     port = _free_port()
     with tempfile.TemporaryDirectory() as out:
         procs = []
         for r in range(world):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                       MASTER_PORT=str(port), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                       MASTER_PORT=str(port), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                       DWX_TEST_MIXED="1" if mixed else "0")
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gpu_gloo_worker.py"),
                                            out, str(total), str(W), str(stepsize)], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -51,11 +56,13 @@ def test_two_ranks_share_one_gpu_over_gloo(stepsize):
         res = [dict(np.load(os.path.join(out, "rank%d.npz" % r))) for r in range(world)]
     assert np.array_equal(res[0]["weights"], res[1]["weights"])
     assert np.array_equal(res[0]["batches"], res[1]["batches"]) and np.array_equal(res[0]["eta"], res[1]["eta"])
-    if stepsize > 0.01:
+    if mixed:
+        assert (res[0]["batches"][0] > 1) == (stepsize > 0.01)
+    elif stepsize > 0.01:
         assert res[0]["batches"][0] > 1 and res[0]["batches"][-1] < res[0]["batches"][0]
     else:
         assert np.all(res[0]["batches"] == 1)
-    shards = [shard_graph(total, W, r, world, 1234)[0] for r in range(world)]
+    shards = [shard_graph(total, W, r, world, 1234, mixed=mixed)[0] for r in range(world)]
     union = _concat(shards)
     o = orc.Oracle(union, reg_param=0.01)
     sweep = 0
@@ -79,8 +86,10 @@ def test_two_ranks_share_one_gpu_over_gloo(stepsize):
     order = np.concatenate([res[r]["order"] + np.uint64(res[r]["begin"]) for r in range(world)])
     for _ in range(3):
         o.sched_sample(order, np.array([0, len(order)], np.uint64), 4242, sweep); sweep += 1
+    row0 = 0      # value rows: one per boolean variable, eight per categorical one
     for r in range(world):
-        b = int(res[r]["begin"]); n = len(res[r]["free"])
+        b = int(res[r]["begin"]); n = len(res[r]["free"]); rows = len(res[r]["tallies"])
         assert np.array_equal(res[r]["free"], o.assignments("free")[b:b + n])
         assert np.array_equal(res[r]["evid"], o.assignments("evid")[b:b + n])
-        assert np.array_equal(res[r]["tallies"], o.tallies[b:b + n])
+        assert np.array_equal(res[r]["tallies"], o.tallies[row0:row0 + rows])
+        row0 += rows

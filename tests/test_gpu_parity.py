@@ -165,48 +165,19 @@ def test_cfg3_learning_recovers_evidence_rate(lib):
 # ---------------- against the real reference (KS on per-variable marginals) --------
 
 def _parse_marginals(txt, V):
-    p = np.full(V, np.nan)
-    for line in txt.strip().splitlines():
-        a, b, c = line.split()
-        if b == "1":
-            p[int(a)] = float(c)
-    return p
+    import ks_golden
+    return ks_golden.parse_marginals(txt, V)
 
 
-@pytest.mark.parametrize("name", ["synth_cfg2", "synth_cfg3", "synth_cfg3b"])
+@pytest.mark.parametrize("name", ["synth_cfg2", "synth_cfg3", "synth_cfg3b", "synth_cfg4"])
 def test_ks_against_reference_golden_marginals(lib, name):
     """Committed marginals of the REAL reference (multi-threaded run in the build
-    container, tests/golden/make_golden.py) on 1/500-scale configs 2, 3, 3b:
-    two-sample z-scores of per-variable marginals must be N(0,1) (KS, alpha 0.01)."""
-    import synth_cases
-    d = os.path.join(GOLDEN, name)
-    raw = synth_cases.load(name)
-    o = parse_dw_args(open(os.path.join(d, "dw-args")).read())
-    s = dwx.GibbsSampler(dwx.Graph(raw, lib=lib), seed=321, reg_param=o["reg_param"])
-    dwx.DimmWitted(s, o["l"], o["i"], o["alpha"], o["diminish"]).learn()
-    w_ref = np.array([float(l.split()[1]) for l in open(os.path.join(d, "ref.weights.text"))])
-    if o["l"]:
-        # learned weights: same distribution as the reference's (noisy SGD): compare
-        # the weight vectors through their first two moments
-        w = s.weights
-        assert abs(w.mean() - w_ref.mean()) < 0.05 and abs(w.std() - w_ref.std()) < 0.05
-        assert np.corrcoef(w, w_ref)[0, 1] > 0.9
-        s.weights = w_ref          # then isolate the sampler: same weights on both sides
-    dwx.DimmWitted(s, 0, o["i"]).inference()
-    t, n = s.tallies()
-    q = raw.var_role == 0
-    p_gpu = (t / np.maximum(n, 1))[q]
-    p_ref = _parse_marginals(open(os.path.join(d, "ref.text")).read(), raw.num_variables)[q]
-    z = stats.z_scores_two_sample(p_gpu, o["i"], p_ref, o["i"])
-    pbar = 0.5 * (p_gpu + p_ref)
-    ok = (pbar > 0.1) & (pbar < 0.9)
-    if name == "synth_cfg3b":
-        # pairwise factors: successive samples are autocorrelated, so z is over-
-        # dispersed on BOTH sides; compare the marginal distributions instead
-        assert stats.ks_two_sample(p_gpu, p_ref) > 0.01
-    else:
-        assert stats.ks_normal(z[ok]) > 0.01
-    assert abs(p_gpu.mean() - p_ref.mean()) < 0.01
+    container, tests/golden/make_golden.py) on 1/500-scale configs 2, 3, 3b, 4: with this
+    build's OWN learned weights the distribution of the marginals must match (two-sample KS);
+    with the reference's weights substituted the per-variable z-scores must be N(0,1) (KS,
+    alpha 0.01).  tests/ks_golden.py."""
+    import ks_golden
+    ks_golden.check(lib, name, dict(device=0))
 
 
 def test_ks_against_reference_live(lib):
@@ -313,7 +284,7 @@ def test_high_degree_hub_variables(lib):
 
 
 def test_full_pipeline_learn_infer_vs_reference_live(lib):
-    """Config-3 shape at 300k variables, the WHOLE pipeline on both sides (the real
+    """Config-3 shape at 1M variables, the WHOLE pipeline on both sides (the real
     reference binary vs this build's `dw` drop-in, same files, same flags).  Learned
     weights are noisy SGD estimates of the same optimum, so the yardstick is the
     reference's own run-to-run spread (parity item 4): the reference is run
@@ -323,8 +294,8 @@ def test_full_pipeline_learn_infer_vs_reference_live(lib):
     from oracle import binding as orc
     if not orc.have_reference():
         pytest.skip("oracle/_ref/dw not present")
-    V, N = 300_000, 200
-    raw = synthetic.cfg3(V, n_weights=3000, seed=2024)
+    V, N = 1_000_000, 200
+    raw = synthetic.cfg3(V, n_weights=10_000, seed=2024)
     args = ["-l", "40", "-i", str(N), "--alpha", "0.01", "--diminish", "0.95", "--reg_param", "0.01"]
     dw = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sampler_amd", "csrc", "dw")
     q = raw.var_role == 0

@@ -51,6 +51,14 @@ def test_synth_cfg3b_colouring(lib):
     assert s.graph.info.num_colors >= 2
 
 
+@pytest.mark.parametrize("name", ["synth_cfg2", "synth_cfg3", "synth_cfg3b", "synth_cfg4"])
+def test_ks_against_reference_golden_marginals_emulated(lib, name):
+    """The KS comparison with the real reference's committed marginals (tests/ks_golden.py),
+    on the emulated kernels: the CPU suite covers it too, not only the -m gpu leg."""
+    import ks_golden
+    ks_golden.check(lib, name, {})
+
+
 def test_synth_cfg4(lib):
     run_parity(lib, synthetic.cfg4(700, card=8, seed=6, learn=False), n_learn=0, n_infer=5)
     run_parity(lib, synthetic.cfg4(700, card=5, seed=7, learn=True), n_learn=5, n_infer=3,
