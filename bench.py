@@ -1,14 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- variables sampled per second of the Gibbs sweep hot path on MI355X.
 
-Workload (BASELINE.json config 3, the graph north_star quotes its target on): 10M
-boolean variables x 10 unary ISTRUE factors each, 1M learnable weights, 50 % evidence;
-one STEP = one learning sweep (sample_sgd: two chains + weight SGD) followed by one
-inference sweep (sample) over all variables of the rank's block, i.e. 2 V variables
-sampled per step, counted as the reference's own `vars/sec` print counts them
-(src/dimmwitted.cc:152,232).  With --gpus N > 1 the graph is sharded by variable block
-(config 5: 12.5M variables per GPU, weights global); each learning sweep all-reduces
-the int64 gradient vector over RCCL.  Inputs are resident in HBM before timing starts.
+Workloads (BASELINE.json; `config.workload` names the one that ran):
+  cfg3  (default)  10M boolean variables x 10 unary ISTRUE factors each, 1M learnable
+        weights, 50 % evidence -- the graph north_star quotes its target on.  With --gpus N > 1
+        it is config 5a: the graph sharded by variable block, 12.5M variables per GPU, weights
+        global, no cross-shard factor (empty halo).
+  cfg5b the 3b mix (6 unary + 4 pairwise EQUAL factors per variable, offsets 1, 7, 101 and
+        V/8 + 3) over variable-block shards: factors cross the shard boundaries, ghost
+        variables are refreshed by a halo exchange after every sweep (dense halo from the last
+        offset).  At one GPU it is config 3b.
+One STEP = one learning sweep (sample_sgd: two chains + weight SGD; over N GPUs one all-reduce
+of the int64 gradient vector per mini-batch) followed by one inference sweep (sample), i.e.
+2 V variables sampled per step and GPU, counted as the reference's own `vars/sec` print counts
+them (src/dimmwitted.cc:152,232).  Inputs are resident in HBM before timing starts.
+
+Launch: `python bench.py --gpus N --steps K --warmup W`.  Under torch.distributed.run (the
+driver's way for N > 1) every rank reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; WITHOUT it
+(`WORLD_SIZE` unset) and N > 1 this process starts the N ranks itself -- fresh child processes,
+started before anything here touches a GPU -- and fails loudly if the node has fewer than N
+devices.  Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by a
+barrier + synchronize on both sides, repeated until 0.5 s of timed work has accumulated
+(--min-time); a block's time is the MAX over ranks; `value` comes from the MEDIAN block, the
+spread is reported next to it.
 
 Prints ONE JSON line (rank 0).  See DESIGN.md §6 for every field.
 """
@@ -16,7 +30,9 @@ import argparse
 import json
 import os
 import re
+import socket
 import statistics
+import subprocess
 import sys
 import tempfile
 import time
@@ -24,16 +40,91 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-B_INFER, B_LEARN = 340.0, 404.0  # algorithmic bytes per variable, SURVEY.md §8(d) cfg 3
+# algorithmic bytes per variable, SURVEY.md §8(d): (inference, learning)
+ALGO_BYTES = {"cfg3": (340.0, 404.0), "cfg5b": (564.0, 684.0)}
+RECORDS_PER_VAR = {"cfg3": 10, "cfg5b": 14}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["cfg3", "cfg5b"], default="cfg3")
+    ap.add_argument("--min-time", type=float, default=0.5,
+                    help="repeat the timed block of --steps steps until this many seconds are timed")
+    ap.add_argument("--max-repeats", type=int, default=200)
+    ap.add_argument("--vars-per-gpu", type=int, default=0,
+                    help="override the per-GPU variable count (default 10M at 1 GPU, 12.5M else)")
+    ap.add_argument("--cpu-sample-vars", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-repeat-infer", action="store_true",
+                    help="skip the untimed repeated-inference leg (profiling runs: keeps the kernel stats clean)")
+    ap.add_argument("--no-gather-ceiling", action="store_true",
+                    help="skip tools/gather_bench --ceiling (roofline.secondary.peak is then the committed figure)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / JSON plumbing only, over gloo on CPU: no GPU, no sampler")
+    ap.add_argument("--weights", type=int, default=0, help="override the weight count (experiments)")
+    ap.add_argument("--tile-vars", type=int, default=0, help="graph-compile knob (experiments)")
+    ap.add_argument("--tile-edges", type=int, default=0, help="graph-compile knob (experiments)")
+    ap.add_argument("--wide-records", action="store_true",
+                    help="graph-compile knob (experiments): 16-byte records even though the graph is all-unary")
+    return ap.parse_args(argv)
+
+
+# --------------------------------------------------------------------------- launcher
+def self_launch(args, argv):
+    """--gpus N without a launcher: start N ranks as fresh children (one process per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and pass rank 0's JSON line
+    through.  Nothing in this process has touched the GPU (device_count() does not initialise
+    it on this image); no process that did is ever re-executed."""
+    n = args.gpus
+    if not args.dry_run and not os.environ.get("DWX_BENCH_SKIP_DEVICE_COUNT_CHECK"):   # (test hook)
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.exit("bench.py: --gpus %d but this node has %d visible GPU(s); refusing to measure fewer "
+                     "GPUs than asked for" % (n, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DWX_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        # a rank that dies takes the others down with it (they would wait in a collective forever)
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    log("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code))
+                    for q in alive:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
+# --------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(n_vars, stepsize, decay, reg):
     """Time the CPU side on a bounded sample of the same workload: the same generator at
     n_vars variables, 3 learning + 10 inference epochs on all host cores.  Uses the real
@@ -46,6 +137,9 @@ def cpu_baseline(n_vars, stepsize, decay, reg):
     sample = ("config-3 generator at V=%d (10 unary ISTRUE factors/var, W=V/10, 50%% evidence); "
               "3 learning + 10 inference epochs, all host cores; value = 2V / (median learn "
               "epoch + median inference epoch)" % n_vars)
+    extra = {"sample_is_smaller": True,
+             "note": "a smaller graph than the GPU's (its tables sit higher in the CPU's caches: "
+                     "conservative for the CPU); the GPU/CPU ratio is not like-for-like"}
     if orc.have_reference():
         with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
             binary_format.write_graph(raw, d)
@@ -56,10 +150,10 @@ def cpu_baseline(n_vars, stepsize, decay, reg):
         ti = [float(x) for x in re.findall(r"INFERENCE EPOCH[^\n]*?\.\.\.\.([0-9.eE+-]+) sec\.", out)]
         if tl and ti:
             t = statistics.median(tl) + statistics.median(ti)
-            return {"value": 2.0 * n_vars / t, "unit": "variables/s", "cores": cores,
-                    "kind": "reference", "sample": sample,
-                    "learn_vars_per_sec": n_vars / statistics.median(tl),
-                    "infer_vars_per_sec": n_vars / statistics.median(ti)}
+            return dict({"value": 2.0 * n_vars / t, "unit": "variables/s", "cores": cores,
+                         "kind": "reference", "sample": sample,
+                         "learn_vars_per_sec": n_vars / statistics.median(tl),
+                         "infer_vars_per_sec": n_vars / statistics.median(ti)}, **extra)
     o = orc.Oracle(raw, reg_param=reg)
     o.set_workers(cores)
     tl, ti = [], []
@@ -70,28 +164,33 @@ def cpu_baseline(n_vars, stepsize, decay, reg):
     for _ in range(10):
         t0 = time.perf_counter(); o.sample(threaded=True); ti.append(time.perf_counter() - t0)
     t = statistics.median(tl) + statistics.median(ti)
-    return {"value": 2.0 * n_vars / t, "unit": "variables/s", "cores": cores, "kind": "port",
-            "sample": sample, "learn_vars_per_sec": n_vars / statistics.median(tl),
-            "infer_vars_per_sec": n_vars / statistics.median(ti)}
+    return dict({"value": 2.0 * n_vars / t, "unit": "variables/s", "cores": cores, "kind": "port",
+                 "sample": sample, "learn_vars_per_sec": n_vars / statistics.median(tl),
+                 "infer_vars_per_sec": n_vars / statistics.median(ti)}, **extra)
 
 
+def gather_ceiling():
+    """tools/gather_bench --ceiling (built by __graft_entry__.build): the sweep's own access
+    shape -- an 8-byte record stream + one random 4-byte gather per record out of a 4 MB table,
+    3 waves per SIMD -- and nothing else.  -> gathers per second, or None."""
+    exe = os.path.join(ROOT, "tools", "gather_bench")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "--ceiling"], capture_output=True, text=True, timeout=120)
+        for line in r.stdout.splitlines():
+            if line.startswith('{"mode"'):
+                return float(json.loads(line)["gathers_per_s"])
+    except Exception as e:                  # the ceiling must never lose the measurement
+        log("bench.py: gather_bench failed: %r" % (e,))
+    return None
+
+
+# --------------------------------------------------------------------------- one rank
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--vars-per-gpu", type=int, default=0,
-                    help="override the per-GPU variable count (default 10M at 1 GPU, 12.5M else)")
-    ap.add_argument("--cpu-sample-vars", type=int, default=1_000_000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-repeat-infer", action="store_true",
-                    help="skip the untimed repeated-inference leg (profiling runs: keeps the kernel stats clean)")
-    ap.add_argument("--weights", type=int, default=0, help="override the weight count (experiments)")
-    ap.add_argument("--tile-vars", type=int, default=0, help="graph-compile knob (experiments)")
-    ap.add_argument("--tile-edges", type=int, default=0, help="graph-compile knob (experiments)")
-    ap.add_argument("--wide-records", action="store_true",
-                    help="graph-compile knob (experiments): 16-byte records even though the graph is all-unary")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])        # never returns
 
     # stdout carries exactly ONE JSON line.  Libraries that print to the process's stdout
     # (RCCL's version banner: NCCL_DEBUG=VERSION is exported on the GPU boxes) are sent to
@@ -100,58 +199,98 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
-    from sampler_amd import dwx, synthetic
-    from sampler_amd.dist import HipEngine, ShardedDimmWitted
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log("bench.py: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d: launch one rank per GPU "
+                 "(torch.distributed.run --nproc-per-node %d, or no launcher at all)"
+                 % (args.gpus, world, args.gpus))
     n_gpus = world
-    if not torch.cuda.is_available():
-        sys.exit("bench.py: no GPU visible; the dwx sampler has no CPU fallback")
-    torch.cuda.set_device(local_rank)
     # DWX_BENCH_FORCE_DIST=1 runs the multi-GPU code path (process group, RCCL
     # all-reduces, barriers) even at world size 1 -- a self-check for single-GPU boxes
     use_dist = world > 1 or os.environ.get("DWX_BENCH_FORCE_DIST") == "1"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+
+    if args.dry_run:
+        # the launcher, the rendezvous and the result line, nothing else (CPU, gloo)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        ranks = int(t.item())
+        dist.barrier()
+        if rank == 0:
+            out = {"metric": "variables sampled/sec (whole node)", "value": None, "unit": "variables/s",
+                   "n_gpus": n_gpus, "rccl_ranks": ranks, "steps": args.steps, "warmup": args.warmup,
+                   "dry_run": True, "backend": "gloo",
+                   "launcher": "self" if os.environ.get("DWX_BENCH_SELF_LAUNCHED") else "external",
+                   "config": {"workload": args.workload}}
+            os.write(result_fd, (json.dumps(out) + "\n").encode())
+        dist.destroy_process_group()
+        return
+
+    from sampler_amd import dwx, synthetic
+    from sampler_amd.dist import CommTiming, HaloExchange, HipEngine, ShardedDimmWitted, shard_range
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; the dwx sampler has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    rccl_ranks = 1
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+        t = torch.ones(1, device="cuda")
+        dist.all_reduce(t)
+        rccl_ranks = int(t.item())          # how many ranks RCCL actually joined
+        assert rccl_ranks == dist.get_world_size() == world
 
+    wl = args.workload
     V = args.vars_per_gpu or (10_000_000 if n_gpus == 1 else 12_500_000)
     W = args.weights or (1_000_000 if V >= 1_000_000 else max(1, V // 10))
     stepsize, decay, reg = 0.001, 0.95, 0.01       # SURVEY.md §8(d) config-3 run flags
     t0 = time.time()
-    raw = synthetic.cfg3(V, n_weights=W, seed=1234, shard=rank)
+    ghosts, bounds = None, None
+    if wl == "cfg3":
+        raw = synthetic.cfg3(V, n_weights=W, seed=1234, shard=rank)
+    else:
+        bounds = [shard_range(V * n_gpus, k, n_gpus) for k in range(n_gpus)]
+        raw, ghosts = synthetic.cfg5b_shard(V * n_gpus, bounds[rank][0], bounds[rank][1], W, seed=1234)
     graph = dwx.Graph(raw, tile_vars=args.tile_vars, tile_edges=args.tile_edges,
                       no_compact_records=1 if args.wide_records else 0)
     sampler = dwx.GibbsSampler(graph, device=local_rank, reg_param=reg, seed=20260103,
                                var_id_offset=rank * V)
     if rank == 0:
-        log("setup: V/GPU=%d W=%d tiles=%d colours=%d device_bytes=%.2f GB (%.1f s)"
-            % (V, W, graph.info.num_tiles, graph.info.num_colors,
+        log("setup: %s V/GPU=%d W=%d tiles=%d colours=%d ghosts=%d device_bytes=%.2f GB (%.1f s)"
+            % (wl, V, W, graph.info.num_tiles, graph.info.num_colors, raw.num_ghost_variables,
                graph.info.device_bytes / 1e9, time.time() - t0))
     del raw
     engine = HipEngine(sampler)
-    drv = ShardedDimmWitted(engine, 0, 0, stepsize, decay)
+    halo = None
+    if ghosts is not None and use_dist and len(ghosts):
+        halo = HaloExchange(engine, bounds[rank][0], bounds[rank][1], ghosts, bounds)
+    drv = ShardedDimmWitted(engine, 0, 0, stepsize, decay, halo=halo)
     if use_dist and not drv.distributed:      # forced self-check at world size 1
         drv.distributed = True
+        engine.agree()
         engine.allreduce_static_counts()
     if os.environ.get("DWX_BENCH_PLAN_WORLD"):
         # experiment: one rank of an N-GPU run (its mini-batch plan and collectives, minus the
         # xGMI time): plan as if N equal shards contributed to every weight
         drv.plan_world = int(os.environ["DWX_BENCH_PLAN_WORLD"])
+    engine.comm_timing = CommTiming() if use_dist else None
 
     drv.prepare(stepsize)         # one-off planning work, whatever --warmup says
 
     def step(cur):
-        drv.learn_epoch(cur)      # sample_sgd (+ RCCL all-reduce of the gradient vector)
-        engine.sample()           # sample
+        drv.learn_epoch(cur)      # sample_sgd (+ RCCL all-reduce of the gradient vector, + halo)
+        drv.sample_epoch()        # sample (+ halo refresh of the evidence chain)
 
     def fence():
         engine.wait()
@@ -164,20 +303,38 @@ def main():
     for _ in range(args.warmup):
         step(cur); cur *= decay
     fence()
+    if engine.comm_timing is not None:
+        engine.comm_timing.drain()
     sampler.kernel_time_reset(True)
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step(cur); cur *= decay
-    fence()
-    elapsed = time.perf_counter() - t_start
+    # blocks of EXACTLY --steps steps, fenced on both sides; at least one, until --min-time
+    # seconds are timed.  The number of blocks must be the same on every rank: rank 0 decides.
+    blocks_local, total = [], 0.0
+    while True:
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            step(cur); cur *= decay
+        fence()
+        dt = time.perf_counter() - t_start
+        blocks_local.append(dt)
+        total += dt
+        go_on = 1 if (total < args.min_time and len(blocks_local) < args.max_repeats) else 0
+        if use_dist:
+            flag = torch.tensor([go_on], dtype=torch.int32, device="cuda")
+            dist.broadcast(flag, src=0)
+            go_on = int(flag.item())
+            torch.cuda.synchronize()
+        if not go_on:
+            break
+    repeats = len(blocks_local)
     ms_i, nl_i, ns_i = sampler.kernel_time("infer")
     ms_l, nl_l, ns_l = sampler.kernel_time("learn")
     ms_p, nl_p, ns_p = sampler.kernel_time("pull")
+    comm = engine.comm_timing.drain() if engine.comm_timing is not None else {}
     # outside the timed region: inference sweeps that FOLLOW EACH OTHER on unchanged weights
     # (what `dw gibbs -i N` runs) stream tabulated potential terms instead of gathering
     # weights; the step above alternates learning and inference and never gets there
     ms_r = nl_r = ns_r = 0
-    if not args.no_repeat_infer:
+    if not args.no_repeat_infer and halo is None:
         sampler.kernel_time_reset(True)
         for _ in range(6):
             engine.sample()
@@ -188,67 +345,130 @@ def main():
         engine.wait()
         ms_r, nl_r, ns_r = sampler.kernel_time("infer")
     sampler.kernel_time_reset(False)
+    # per block: MAX over ranks; per rank: its own median (reported as the per-rank spread)
+    blocks = list(blocks_local)
+    rank_ms = [1e3 * statistics.median(blocks_local) / args.steps]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        tb = torch.tensor(blocks_local, dtype=torch.float64, device="cuda")
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        blocks = [float(x) for x in tb.tolist()]
+        tr = torch.zeros(world, dtype=torch.float64, device="cuda")
+        tr[rank] = rank_ms[0]
+        dist.all_reduce(tr)
+        rank_ms = [float(x) for x in tr.tolist()]
     w = sampler.weights
     assert np.isfinite(w).all()
     # mini-batch plan at the LARGEST step of the run: 1 = un-split sweeps
-    plan_batches, _, plan_eta = sampler.sgd_plan(stepsize * n_gpus)
+    plan_batches, _, plan_min_step = sampler.sgd_plan(stepsize)
+    if use_dist:
+        plan_batches = drv._plan(stepsize)[0]
 
     if rank == 0:
+        elapsed = statistics.median(blocks)            # one block of exactly --steps steps
         total_vars = 2.0 * V * n_gpus * args.steps
         # units one launch processes: a learning launch visits every variable of the
         # block (both chains); an inference launch visits the query variables only
         # (evidence is skipped, as in the reference, but still counted in vars/sec)
         Vq = int(graph.info.num_query_variables)
-        # config 3 is all-unary: its sweeps run sweep8_kernel (8-byte records) unless --wide-records
-        kern = "sweep_kernel" if args.wide_records else "sweep8_kernel"
-        if ms_l >= ms_i:
-            kname, per_launch_ms, bpv, units = kern + "<LEARN=true>", ms_l / max(nl_l, 1), B_LEARN, V
+        B_INFER, B_LEARN = ALGO_BYTES[wl]
+        if wl == "cfg3":
+            # all-unary: the sweeps run sweep8_kernel (8-byte records) unless --wide-records
+            kern = "sweep_kernel" if args.wide_records else "sweep8_kernel"
         else:
-            kname, per_launch_ms, bpv, units = kern + "<LEARN=false>", ms_i / max(nl_i, 1), B_INFER, Vq
-        achieved = bpv * units / (per_launch_ms * 1e-3) / 1e9
+            kern = "sweep_kernel"
+        # a sweep is one launch per colour: per-launch figures are per colour launch, the
+        # roofline is priced per SWEEP (all its colour launches), which is what moves the bytes
+        sw_l, sw_i = ms_l / max(ns_l, 1), ms_i / max(ns_i, 1)
+        if sw_l >= sw_i:
+            kname, per_sweep_ms, bpv, units, nl, ns = kern + "<LEARN=true>", sw_l, B_LEARN, V, nl_l, ns_l
+        else:
+            kname, per_sweep_ms, bpv, units, nl, ns = kern + "<LEARN=false>", sw_i, B_INFER, Vq, nl_i, ns_i
+        launches_per_sweep = nl / max(ns, 1)
+        achieved = bpv * units / (per_sweep_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and wl == "cfg3" and V == 10_000_000 and W == 1_000_000:
             try:
                 traffic = json.load(open(tp)).get(kname)
             except Exception:
                 traffic = None
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "algorithmic_bytes_per_var": bpv,
+                    "vars_per_launch": units / max(launches_per_sweep, 1),
+                    "avg_launch_ms": per_sweep_ms / max(launches_per_sweep, 1),
+                    "launches_per_sweep": launches_per_sweep, "per_gpu": True}
+        if traffic:
+            # the fraction of PHYSICAL HBM bandwidth the kernel draws (PMC bytes, not the
+            # survey's byte model): the layout moves 2.4x fewer bytes than section 8(d) assumed
+            roofline["physical_frac"] = traffic / (per_sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        # What actually bounds the all-unary sweeps: one random 4-byte gather out of the 4 MB f32
+        # weight table per record = one 128-byte L2 request each (tools/gather_bench: ~13.7
+        # requests/clk/XCD whatever the occupancy).  Ceiling = the same stream + gather shape
+        # with nothing else, measured on this box right now.
+        if wl == "cfg3":
+            gathers = RECORDS_PER_VAR[wl] * units
+            peak = None if args.no_gather_ceiling else gather_ceiling()
+            committed = 1.87e11     # profiles/r02/gather_bench.jsonl: stream mode, 4 MB, 3 waves/SIMD
+            g_ach = gathers / (per_sweep_ms * 1e-3)
+            roofline["secondary"] = {"bound": "l2_req", "what": "random 4-byte weight gathers (one 128-byte L2 "
+                                     "request per record) next to the 8-byte record stream",
+                                     "achieved": g_ach / 1e9, "peak": (peak or committed) / 1e9,
+                                     "unit": "Ggather/s", "frac": g_ach / (peak or committed),
+                                     "peak_source": "tools/gather_bench --ceiling, this run" if peak else
+                                     "profiles/r02/gather_bench.jsonl (committed)",
+                                     "pure_gather_peak": 264.0}
         out = {
             "metric": "variables sampled/sec (whole node)",
             "value": total_vars / elapsed,
             "unit": "variables/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_gpus, "rccl_ranks": rccl_ranks if use_dist else None,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "repeats": repeats,
+            "ms_per_step_min": 1e3 * min(blocks) / args.steps, "ms_per_step_max": 1e3 * max(blocks) / args.steps,
+            "ms_per_step_stdev": 1e3 * (statistics.pstdev(blocks) if repeats > 1 else 0.0) / args.steps,
+            "timed_seconds": sum(blocks),
+            "ms_per_step_per_rank_min": min(rank_ms), "ms_per_step_per_rank_max": max(rank_ms),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64 (f32 sampling weights)", "data": "synthetic",
+            "launcher": ("self" if os.environ.get("DWX_BENCH_SELF_LAUNCHED") else
+                         ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none")),
             "config": {
-                "workload": "cfg3: %d boolean vars/GPU x 10 unary ISTRUE factors, W=%d learnable "
-                            "weights, 50%% evidence; step = 1 learning sweep (sample_sgd) + 1 "
-                            "inference sweep (sample)" % (V, W),
+                "workload": ("cfg3: %d boolean vars/GPU x 10 unary ISTRUE factors, W=%d learnable "
+                             "weights, 50%% evidence" % (V, W) if wl == "cfg3" else
+                             "cfg5b: %d boolean vars/GPU, 6 unary ISTRUE + 4 pairwise EQUAL factors per var "
+                             "(offsets 1, 7, 101, V/8+3), W=%d learnable weights, 50%% evidence" % (V, W)) +
+                            "; step = 1 learning sweep (sample_sgd) + 1 inference sweep (sample)",
                 "vars_per_gpu": V, "factors_per_var": 10, "weights": W,
-                "parallelism": "variable-block shards x%d, int64 gradient all-reduce per "
-                               "learning sweep" % n_gpus if n_gpus > 1 else "single GPU",
+                "parallelism": ("variable-block shards x%d, int64 gradient all-reduce per learning "
+                                "mini-batch%s" % (n_gpus, ", halo exchange of boundary assignments after every sweep"
+                                                 if halo is not None else "")) if n_gpus > 1 else "single GPU",
                 "stepsize": stepsize, "diminish": decay, "reg_param": reg,
-                "sgd_batches_per_sweep": plan_batches, "effective_stepsize": plan_eta / n_gpus,
+                "sgd_batches_per_sweep": plan_batches, "min_weight_stepsize": plan_min_step,
+                "colours": int(graph.info.num_colors),
+                "ghost_variables_per_gpu": int(len(ghosts)) if ghosts is not None else 0,
             },
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_var": bpv,
-                         "vars_per_launch": units, "avg_launch_ms": per_launch_ms},
-            "infer_roofline_frac": (B_INFER * Vq / (ms_i / max(nl_i, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if nl_i else None,
-            "learn_roofline_frac": (B_LEARN * V / (ms_l / max(nl_l, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if nl_l else None,
+            "roofline": roofline,
+            "infer_roofline_frac": (B_INFER * Vq / (sw_i * 1e-3) / 1e9 / HBM_PEAK_GBS) if ns_i else None,
+            "learn_roofline_frac": (B_LEARN * V / (sw_l * 1e-3) / 1e9 / HBM_PEAK_GBS) if ns_l else None,
             "sampled_vars_per_sec": (V + Vq) * n_gpus * args.steps / elapsed,
-            "infer_vars_per_sec": V * n_gpus / (ms_i / max(ns_i, 1) * 1e-3) if ns_i else None,
-            "learn_vars_per_sec": V * n_gpus / (ms_l / max(ns_l, 1) * 1e-3) if ns_l else None,
-            "infer_kernel_ms": ms_i / max(nl_i, 1), "learn_kernel_ms": ms_l / max(nl_l, 1),
-            "pull_grad_kernel_ms": (ms_p / nl_p) if nl_p else None,
-            "infer_repeat_kernel_ms": (ms_r / nl_r) if nl_r else None,
+            "infer_vars_per_sec": V * n_gpus / (sw_i * 1e-3) if ns_i else None,
+            "learn_vars_per_sec": V * n_gpus / (sw_l * 1e-3) if ns_l else None,
+            "infer_kernel_ms": sw_i, "learn_kernel_ms": sw_l,
+            "pull_grad_kernel_ms": (ms_p / ns_p) if ns_p else None,
+            "infer_repeat_kernel_ms": (ms_r / ns_r) if ns_r else None,
             "infer_repeat_vars_per_sec": V * n_gpus / (ms_r / max(ns_r, 1) * 1e-3) if ns_r else None,
         }
+        if use_dist:
+            n_steps_timed = args.steps * repeats
+            ar = comm.get("allreduce", (0.0, 0, 0))
+            hl = comm.get("halo", (0.0, 0, 0))
+            out["allreduce_ms_per_step"] = ar[0] / n_steps_timed
+            out["allreduce_calls_per_step"] = ar[1] / n_steps_timed
+            out["allreduce_bytes_per_step"] = ar[2] / n_steps_timed
+            out["halo_ms_per_step"] = hl[0] / n_steps_timed
+            out["halo_bytes_per_step"] = hl[2] / n_steps_timed
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_vars, stepsize, decay, reg)

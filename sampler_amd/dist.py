@@ -28,6 +28,36 @@ class _CudaArray:
         }
 
 
+class CommTiming:
+    """Device time spent in collectives, measured with events on the engine's stream (the
+    stream waits for RCCL's own stream before the closing event is recorded).  Used by
+    bench.py; costs two event records per collective."""
+
+    def __init__(self):
+        self.pending, self.ms, self.calls, self.bytes = [], {}, {}, {}
+        self._open = {}
+
+    def begin(self, kind, stream, nbytes=0):
+        a = torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        self._open[kind] = a
+        self.bytes[kind] = self.bytes.get(kind, 0) + nbytes
+
+    def end(self, kind, stream):
+        b = torch.cuda.Event(enable_timing=True)
+        b.record(stream)
+        self.pending.append((kind, self._open.pop(kind), b))
+
+    def drain(self):
+        """(call after a synchronisation) -> {kind: (total ms, calls, bytes)}; resets."""
+        for kind, a, b in self.pending:
+            self.ms[kind] = self.ms.get(kind, 0.0) + a.elapsed_time(b)
+            self.calls[kind] = self.calls.get(kind, 0) + 1
+        out = {k: (self.ms[k], self.calls[k], self.bytes.get(k, 0)) for k in self.ms}
+        self.pending, self.ms, self.calls, self.bytes = [], {}, {}, {}
+        return out
+
+
 class HipEngine:
     """The product engine: a dwx.GibbsSampler on this rank's GPU.  Collectives run on
     the sampler's own HIP stream (made torch's current stream), so kernels and RCCL
@@ -52,6 +82,7 @@ class HipEngine:
         self.stream = torch.cuda.ExternalStream(sampler.stream(), device=dev)
         self._plan_batches, self._dynamic_counts, self._shared_levels = 1, False, set()
         self._level_dynamic = {}      # batches -> agreed "some rank counts dynamically"
+        self.comm_timing = None       # CommTiming: device time of the collectives (bench.py)
 
     def agree(self, group=None):
         """Once after create: what every rank must decide alike.  A shard without categorical
@@ -142,8 +173,12 @@ class HipEngine:
 
     def allreduce_grad(self, group=None):
         with torch.cuda.stream(self.stream):
-            dist.all_reduce(self.grad if self._dynamic_counts else self.grad_reduced,
-                            op=dist.ReduceOp.SUM, group=group)
+            t = self.grad if self._dynamic_counts else self.grad_reduced
+            if self.comm_timing is not None:
+                self.comm_timing.begin("allreduce", self.stream, t.numel() * t.element_size())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            if self.comm_timing is not None:
+                self.comm_timing.end("allreduce", self.stream)
 
     # ---- replicas (the reference's n_datacopy) ----
     def sample_sgd(self, stepsize):
@@ -201,11 +236,16 @@ class HipEngine:
 class HaloExchange:
     """Boundary-assignment exchange between sweeps (north_star: "halo-exchange of boundary
     assignments between sweeps").  Rank r owns the global variable block
-    [begin_r, end_r); its ghosts are remote variables its factors read.  Built once:
-    every rank learns which of its owned variables each peer ghosts; per exchange one
-    gather -> point-to-point send/recv per peer -> scatter, 4 B per boundary variable and
-    chain, on the engine's stream.  Reads of ghosts between exchanges are stale by at
-    most one sweep -- the reference's own Hogwild semantics across threads."""
+    [begin_r, end_r); its ghosts are remote variables its factors read.  Built once: every
+    rank learns which of its owned variables each peer ghosts, and allocates ONE send and ONE
+    receive buffer per peer, sized for both chains.  Per exchange, all on the engine's stream
+    and with no allocation and no host synchronisation: gather the boundary values of the
+    requested chains into the send buffers (index_select into the persistent buffer), ONE
+    grouped send/recv for all peers and chains (ncclGroupStart/End under batch_isend_irecv; the
+    returned works are waited on by the STREAM, which RCCL's work objects do without blocking
+    the host), scatter the received values into the ghost slots.  4 B per boundary variable and
+    chain.  Reads of ghosts between exchanges are stale by at most one sweep -- the reference's
+    own Hogwild semantics across threads."""
 
     def __init__(self, engine, begin, end, ghost_global_ids, bounds, group=None):
         self.e = engine
@@ -231,22 +271,33 @@ class HaloExchange:
                 local = n_owned + np.searchsorted(ghosts, mine)
                 self.recv_pos[k] = engine.positions(local.astype(np.uint64))
         self.n_boundary = sum(len(v) for v in self.send_pos.values())
+        self.n_ghost = sum(len(v) for v in self.recv_pos.values())
+        a = engine.assign_tensor("free")
+        # persistent buffers: [chain 0 values | chain 1 values] per peer
+        self.send_buf = {k: torch.empty(2 * len(p), dtype=a.dtype, device=a.device) for k, p in self.send_pos.items()}
+        self.recv_buf = {k: torch.empty(2 * len(p), dtype=a.dtype, device=a.device) for k, p in self.recv_pos.items()}
+        self.bytes_per_exchange = 0      # of the last exchange: sent + received by this rank
 
     def exchange(self, chains=("free", "evid")):
+        nc = len(chains)
         with self.e.stream_context():
-            for chain in chains:
-                a = self.e.assign_tensor(chain)
-                ops, recv = [], {}
-                for k, pos in self.send_pos.items():
-                    ops.append(dist.P2POp(dist.isend, a[pos].contiguous(), k, group=self.group))
-                for k, pos in self.recv_pos.items():
-                    recv[k] = torch.empty(len(pos), dtype=a.dtype, device=a.device)
-                    ops.append(dist.P2POp(dist.irecv, recv[k], k, group=self.group))
-                if ops:
-                    for w in dist.batch_isend_irecv(ops):
-                        w.wait()
-                for k, pos in self.recv_pos.items():
-                    a[pos] = recv[k]
+            views = [self.e.assign_tensor(c) for c in chains]
+            ops = []
+            for k, pos in self.send_pos.items():
+                n = len(pos)
+                for c, a in enumerate(views):
+                    torch.index_select(a, 0, pos, out=self.send_buf[k][c * n:(c + 1) * n])
+                ops.append(dist.P2POp(dist.isend, self.send_buf[k][:nc * n], k, group=self.group))
+            for k, pos in self.recv_pos.items():
+                ops.append(dist.P2POp(dist.irecv, self.recv_buf[k][:nc * len(pos)], k, group=self.group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            for k, pos in self.recv_pos.items():
+                n = len(pos)
+                for c, a in enumerate(views):
+                    a.index_copy_(0, pos, self.recv_buf[k][c * n:(c + 1) * n])
+        self.bytes_per_exchange = 4 * nc * (self.n_boundary + self.n_ghost)
 
 
 class ShardedDimmWitted:
@@ -288,7 +339,7 @@ class ShardedDimmWitted:
                 self.e.sgd_apply()
         self.e.sgd_finish()
         if self.halo is not None:
-            self.halo.exchange(("free", "evid"))
+            self._halo(("free", "evid"))
 
     def prepare(self, stepsize):
         """Do the one-off work of the first learning sweep now (curvature estimates, plan
@@ -372,10 +423,23 @@ class ShardedDimmWitted:
 
     def inference(self):
         for _ in range(self.n_inference_epoch):
-            self.e.sample()
-            if self.halo is not None:
-                self.halo.exchange(("evid",))
+            self.sample_epoch()
         self.e.wait()
+
+    def sample_epoch(self):
+        """One inference sweep (+ the evidence-chain halo refresh)."""
+        self.e.sample()
+        if self.halo is not None:
+            self._halo(("evid",))
+
+    def _halo(self, chains):
+        ct = getattr(self.e, "comm_timing", None)
+        if ct is not None:
+            ct.begin("halo", self.e.stream)
+        self.halo.exchange(chains)
+        if ct is not None:
+            ct.bytes["halo"] = ct.bytes.get("halo", 0) + self.halo.bytes_per_exchange
+            ct.end("halo", self.e.stream)
 
 
 class ReplicatedDimmWitted:

@@ -189,6 +189,96 @@ def cfg4(V=5_000_000, card=8, seed=1234, learn=False, shard=0):
         w_initial_value=w0, w_is_fixed=fixed)
 
 
+# ---- config 5b: the 3b mix over variable-block shards, generated shard by shard ----------
+# Every attribute is a pure function of a GLOBAL id (splitmix64 of (seed, kind, id)), so a rank
+# can build its own block -- and the factors other blocks own that touch it -- without anybody
+# ever holding the 10^8-variable graph.
+
+def _mix64(x, salt):
+    """splitmix64 finaliser over uint64 arrays (wraps modulo 2^64 by construction)."""
+    with np.errstate(over="ignore"):
+        z = x.astype(np.uint64) + np.uint64((0x9E3779B97F4A7C15 * (salt + 1)) & 0xFFFFFFFFFFFFFFFF)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _unit(x, salt):
+    return (_mix64(x, salt) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def cfg5b_offsets(V_total):
+    return [1, 7, 101, V_total // 8 + 3]
+
+
+def cfg5b_shard(V_total, begin, end, n_weights, seed=1234, offsets=None):
+    """The block [begin, end) of the config-5b graph: V_total boolean variables, 50 % evidence
+    ~ Bernoulli(0.7), per variable v 6 unary ISTRUE factors and 4 binary EQUAL(v, (v + o) mod
+    V_total), o in {1, 7, 101, V_total/8 + 3} (global factor id = 10 v + j; weight id = hash of
+    the factor id).  Returns (local RawGraph, ghost global ids): the owned variables (local id =
+    global - begin), then the ghosts -- remote endpoints of local factors -- in ascending global
+    id; local factors = the 10 factors of every owned variable, then (ascending global factor
+    id) the binary factors OTHER blocks own whose second endpoint is owned here: a factor
+    spanning two shards lives on both, as sampler_amd.shard.make_shard does for a graph in
+    memory.  With 8 equal blocks the last offset makes every variable read a neighbour in the
+    next block: a dense halo; the small offsets give thin ones."""
+    offsets = offsets or cfg5b_offsets(V_total)
+    W = n_weights
+    n = end - begin
+    nu, nb = 6, len(offsets)
+    k = nu + nb
+    own = np.arange(begin, end, dtype=np.uint64)
+    Vt = np.uint64(V_total)
+    # own factors, variable-major
+    per = nu + 2 * nb
+    ev = np.empty((n, per), np.uint64)
+    for j in range(nu):
+        ev[:, j] = own
+    for j, o in enumerate(offsets):
+        ev[:, nu + 2 * j] = own
+        ev[:, nu + 2 * j + 1] = (own + np.uint64(o)) % Vt
+    fid_own = (own[:, None] * np.uint64(k) + np.arange(k, dtype=np.uint64)[None, :]).ravel()
+    # incoming: factor (v', u), v' = (u - o) mod V_total outside the block, u owned
+    inc_fid, inc_src, inc_dst = [], [], []
+    for j, o in enumerate(offsets):
+        src = (own + Vt - np.uint64(o % V_total)) % Vt
+        outside = (src < np.uint64(begin)) | (src >= np.uint64(end))
+        inc_src.append(src[outside]); inc_dst.append(own[outside])
+        inc_fid.append(src[outside] * np.uint64(k) + np.uint64(nu + j))
+    inc_fid = np.concatenate(inc_fid); inc_src = np.concatenate(inc_src); inc_dst = np.concatenate(inc_dst)
+    order = np.argsort(inc_fid, kind="stable")
+    inc_fid, inc_src, inc_dst = inc_fid[order], inc_src[order], inc_dst[order]
+    n_inc = len(inc_fid)
+    edge_global = np.concatenate([ev.ravel(), np.stack([inc_src, inc_dst], 1).ravel()])
+    remote = (edge_global < np.uint64(begin)) | (edge_global >= np.uint64(end))
+    ghosts = np.unique(edge_global[remote])
+    local = np.where(remote, np.uint64(n) + np.searchsorted(ghosts, edge_global).astype(np.uint64),
+                     edge_global - np.uint64(begin))
+    arity = np.concatenate([np.tile(np.array([1] * nu + [2] * nb, np.uint64), n), np.full(n_inc, 2, np.uint64)])
+    off = np.zeros(len(arity) + 1, np.uint64)
+    np.cumsum(arity, out=off[1:])
+    func = np.concatenate([np.tile(np.array([FUNC_ISTRUE] * nu + [FUNC_EQUAL] * nb, np.uint16), n),
+                           np.full(n_inc, FUNC_EQUAL, np.uint16)])
+    fid = np.concatenate([fid_own, inc_fid])
+    wid = _mix64(fid, 3 * seed + 2) % np.uint64(W)
+    ids = np.concatenate([own, ghosts])
+    is_evid = _unit(ids, 3 * seed) < 0.5
+    val = (_unit(ids, 3 * seed + 1) < 0.7) & is_evid
+    nv = len(ids)
+    g = RawGraph(
+        var_role=is_evid.astype(np.uint8), var_init_value=val.astype(np.uint64),
+        var_dtype=np.full(nv, DTYPE_BOOLEAN, np.uint16), var_cardinality=np.full(nv, 2, np.uint64),
+        fac_func=func, fac_edge_offset=off, fac_weight_id=wid, fac_feature_value=np.ones(len(fid)),
+        edge_vid=local, edge_equal_to=np.ones(len(local), np.uint64),
+        w_initial_value=np.zeros(W), w_is_fixed=np.zeros(W, np.uint8), num_ghost_variables=len(ghosts))
+    return g, ghosts
+
+
+def cfg5b(V_total, n_weights, seed=1234):
+    """The WHOLE config-5b graph (small sizes: tests): one block, no ghosts."""
+    return cfg5b_shard(V_total, 0, V_total, n_weights, seed)[0]
+
+
 def cfg4_closed_form(g: RawGraph, card):
     w = g.w_initial_value[:card]
     p = np.exp(w - w.max())

@@ -22,6 +22,8 @@ def _check(out, n_gpus):
     assert d["n_gpus"] == n_gpus and d["value"] > 0 and d["higher_is_better"] is True
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"]
     assert "workload" in d["config"]
+    assert d["repeats"] >= 1 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    assert d["dtype"].startswith("f64")
     return d
 
 
@@ -33,6 +35,12 @@ def test_bench_single_process_small():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _check(r.stdout, 1)
     assert d["cpu_baseline"]["value"] and d["cpu_baseline"]["kind"] in ("reference", "port")
+    assert d["cpu_baseline"]["sample_is_smaller"] is True
+    # the second ceiling: random weight gathers, calibrated on this box by tools/gather_bench
+    sec = d["roofline"]["secondary"]
+    assert sec["bound"] == "l2_req" and sec["peak"] > 0 and 0 < sec["frac"] < 1.5
+    assert "this run" in sec["peak_source"]
+    assert d["rccl_ranks"] is None and d["timed_seconds"] >= 0.4
 
 
 @pytest.mark.gpu
@@ -44,4 +52,20 @@ def test_bench_under_torch_distributed_run_with_rccl_path():
                         "--vars-per-gpu", "200000", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    _check(r.stdout, 1)
+    d = _check(r.stdout, 1)
+    assert d["rccl_ranks"] == 1 and d["launcher"] == "torch.distributed.run"
+    assert d["allreduce_calls_per_step"] >= 1 and d["allreduce_ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_cfg5b_workload_runs_the_pairwise_kernels_and_the_collective_path():
+    """--workload cfg5b at one rank (forced through the RCCL path): the 3b mix, several colours,
+    sweep_kernel instead of sweep8_kernel; the halo itself needs a second GPU."""
+    env = dict(os.environ, DWX_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29619")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg5b", "--steps", "3",
+                        "--warmup", "1", "--vars-per-gpu", "200000", "--no-cpu-baseline", "--min-time", "0.05"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = _check(r.stdout, 1)
+    assert d["config"]["colours"] >= 2 and "cfg5b" in d["config"]["workload"]
+    assert d["roofline"]["kernel"].startswith("sweep_kernel") and d["roofline"]["launches_per_sweep"] >= 2
