@@ -154,6 +154,8 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
  * the same on its own if this was never called.  (No reference counterpart: the reference
  * has no device.) */
 int dwx_device_init(int32_t device);
+/* Number of usable HIP devices (0 without a GPU: not an error). */
+int dwx_device_count(int32_t *count);
 void dwx_sampler_destroy(dwx_sampler *s);
 
 /* GibbsSampler::sample(i_epoch) (src/gibbs_sampler.cc:20-25): one inference sweep. */
@@ -260,12 +262,36 @@ enum {
                                batch count (the library caches it per batch count)   */
 };
 int dwx_device_buffer(dwx_sampler *s, int which, void **dev_ptr, uint64_t *nbytes);
+/* Copy between host memory and a device pointer obtained from dwx_device_buffer /
+ * dwx_halo_buffer (to_device != 0: host -> device), ordered after everything already queued
+ * on the sampler's stream; returns when the copy is done.  For drivers without a device
+ * runtime of their own (the host-staged test communicator of `dw gibbs --comm host`). */
+int dwx_buffer_copy(dwx_sampler *s, void *dst, const void *src, uint64_t nbytes, int to_device);
+/* Halo exchange support (multi-GPU with factors that cross the shard boundary; SURVEY.md 8e:
+ * "exchange halo assignments ... grouped in one ncclGroupStart/End").  A halo list is one side
+ * of the exchange with one peer: `vids` = local variable ids (owned variables a peer ghosts:
+ * a SEND list; ghost variables a peer owns: a RECEIVE list, dwx_graph_desc.num_ghost_variables)
+ * and a device buffer of 2 n uint32.  dwx_halo_pack_async gathers the listed variables'
+ * assignments of the selected chains (bit 0: free chain, bit 1: evidence chain; selected
+ * chains back to back, n values each) into the buffer; the caller moves buffers between
+ * ranks with its collective library on dwx_stream (ncclSend / ncclRecv); dwx_halo_unpack_async
+ * scatters a received buffer into the ghosts.  All on the sampler's stream, no host
+ * synchronisation.  (No reference counterpart: the reference's threads share one address
+ * space and read each other's assignments directly, src/gibbs_sampler.h:198-215.) */
+typedef struct dwx_halo dwx_halo;
+int dwx_halo_create(dwx_sampler *s, const uint64_t *vids, uint64_t n, dwx_halo **out);
+void dwx_halo_destroy(dwx_halo *h);
+int dwx_halo_buffer(dwx_halo *h, void **dev_ptr, uint64_t *nbytes);
+int dwx_halo_pack_async(dwx_halo *h, int chains);
+int dwx_halo_unpack_async(dwx_halo *h, int chains);
+
 /* The HIP stream (hipStream_t) the sampler enqueues on. */
 int dwx_stream(dwx_sampler *s, void **stream);
 
 /* Device time of the sweep kernels only, measured with HIP events on the sampler's
  * stream around every launch since the last reset: total milliseconds, number of
- * kernel launches and number of sweeps.  kind: 0 = inference sweep kernels, 1 = learning
+ * kernel launches and number of sweeps (a learning sweep of several colours or
+ * mini-batches is ONE sweep of several launches).  kind: 0 = inference sweep kernels, 1 = learning
  * sweep kernels, 2 = the pull-based gradient kernel of learning sweeps. */
 int dwx_kernel_time(dwx_sampler *s, int kind, double *ms, uint64_t *launches, uint64_t *sweeps);
 int dwx_kernel_time_reset(dwx_sampler *s, int enable);

@@ -38,6 +38,7 @@ const FlagSpec kFlags[] = {
     {"", "regularization", true}, {"q", "quiet", false}, {"", "sample_evidence", false},
     {"", "learn_non_evidence", false}, {"", "noise_aware", false},
     {"", "device", true}, {"", "seed", true}, {"", "step_cap", true},
+    {"", "gpus", true}, {"", "devices", true}, {"", "comm", true},
 };
 
 const FlagSpec *find_flag(const std::string &tok) {
@@ -171,14 +172,27 @@ CmdLine parse_cmdline(int argc, const char *const argv[]) {
     else if (n == "device") { if (need_u()) a.device = (int)u; }
     else if (n == "seed") { if (need_u()) a.seed = u; }
     else if (n == "step_cap") { if (need_d()) a.step_cap = d; }
+    else if (n == "gpus") { if (need_u()) a.gpus = (int)u; }
+    else if (n == "comm") {
+      if (val != "rccl" && val != "host") { ++a.num_errors; err << "PARSE ERROR: Argument: --comm\n             must be rccl or host\n"; }
+      a.comm = val;
+    } else if (n == "devices") {
+      a.devices.clear();
+      std::istringstream ss(val);
+      std::string el;
+      while (getline(ss, el, ',')) {
+        if (!to_u64(el, u)) { ++a.num_errors; err << "PARSE ERROR: Argument: --devices\n             expects a comma-separated list of device ordinals\n"; break; }
+        a.devices.push_back((int)u);
+      }
+    }
   }
   // -l and -i are required for gibbs (src/cmd_parser.cc:75-80)
   if (is_gibbs && !have_l) { ++a.num_errors; err << "PARSE ERROR:\n             Required argument missing: n_learning_epoch\n"; }
   if (is_gibbs && !have_i) { ++a.num_errors; err << "PARSE ERROR:\n             Required argument missing: n_inference_epoch\n"; }
   // XXX hack of the reference to support two step-size flags (src/cmd_parser.cc:158-160)
   if (a.stepsize == 0.01) a.stepsize = a.stepsize2;
-  // n_datacopy / n_threads describe CPU replicas and threads; one GPU sampler replaces
-  // them.  They are accepted and normalised so existing command lines keep working.
+  // n_threads describes CPU threads: accepted and ignored.  n_datacopy > 1 asks for replicas
+  // of the whole graph (one per GPU, dw_multi.h); --gpus N for variable-block shards.
   if (a.n_datacopy == 0) a.n_datacopy = 1;
   if (a.n_threads == 0) a.n_threads = (uint64_t)std::max(1L, sysconf(_SC_NPROCESSORS_CONF));
   a.error_text = err.str();
@@ -510,15 +524,15 @@ void dump_marginals_in_text(std::ostream &o, const LoadedGraph &g, bool sample_e
                             const std::vector<uint64_t> &var_val_base,
                             const std::vector<uint64_t> &value_sparse,
                             const std::vector<uint64_t> &tallies,
-                            const std::vector<uint64_t> &nsamples) {
-  dump_parallel(o, g.n_variables, [&](uint64_t v, std::string &s) {
+                            const std::vector<uint64_t> &nsamples, uint64_t id_offset, uint64_t n_vars) {
+  dump_parallel(o, std::min<uint64_t>(g.n_variables, n_vars), [&](uint64_t v, std::string &s) {
     if (g.var_role[v] >= 1 && !sample_evidence) return;
     const uint64_t b = var_val_base[v];
     if (g.var_dtype[v] == 0) {
-      append_line(s, v, (uint64_t)1, 1.0 * tallies[b] / nsamples[v]);
+      append_line(s, v + id_offset, (uint64_t)1, 1.0 * tallies[b] / nsamples[v]);
     } else {
       for (uint64_t j = 0; j < g.var_cardinality[v]; ++j)
-        append_line(s, v, value_sparse[b + j], 1.0 * tallies[b + j] / nsamples[v]);
+        append_line(s, v + id_offset, value_sparse[b + j], 1.0 * tallies[b + j] / nsamples[v]);
     }
   });
 }
@@ -919,6 +933,7 @@ int dw_main(int argc, const char *const argv[]) {
   }
   if (a.app_name == "text2bin") return text2bin(a);
   if (a.app_name == "bin2text") return bin2text(a);
+  if (a.gpus >= 1 || a.n_datacopy > 1) return gibbs_multi(a);
   return gibbs(a);
 }
 

@@ -39,6 +39,9 @@ struct CmdLine {
   int device = 0;
   uint64_t seed = 0x5eed5eedULL;
   double step_cap = 1.5;
+  int gpus = 0;                 // --gpus N: variable-block shards over N GPUs (dw_multi.h)
+  std::vector<int> devices;     // --devices a,b,...: the ranks' HIP devices (default 0..N-1)
+  std::string comm = "rccl";    // --comm rccl | host (host-staged sums: a test stand-in)
   int num_errors = 0;
   std::string error_text;
 };
@@ -80,10 +83,13 @@ void dump_marginals_in_text(std::ostream &o, const LoadedGraph &g, bool sample_e
                             const std::vector<uint64_t> &var_val_base,
                             const std::vector<uint64_t> &value_sparse,
                             const std::vector<uint64_t> &tallies,
-                            const std::vector<uint64_t> &nsamples);
+                            const std::vector<uint64_t> &nsamples,
+                            uint64_t id_offset = 0, uint64_t n_vars = ~0ull);   // (a shard: local ids + offset, owned only)
 
 // the `dw gibbs` mode (src/dimmwitted.cc:37-95); returns the process exit code
 int gibbs(const CmdLine &args);
+// the same over several GPUs (dw_multi.cc): --gpus N shards, -c N replicas
+int gibbs_multi(const CmdLine &args);
 // `dw text2bin` (src/text2bin.cc:19-260) and `dw bin2text` (src/bin2text.cc:23-151)
 int text2bin(const CmdLine &args);
 int bin2text(const CmdLine &args);

@@ -88,6 +88,7 @@ struct TimedSpan {
   int kind;
   uint32_t launches;
   bool has_pull;
+  bool new_sweep;   // the span opens a sweep (inference: always; learning: its first chunk)
 };
 }  // namespace
 
@@ -197,6 +198,15 @@ struct dwx_sampler {
   }
 };
 
+// One side of a halo exchange with one peer: the device positions of the variables whose
+// assignments travel, and the buffer they travel in ([chain][i], both chains' worth).
+struct dwx_halo {
+  dwx_sampler *s = nullptr;
+  uint32_t n = 0;
+  uint32_t *d_pos = nullptr, *d_buf = nullptr;
+  ~dwx_halo() { rt::dfree(d_pos); rt::dfree(d_buf); }
+};
+
 namespace {
 // launch the sweep kernel (+ the oversized-variable kernel) over tiles [t0, t1) of launch l
 template <bool LEARN>
@@ -295,7 +305,7 @@ void enqueue_inference(dwx_sampler *s) {
   if (s->timing) {
     rt::event_record(sp.b, s->stream);
     rt::event_record(sp.c, s->stream);
-    sp.launches = launches; sp.has_pull = false;
+    sp.launches = launches; sp.has_pull = false; sp.new_sweep = true;
     s->spans.push_back(sp);
   }
   ++s->sweep;
@@ -929,7 +939,7 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
   }
   if (s->timing) {
     rt::event_record(sp.c, s->stream);
-    sp.launches = launches; sp.has_pull = pulled;
+    sp.launches = launches; sp.has_pull = pulled; sp.new_sweep = chunk == 0;
     s->spans.push_back(sp);
   }
 }
@@ -966,12 +976,12 @@ void drain_spans(dwx_sampler *s) {
   for (auto &sp : s->spans) {
     s->t_ms[sp.kind] += rt::event_elapsed_ms(sp.a, sp.b);
     s->t_launches[sp.kind] += sp.launches;
-    s->t_sweeps[sp.kind] += 1;   // (a learning sweep split into chunks counts once per chunk)
+    s->t_sweeps[sp.kind] += sp.new_sweep ? 1 : 0;   // (a learning sweep is one or more chunks)
     if (sp.has_pull) {
       s->t_ms[2] += rt::event_elapsed_ms(sp.b, sp.c);
       s->t_launches[2] += 1;
-      s->t_sweeps[2] += 1;
     }
+    if (sp.kind == 1 && sp.new_sweep) s->t_sweeps[2] += 1;
     rt::event_destroy(sp.a); rt::event_destroy(sp.b); rt::event_destroy(sp.c);
   }
   s->spans.clear();
@@ -1248,6 +1258,21 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
   return DWX_OK;
 }
 
+int dwx_device_count(int32_t *count) {
+  if (!count) return fail(DWX_E_INVALID, "null argument");
+  return guarded([&]() { *count = rt::device_count(); });
+}
+
+int dwx_buffer_copy(dwx_sampler *s, void *dst, const void *src, uint64_t nbytes, int to_device) {
+  if (!s || (nbytes && (!dst || !src))) return fail(DWX_E_INVALID, "null argument");
+  return guarded([&]() {
+    rt::set_device(s->device);
+    if (to_device) rt::h2d(dst, src, nbytes, s->stream);
+    else rt::d2h(dst, src, nbytes, s->stream);
+    rt::stream_sync(s->stream);
+  });
+}
+
 int dwx_device_init(int32_t device) {
   return guarded([&]() {
     rt::init_device(device);
@@ -1510,6 +1535,60 @@ int dwx_device_buffer(dwx_sampler *s, int which, void **dev_ptr, uint64_t *nbyte
   }
   return DWX_OK;
 }
+
+int dwx_halo_create(dwx_sampler *s, const uint64_t *vids, uint64_t n, dwx_halo **out) {
+  if (!s || !out || (n && !vids)) return fail(DWX_E_INVALID, "null argument");
+  if (n >= 0xFFFFFFFFull) return fail(DWX_E_LIMIT, "halo list exceeds 2^32-1 entries");
+  std::unique_ptr<dwx_halo> h(new dwx_halo());
+  int rc = guarded([&]() {
+    const CompiledGraph &c = *s->cg;
+    rt::set_device(s->device);
+    std::vector<uint32_t> pos(n);
+    for (uint64_t i = 0; i < n; ++i) {
+      if (vids[i] >= c.V) throw std::invalid_argument("halo list: variable id out of range");
+      pos[i] = c.pos[vids[i]];
+    }
+    h->s = s; h->n = (uint32_t)n;
+    h->d_pos = upload(pos, s->stream);
+    h->d_buf = (uint32_t *)rt::dmalloc((size_t)2 * n * 4);
+    rt::dmemset(h->d_buf, 0, (size_t)2 * n * 4, s->stream);
+    rt::stream_sync(s->stream);
+  });
+  if (rc != DWX_OK) return rc;
+  *out = h.release();
+  return DWX_OK;
+}
+
+void dwx_halo_destroy(dwx_halo *h) { delete h; }
+
+int dwx_halo_buffer(dwx_halo *h, void **dev_ptr, uint64_t *nbytes) {
+  if (!h || !dev_ptr || !nbytes) return fail(DWX_E_INVALID, "null argument");
+  *dev_ptr = h->d_buf;
+  *nbytes = (uint64_t)2 * h->n * 4;
+  return DWX_OK;
+}
+
+namespace {
+int halo_move(dwx_halo *h, int chains, bool pack) {
+  if (!h) return fail(DWX_E_INVALID, "null halo list");
+  if (chains < 1 || chains > 3) return fail(DWX_E_INVALID, "chains: bit 0 = free chain, bit 1 = evidence chain");
+  if (!h->n) return DWX_OK;
+  return guarded([&]() {
+    dwx_sampler *s = h->s;
+    rt::set_device(s->device);
+    const unsigned grid = std::min<unsigned>((h->n + BLOCK_THREADS - 1) / BLOCK_THREADS, 4096u);
+    if (pack)
+      rt::launch(halo_pack_kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)h->d_pos, h->n,
+                 (const uint32_t *)s->d_assign_free, (const uint32_t *)s->d_assign_evid, (uint32_t)chains, h->d_buf);
+    else
+      rt::launch(halo_unpack_kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)h->d_pos, h->n,
+                 s->d_assign_free, s->d_assign_evid, (uint32_t)chains, (const uint32_t *)h->d_buf);
+  });
+}
+}  // namespace
+
+int dwx_halo_pack_async(dwx_halo *h, int chains) { return halo_move(h, chains, true); }
+int dwx_halo_unpack_async(dwx_halo *h, int chains) { return halo_move(h, chains, false); }
 
 int dwx_stream(dwx_sampler *s, void **stream) {
   if (!s || !stream) return fail(DWX_E_INVALID, "null argument");

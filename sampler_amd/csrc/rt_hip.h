@@ -32,6 +32,11 @@ inline void init_device(int dev) {
   DWX_HIP(hipSetDevice(dev));
 }
 inline void set_device(int dev) { DWX_HIP(hipSetDevice(dev)); }
+inline int device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  return n;
+}
 
 inline void *dmalloc(size_t n) {
   void *p = nullptr;

@@ -1895,6 +1895,33 @@ average_weights_kernel(double *weights, float *w32, const uint8_t *w_fixed, cons
   }
 }
 
+// Halo exchange (multi-GPU, cross-shard factors): gather the listed variables' assignments of
+// the selected chains into a contiguous buffer [chain][i] (what a peer receives), and the
+// reverse for the ghosts.  pos = device positions; chains = bit 0 free, bit 1 evidence chain;
+// the buffer holds the selected chains back to back.
+__global__ void __launch_bounds__(BLOCK_THREADS)
+halo_pack_kernel(const uint32_t *pos, uint32_t n, const uint32_t *assign_free, const uint32_t *assign_evid,
+                 uint32_t chains, uint32_t *buf) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t second = (chains & 1u) ? n : 0u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t p = pos[i];
+    if (chains & 1u) buf[i] = assign_free[p];
+    if (chains & 2u) buf[second + i] = assign_evid[p];
+  }
+}
+__global__ void __launch_bounds__(BLOCK_THREADS)
+halo_unpack_kernel(const uint32_t *pos, uint32_t n, uint32_t *assign_free, uint32_t *assign_evid,
+                   uint32_t chains, const uint32_t *buf) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t second = (chains & 1u) ? n : 0u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t p = pos[i];
+    if (chains & 1u) assign_free[p] = buf[i];
+    if (chains & 2u) assign_evid[p] = buf[second + i];
+  }
+}
+
 // test hook: the raw Philox4x32-10 block function and the two uniforms drawn from it, on the
 // device (Random123 known-answer vectors; tests/test_philox_kat.py)
 __global__ void test_philox_kernel(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,

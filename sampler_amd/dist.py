@@ -229,6 +229,17 @@ class HipEngine:
         """device positions of local variable ids (index into assign_tensor)."""
         return torch.as_tensor(self.s.graph.positions(local_vids).astype(np.int64), device=self.grad.device)
 
+    def halo_list(self, local_vids):
+        """One side of the halo exchange with one peer: dwx_halo_* list + a tensor view of its
+        device buffer for the point-to-point call."""
+        from . import dwx
+        h = dwx.HaloList(self.s, local_vids)
+        ptr, nbytes = h.buffer()
+        holder = _CudaArray(ptr, max(nbytes, 4), "<i4", 4)
+        h._holder = holder
+        h.tensor = torch.as_tensor(holder, device=self.grad.device)[:nbytes // 4]
+        return h
+
     def stream_context(self):
         return torch.cuda.stream(self.stream)
 
@@ -259,44 +270,39 @@ class HaloExchange:
         wanted = [ghosts[owner == k] for k in range(world)]        # ascending global ids
         all_wanted = [None] * world
         dist.all_gather_object(all_wanted, wanted, group=group)     # setup only (host)
-        self.send_pos, self.recv_pos = {}, {}
+        # one halo list per peer and direction: the engine gathers / scatters through it on its
+        # own stream (HipEngine: dwx_halo_pack_async / dwx_halo_unpack_async of the C ABI) and
+        # owns the buffer -- [chain 0 values | chain 1 values], persistent
+        self.send, self.recv = {}, {}
         for k in range(world):
             if k == rank:
                 continue
             theirs = np.asarray(all_wanted[k][rank], np.int64)     # my owned vars peer k ghosts
             if len(theirs):
-                self.send_pos[k] = engine.positions((theirs - begin).astype(np.uint64))
+                self.send[k] = engine.halo_list((theirs - begin).astype(np.uint64))
             mine = wanted[k]
             if len(mine):
                 local = n_owned + np.searchsorted(ghosts, mine)
-                self.recv_pos[k] = engine.positions(local.astype(np.uint64))
-        self.n_boundary = sum(len(v) for v in self.send_pos.values())
-        self.n_ghost = sum(len(v) for v in self.recv_pos.values())
-        a = engine.assign_tensor("free")
-        # persistent buffers: [chain 0 values | chain 1 values] per peer
-        self.send_buf = {k: torch.empty(2 * len(p), dtype=a.dtype, device=a.device) for k, p in self.send_pos.items()}
-        self.recv_buf = {k: torch.empty(2 * len(p), dtype=a.dtype, device=a.device) for k, p in self.recv_pos.items()}
+                self.recv[k] = engine.halo_list(local.astype(np.uint64))
+        self.n_boundary = sum(h.n for h in self.send.values())
+        self.n_ghost = sum(h.n for h in self.recv.values())
         self.bytes_per_exchange = 0      # of the last exchange: sent + received by this rank
 
     def exchange(self, chains=("free", "evid")):
         nc = len(chains)
+        mask = (1 if "free" in chains else 0) | (2 if "evid" in chains else 0)
         with self.e.stream_context():
-            views = [self.e.assign_tensor(c) for c in chains]
             ops = []
-            for k, pos in self.send_pos.items():
-                n = len(pos)
-                for c, a in enumerate(views):
-                    torch.index_select(a, 0, pos, out=self.send_buf[k][c * n:(c + 1) * n])
-                ops.append(dist.P2POp(dist.isend, self.send_buf[k][:nc * n], k, group=self.group))
-            for k, pos in self.recv_pos.items():
-                ops.append(dist.P2POp(dist.irecv, self.recv_buf[k][:nc * len(pos)], k, group=self.group))
+            for k, h in self.send.items():
+                h.pack(mask)
+                ops.append(dist.P2POp(dist.isend, h.tensor[:nc * h.n], k, group=self.group))
+            for k, h in self.recv.items():
+                ops.append(dist.P2POp(dist.irecv, h.tensor[:nc * h.n], k, group=self.group))
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
-            for k, pos in self.recv_pos.items():
-                n = len(pos)
-                for c, a in enumerate(views):
-                    a.index_copy_(0, pos, self.recv_buf[k][c * n:(c + 1) * n])
+            for h in self.recv.values():
+                h.unpack(mask)
         self.bytes_per_exchange = 4 * nc * (self.n_boundary + self.n_ghost)
 
 

@@ -24,13 +24,14 @@ SYMBOLS = [
     "dwx_last_error", "dwx_version", "dwx_default_options",
     "dwx_graph_create", "dwx_graph_destroy", "dwx_graph_get_info", "dwx_graph_get_schedule",
     "dwx_graph_get_values", "dwx_graph_get_positions", "dwx_graph_get_index",
-    "dwx_sampler_create", "dwx_device_init", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
+    "dwx_sampler_create", "dwx_device_init", "dwx_device_count", "dwx_buffer_copy", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
     "dwx_wait", "dwx_sgd_plan", "dwx_sgd_curvature", "dwx_sgd_plan_rows", "dwx_sgd_plan_force_dynamic", "dwx_sgd_get_chunks", "dwx_sgd_accumulate_async",
     "dwx_sgd_apply_async", "dwx_sgd_finish",
     "dwx_get_weights", "dwx_set_weights", "dwx_average_weights_async",
     "dwx_clear_tallies", "dwx_get_tallies",
     "dwx_get_assignments", "dwx_set_assignments", "dwx_get_sweep", "dwx_set_sweep",
-    "dwx_device_buffer", "dwx_stream", "dwx_kernel_time", "dwx_kernel_time_reset",
+    "dwx_device_buffer", "dwx_halo_create", "dwx_halo_destroy", "dwx_halo_buffer", "dwx_halo_pack_async",
+    "dwx_halo_unpack_async", "dwx_stream", "dwx_kernel_time", "dwx_kernel_time_reset",
     "dwx_test_factor_sign", "dwx_test_philox",
 ]
 
@@ -87,6 +88,8 @@ class Library:
         L.dwx_graph_get_positions.argtypes = [vp, vp, u64, vp]
         L.dwx_sampler_create.argtypes = [vp, vp, vp]
         L.dwx_device_init.argtypes = [C.c_int32]
+        L.dwx_device_count.argtypes = [vp]
+        L.dwx_buffer_copy.argtypes = [vp, vp, vp, u64, i32]
         L.dwx_sampler_destroy.argtypes = [vp]; L.dwx_sampler_destroy.restype = None
         L.dwx_sample_async.argtypes = [vp]
         L.dwx_sample_sgd_async.argtypes = [vp, dbl]
@@ -108,6 +111,11 @@ class Library:
         L.dwx_get_sweep.argtypes = [vp, vp]; L.dwx_set_sweep.argtypes = [vp, u64]
         L.dwx_device_buffer.argtypes = [vp, i32, vp, vp]
         L.dwx_stream.argtypes = [vp, vp]
+        L.dwx_halo_create.argtypes = [vp, vp, u64, vp]
+        L.dwx_halo_destroy.argtypes = [vp]; L.dwx_halo_destroy.restype = None
+        L.dwx_halo_buffer.argtypes = [vp, vp, vp]
+        L.dwx_halo_pack_async.argtypes = [vp, i32]
+        L.dwx_halo_unpack_async.argtypes = [vp, i32]
         L.dwx_kernel_time.argtypes = [vp, i32, vp, vp, vp]
         L.dwx_kernel_time_reset.argtypes = [vp, i32]
         L.dwx_test_factor_sign.argtypes = [i32, i32, u64, vp, vp]
@@ -358,6 +366,36 @@ class GibbsSampler:
                 for j in range(int(raw.var_cardinality[v])):
                     out.append("%d %d %s\n" % (v, int(sparse[b + j]), fmt_g(_div(t[b + j], n[v]))))
         return "".join(out)
+
+
+class HaloList:
+    """One side of a halo exchange with one peer (dwx_halo_*): the listed local variables'
+    assignments are packed into / unpacked from a device buffer on the sampler's stream."""
+    FREE, EVID = 1, 2
+
+    def __init__(self, sampler: GibbsSampler, local_vids):
+        self.lib, self.sampler = sampler.lib, sampler
+        v = np.ascontiguousarray(local_vids, np.uint64)
+        self.n = len(v)
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.dwx_halo_create(sampler.h, v.ctypes.data, len(v), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.L.dwx_halo_destroy(self.h)
+            self.h = None
+
+    def buffer(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self.lib.check(self.lib.L.dwx_halo_buffer(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def pack(self, chains):
+        self.lib.check(self.lib.L.dwx_halo_pack_async(self.h, int(chains)))
+
+    def unpack(self, chains):
+        self.lib.check(self.lib.L.dwx_halo_unpack_async(self.h, int(chains)))
 
 
 def _div(a, b):

@@ -50,6 +50,22 @@ def main():
     assert np.array_equal(ev[pos].cpu().numpy().astype(np.uint64), a.assignments("evid")[:10])
     ev[pos] = 1 - ev[pos]                       # write through the view = what a halo scatter does
     torch.cuda.synchronize()
+    # the halo lists of the C ABI (dwx_halo_*): gather both chains of 1000 scattered variables
+    # into the list's device buffer on the sampler's stream, change them, scatter them back
+    ids = np.arange(3, 200_000, 199, dtype=np.uint64)[:1000]
+    h = eng.halo_list(ids)
+    assert h.n == 1000 and h.tensor.numel() == 2000 and h.tensor.dtype == torch.int32
+    fr0, ev0 = a.assignments("free")[ids.astype(np.int64)], a.assignments("evid")[ids.astype(np.int64)]
+    h.pack(3); a.wait()
+    assert np.array_equal(h.tensor[:1000].cpu().numpy().astype(np.uint64), fr0)
+    assert np.array_equal(h.tensor[1000:].cpu().numpy().astype(np.uint64), ev0)
+    h.pack(2); a.wait()                         # one chain: its values come first
+    assert np.array_equal(h.tensor[:1000].cpu().numpy().astype(np.uint64), ev0)
+    with eng.stream_context():
+        h.tensor[:1000] = 1 - h.tensor[:1000]
+    h.unpack(2); a.wait()
+    assert np.array_equal(a.assignments("evid")[ids.astype(np.int64)], 1 - ev0)
+    assert np.array_equal(a.assignments("free")[ids.astype(np.int64)], fr0)
     assert np.array_equal(a.assignments("evid")[:10], 1 - b.assignments("evid")[:10])
     # split learning sweeps through the collective path: per-chunk static counts are sized and
     # "summed" (world size 1) once per batch count, every chunk is accumulate -> all-reduce ->

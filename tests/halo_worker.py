@@ -82,6 +82,28 @@ class OracleShardEngine:
         import contextlib
         return contextlib.nullcontext()
 
+    def halo_list(self, local_vids):
+        return _HostHaloList(self, np.asarray(local_vids, np.int64))
+
+
+class _HostHaloList:
+    """HipEngine.halo_list's interface on the oracle's host arrays."""
+
+    def __init__(self, engine, ids):
+        self.e, self.pos, self.n = engine, torch.as_tensor(ids), len(ids)
+        self.tensor = torch.zeros(2 * len(ids), dtype=torch.int64)
+
+    def _views(self, mask):
+        return [self.e._views[c] for c, bit in (("free", 1), ("evid", 2)) if mask & bit]
+
+    def pack(self, mask):
+        for c, a in enumerate(self._views(mask)):
+            self.tensor[c * self.n:(c + 1) * self.n] = a[self.pos]
+
+    def unpack(self, mask):
+        for c, a in enumerate(self._views(mask)):
+            a[self.pos] = self.tensor[c * self.n:(c + 1) * self.n]
+
 
 def build(total):
     return synthetic.cfg3b(total, n_weights=30, seed=RNG_SEED, offsets=[1, 7, 101, total // 8 + 3])

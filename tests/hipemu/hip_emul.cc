@@ -5,6 +5,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <vector>
 
@@ -75,6 +76,10 @@ unsigned long long ballot(bool pred) {
 }
 
 void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::function<void()> &body) {
+  // one launch at a time: the emulated "device" state above is global, and the multi-rank host
+  // drivers (dw gibbs --gpus N: one host thread per rank) launch from several threads
+  static std::mutex one_launch;
+  std::lock_guard<std::mutex> hold(one_launch);
   if (g_fibers.size() < block) {
     size_t old = g_fibers.size();
     g_fibers.resize(block);

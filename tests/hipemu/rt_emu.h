@@ -21,6 +21,7 @@ inline void init_device(int dev) {
   if (dev != 0) throw std::runtime_error("emulated device ordinal must be 0");
 }
 inline void set_device(int) {}
+inline int device_count() { return 1; }
 inline void *dmalloc(size_t n) { return malloc(n ? n : 16); }
 inline void dfree(void *p) { free(p); }
 inline void h2d(void *d, const void *h, size_t n, stream_t) { if (n) memcpy(d, h, n); }

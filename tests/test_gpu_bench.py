@@ -40,7 +40,8 @@ def test_bench_single_process_small():
     sec = d["roofline"]["secondary"]
     assert sec["bound"] == "l2_req" and sec["peak"] > 0 and 0 < sec["frac"] < 1.5
     assert "this run" in sec["peak_source"]
-    assert d["rccl_ranks"] is None and d["timed_seconds"] >= 0.4
+    # (200k variables: a block of 3 steps takes 0.2 ms, so the repeat cap ends the run, not --min-time)
+    assert d["rccl_ranks"] is None and (d["timed_seconds"] >= 0.4 or d["repeats"] == 200)
 
 
 @pytest.mark.gpu
