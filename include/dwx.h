@@ -80,6 +80,9 @@ typedef struct dwx_compile_opts {
   uint32_t n_threads;          /* host threads for the build (0 = all cores)           */
   uint32_t no_compact_records; /* 1: keep 16-byte records even for all-unary graphs
                                   (default 0: such graphs stream 8-byte records)       */
+  uint32_t wide_min_records;   /* degree binning: a variable with more edge records than this
+                                  is walked by a whole wave instead of one lane (default 192;
+                                  0xFFFFFFFF: never)                                   */
 } dwx_compile_opts;
 
 typedef struct dwx_graph_info {
@@ -89,12 +92,14 @@ typedef struct dwx_graph_info {
                                   (== FactorGraph size.num_values)                     */
   uint64_t num_index_entries;  /* |factor_index| after dedup (src/factor_graph.cc:177) */
   uint64_t num_vif_entries;    /* factor->variable entries kept for arity >= 2         */
-  uint64_t num_colors, num_launches, num_tiles, num_giant_tiles;
+  uint64_t num_colors, num_launches, num_tiles, num_giant_tiles;   /* giant: workgroup-per-variable */
   uint64_t max_cardinality;
   uint64_t num_query_variables; /* non-evidence variables (sampled by an inference sweep
                                    unless --sample_evidence)                            */
   uint64_t device_bytes;       /* bytes the sampler will hold in HBM                   */
   uint32_t has_categorical, order_is_identity;
+  uint64_t num_wide_tiles;     /* variables walked by a wave each (degree bin, see
+                                  dwx_compile_opts.wide_min_records)                   */
 } dwx_graph_info;
 
 /* Runtime options of one sampler (the CmdParser fields the hot path reads:

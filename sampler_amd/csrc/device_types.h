@@ -97,6 +97,17 @@ constexpr uint32_t TILE_TERMS2 = 1u << 3;
 // TILE_TERMS2 tile whose arity-2 records are EDGE_INLINE2 (only handed to kernels built with
 // K <= 6, the ones that implement TILE_TERMS2)
 constexpr uint32_t TILE_INLINE2 = 1u << 4;
+// Tiles the LDS sweep kernels skip -- ONE variable each, processed straight from HBM by a
+// cooperating group of lanes (degree-binned execution):
+//   TILE_GIANT  rows > rcap or records > ecap: does not fit a tile at all; a whole workgroup
+//               per variable (giant_kernel)
+//   TILE_WIDE   fits, but has more than wide_min_records records (a lane-per-variable walk
+//               would serialise them while its 255 neighbours idle); one WAVE per variable,
+//               four variables per workgroup (wide_kernel)
+constexpr uint32_t TILE_GIANT = 1u << 5;
+constexpr uint32_t TILE_WIDE = 1u << 6;
+constexpr uint32_t TILE_OUTSIDE = TILE_GIANT | TILE_WIDE;
+constexpr uint32_t WIDE_MIN_RECORDS_DEFAULT = 192;
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
 
 // v_meta bits

@@ -105,7 +105,7 @@ struct dwx_sampler {
   uint32_t *d_v_meta = nullptr, *d_v_orig = nullptr, *d_v_row = nullptr, *d_v_init = nullptr;
   uint32_t *d_row_ptr = nullptr;
   TileDesc *d_tiles = nullptr;
-  uint32_t *d_giant = nullptr;
+  uint32_t *d_giant = nullptr, *d_wide = nullptr;
   int stage_k = 12;
   // learning-sweep plan (dwx_sgd_plan)
   struct Chunk { uint32_t launch, t0, t1; };
@@ -190,7 +190,7 @@ struct dwx_sampler {
   ~dwx_sampler() {
     for (auto &sp : spans) { rt::event_destroy(sp.a); rt::event_destroy(sp.b); rt::event_destroy(sp.c); }
     rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
-    rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
+    rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_wide); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
     rt::dfree(d_edges); rt::dfree(d_edges8); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
     rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_terms); rt::dfree(d_delta);
     rt::dfree(d_w_fixed); rt::dfree(d_grad);
@@ -223,6 +223,7 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   const bool slim = LEARN && rec8 && s->all_pull && !(P.flags & OPT_NO_PULL);
   const unsigned grid = std::min<unsigned>(t1 - t0, tab8 ? s->persistent_blocks_tab : slim ? s->persistent_blocks_pull :
                                            (rec8 ? s->persistent_blocks8 : s->persistent_blocks)[LEARN ? 1 : 0]);
+  // (all-unary graphs stage 8-byte terms whenever the compute phase needs no record)
   const size_t lds = tab8 ? s->lds_tab : slim ? s->lds_learn_pull : s->lds_bytes[LEARN ? 1 : 0];
   constexpr int RPC = (int)ROWPTR_UNROLL_CAT;
   if (rec8 && s->rp_cat) {
@@ -261,6 +262,16 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   if (g1 > g0) {
     rt::launch(giant_kernel<LEARN>, g1 - g0, BLOCK_THREADS, 0, s->stream, P,
                (const uint32_t *)(s->d_giant + g0), g1 - g0);
+    ++launches;
+  }
+  // mid-degree variables among these tiles: a wave each
+  const uint32_t *wb = c.wide_tiles.data() + c.launch_wide[l], *we = c.wide_tiles.data() + c.launch_wide[l + 1];
+  const uint32_t w0 = (uint32_t)(std::lower_bound(wb, we, t0) - c.wide_tiles.data());
+  const uint32_t w1 = (uint32_t)(std::lower_bound(wb, we, t1) - c.wide_tiles.data());
+  if (w1 > w0) {
+    const uint32_t per_block = BLOCK_THREADS / 64u;
+    rt::launch(wide_kernel<LEARN>, (w1 - w0 + per_block - 1) / per_block, BLOCK_THREADS, 0, s->stream, P,
+               (const uint32_t *)(s->d_wide + w0), w1 - w0);
     ++launches;
   }
   return launches;
@@ -485,7 +496,7 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
           for (uint64_t ti = tb; ti < te; ++ti) {
             const TileDesc &td = c.tiles[ti];
             if (!(td.flags & TILE_PULL)) continue;
-            if (td.nrows > c.rcap || td.nedges > c.ecap) continue;   // oversized: giant_kernel, atomics
+            if (td.flags & TILE_OUTSIDE) continue;   // giant_kernel / wide_kernel: atomics
             for (uint32_t l = 0; l < td.nv; ++l) {
               const uint32_t p = td.v0 + l, m = c.v_meta[p];
               if (!(o.learn_non_evidence || (!o.noise_aware && (m & VM_EVIDENCE)))) continue;
@@ -1030,6 +1041,7 @@ int dwx_graph_get_info(const dwx_graph *g, dwx_graph_info *out) {
   out->num_values = c.R; out->num_index_entries = c.NIdx; out->num_vif_entries = c.NVif;
   out->num_colors = c.n_colors; out->num_launches = c.launch_off.size() - 1;
   out->num_tiles = c.tile_v.size() - 1; out->num_giant_tiles = c.n_giant_tiles;
+  out->num_wide_tiles = c.n_wide_tiles;
   out->max_cardinality = c.max_card; out->device_bytes = c.device_bytes();
   out->num_query_variables = c.n_query;
   out->has_categorical = c.has_categorical; out->order_is_identity = c.order_is_identity;
@@ -1108,6 +1120,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       s->d_tiles = upload(tiles, st);
     }
     s->d_giant = upload(c.giant_tiles, st);
+    s->d_wide = upload(c.wide_tiles, st);
     if (!c.row_truth.empty()) s->d_row_truth = upload(c.row_truth, st);
     if (!c.edge_fval64.empty()) s->d_edge_fval64 = upload(c.edge_fval64, st);
     s->d_edges = upload(c.edges, st, 1);
@@ -1197,8 +1210,9 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     if (s->rec8) {
       s->all_pull = P.lds_agg_off == 0;   // (TILE_PULL implies it; a graph of oversized variables only has no such tile)
       for (const TileDesc &td : c.tiles)
-        if (td.nrows <= c.rcap && td.nedges <= c.ecap && !(td.flags & TILE_PULL)) { s->all_pull = false; break; }
-      s->lds_learn_pull = s->lds_bytes[0];
+        if (!(td.flags & TILE_OUTSIDE) && !(td.flags & TILE_PULL)) { s->all_pull = false; break; }
+      s->lds_tab = P.lds_edge_off + (size_t)s->stage_k * BLOCK_THREADS * 8;
+      s->lds_learn_pull = s->lds_tab;
       auto prepare8 = [&](auto infer, auto learn) {
         rt::allow_dynamic_lds(infer, s->lds_bytes[0]);
         rt::allow_dynamic_lds(learn, s->lds_bytes[1]);
@@ -1206,7 +1220,6 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
         s->persistent_blocks8[1] = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_bytes[1]);
         s->persistent_blocks_pull = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_learn_pull);
       };
-      s->lds_tab = P.lds_edge_off + (size_t)s->stage_k * BLOCK_THREADS * 8;
       auto prepare_tab = [&](auto tab) {
         rt::allow_dynamic_lds(tab, s->lds_tab);
         s->persistent_blocks_tab = rt::resident_blocks(tab, BLOCK_THREADS, s->lds_tab);

@@ -455,6 +455,10 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     g.rcap = o.tile_rows ? o.tile_rows : (g.has_categorical ? 1536 : g.tile_vars);
     if (g.rcap < g.tile_vars && !g.has_categorical) g.rcap = g.tile_vars;
     g.tile_v.clear(); g.launch_tile.clear(); g.launch_query_tile_end.clear();
+    // degree binning: a variable with more records than this leaves the lane-per-variable tiles
+    // and is walked by a whole wave (TILE_WIDE); 0xFFFFFFFF switches the bin off
+    g.wide_min = o.wide_min_records ? o.wide_min_records : WIDE_MIN_RECORDS_DEFAULT;
+    std::vector<uint8_t> tile_wide;
     const uint64_t nl = g.launch_off.size() - 1;
     const uint32_t kTypeMask = VM_CATEGORICAL | VM_EVIDENCE;
     for (uint64_t l = 0; l < nl; ++l) {
@@ -469,14 +473,19 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
           g.launch_query_tile_end.push_back((uint32_t)g.tile_v.size());
         }
         uint64_t rows = 0, edges = 0;
+        bool wide = false;
         while (p < pend && p - t0 < g.tile_vars && (g.v_meta[p] & kTypeMask) == type) {
           uint64_t nr = g.v_row[p + 1] - g.v_row[p];
           uint64_t ne = g.row_ptr[g.v_row[p + 1]] - g.row_ptr[g.v_row[p]];
-          if (p > t0 && (rows + nr > g.rcap || edges + ne > g.ecap)) break;
+          const bool alone = ne > g.wide_min;      // mid- or high-degree: a tile of its own
+          if (p > t0 && (alone || rows + nr > g.rcap || edges + ne > g.ecap)) break;
           rows += nr; edges += ne; ++p;
           if (rows > g.rcap || edges > g.ecap) break;   // oversized single variable
+          if (alone) { wide = true; break; }
         }
-        if (rows > g.rcap || edges > g.ecap) ++g.n_giant_tiles;
+        if (rows > g.rcap || edges > g.ecap) { ++g.n_giant_tiles; wide = false; }
+        if (wide) ++g.n_wide_tiles;
+        tile_wide.push_back(wide ? 1 : 0);
         g.tile_v.push_back((uint32_t)t0);
       }
       if (!seen_evid) g.launch_query_tile_end.push_back((uint32_t)g.tile_v.size());
@@ -500,14 +509,16 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
         terms2 = terms2 && (pre || (((pk >> EDGE_ARITY_SHIFT) & EDGE_ARITY_MASK) == 2 && !(pk & EDGE_F64_FLAG)));
       }
       const bool cat = g.v_meta[v0] & VM_CATEGORICAL;
-      t.flags = (simple ? TILE_SIMPLE : 0u) | (cat ? TILE_CATEGORICAL : 0u) |
-                ((simple && !cat && W > LDS_AGG_MAX_W) ? TILE_PULL : 0u) |
-                ((terms2 && !simple && !cat && t.nv <= 256) ? TILE_TERMS2 : 0u);
+      const bool giant = t.nrows > g.rcap || t.nedges > g.ecap;
+      const uint32_t outside = giant ? TILE_GIANT : (tile_wide[i] ? TILE_WIDE : 0u);
+      t.flags = (simple ? TILE_SIMPLE : 0u) | (cat ? TILE_CATEGORICAL : 0u) | outside |
+                ((simple && !cat && W > LDS_AGG_MAX_W && !outside) ? TILE_PULL : 0u) |
+                ((terms2 && !simple && !cat && t.nv <= 256 && !outside) ? TILE_TERMS2 : 0u);
       if (t.flags & TILE_TERMS2) ++n_terms2;
       // arity-2 records carry their two vif entries themselves where the kernels that will
       // see the tile implement it (the K <= 6 builds; not the oversized-variable kernel) and
       // the predicates fit 7 bits
-      if ((t.flags & TILE_TERMS2) && g.ecap <= 6 * BLOCK_THREADS && t.nrows <= g.rcap && t.nedges <= g.ecap) {
+      if ((t.flags & TILE_TERMS2) && g.ecap <= 6 * BLOCK_THREADS) {
         bool ok = true;
         for (uint32_t e = t.e0; e < t.e0 + t.nedges && ok; ++e) {
           const EdgeRec &r = g.edges[e];
@@ -565,12 +576,19 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       }
     }
     g.giant_tiles.clear(); g.launch_giant.clear(); g.launch_giant_query_end.clear();
+    g.wide_tiles.clear(); g.launch_wide.clear();
+    for (uint64_t l = 0; l < nl; ++l) {
+      g.launch_wide.push_back((uint32_t)g.wide_tiles.size());
+      for (uint32_t i = g.launch_tile[l]; i < g.launch_tile[l + 1]; ++i)
+        if (g.tiles[i].flags & TILE_WIDE) g.wide_tiles.push_back(i);
+    }
+    g.launch_wide.push_back((uint32_t)g.wide_tiles.size());
     for (uint64_t l = 0; l < nl; ++l) {
       g.launch_giant.push_back((uint32_t)g.giant_tiles.size());
       bool closed = false;
       for (uint32_t i = g.launch_tile[l]; i < g.launch_tile[l + 1]; ++i) {
         if (i == g.launch_query_tile_end[l]) { g.launch_giant_query_end.push_back((uint32_t)g.giant_tiles.size()); closed = true; }
-        if (g.tiles[i].nrows > g.rcap || g.tiles[i].nedges > g.ecap) g.giant_tiles.push_back(i);
+        if (g.tiles[i].flags & TILE_GIANT) g.giant_tiles.push_back(i);
       }
       if (!closed) g.launch_giant_query_end.push_back((uint32_t)g.giant_tiles.size());
     }

@@ -55,6 +55,9 @@ struct CompiledGraph {
   std::vector<uint32_t> giant_tiles;  // indices of oversized tiles, launch-major
   std::vector<uint32_t> launch_giant; // [n_launches+1] into giant_tiles
   std::vector<uint32_t> launch_giant_query_end; // [n_launches]
+  std::vector<uint32_t> wide_tiles;   // indices of TILE_WIDE tiles, launch-major
+  std::vector<uint32_t> launch_wide;  // [n_launches+1] into wide_tiles
+  uint32_t n_wide_tiles = 0, wide_min = 0;
   std::vector<uint32_t> launch_tile;  // [n_launches+1] into tile_v
   std::vector<uint32_t> launch_query_tile_end;  // [n_launches] end of the query-variable tiles
   std::vector<uint64_t> launch_off;   // [n_launches+1] variable positions

@@ -354,7 +354,23 @@ DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const Vif
 //              two potential terms (w*(s1*f), w*(s0*f)); the row walk only adds
 //   W_TERMS8   (inference on the 8-byte terms table) the table's entries as they are: w * f with
 //              the two sign codes in its lowest mantissa bits; the row walk decodes and adds
-enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4 };
+//   W_COOP     (wide_kernel) a whole WAVE walks one variable straight from HBM: lane l takes
+//              records l, l + 64, ... of a row, the 64 partial sums are combined by a butterfly
+//              (all lanes get the total); every lane then follows the same decisions, side
+//              effects happen once
+enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4, W_COOP = 5 };
+
+// sum over the 64 lanes of a wave, the same value (and the same association: the xor
+// butterfly) in every lane
+#ifndef DWX_WAVE_SUM_F64
+DWX_DEV double wave_sum_f64(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+#define DWX_WAVE_SUM_F64(v) wave_sum_f64(v)
+#endif
+DWX_DEV uint32_t wave_lane() { return threadIdx.x & 63u; }
 
 struct alignas(16) EdgeTerms { double t1, t0; };
 // Table entry of a record of a TILE_INLINE2 tile (build_terms_kernel), overlaying an EdgeRec:
@@ -471,6 +487,13 @@ template <int WMODE, bool SIMPLE>
 DWX_DEV double range_potential(const KernelParams &P, const TileView &T, uint32_t es, uint32_t ee,
                                const uint32_t *assign, uint32_t me, uint32_t proposal) {
   double pot = 0.0;
+  if (WMODE == W_COOP) {
+    for (uint32_t e = es + wave_lane(); e < ee; e += 64u) {
+      const EdgeRec er = T.edges[e - T.edge_bias];
+      pot += (double)P.w32[er.wid] * edge_term<SIMPLE>(P, er, e, assign, me, proposal, true);
+    }
+    return DWX_WAVE_SUM_F64(pot);
+  }
   if (WMODE == W_TERMS8) {
     const unsigned long long *tab = (const unsigned long long *)T.edges;
     if (ee - es == 1u) return pot + terms8_hit(tab[es - T.edge_bias]);
@@ -520,6 +543,16 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
                              const uint32_t *assign, uint32_t me, double &pp, double &pn) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   pp = 0.0; pn = 0.0;
+  if (WMODE == W_COOP) {
+    for (uint32_t e = es + wave_lane(); e < ee; e += 64u) {
+      const EdgeRec er = T.edges[e - T.edge_bias];
+      const double w = (double)P.w32[er.wid];
+      pp += w * edge_term<SIMPLE>(P, er, e, assign, me, 1u, true);
+      pn += w * edge_term<SIMPLE>(P, er, e, assign, me, 0u, false);
+    }
+    pp = DWX_WAVE_SUM_F64(pp); pn = DWX_WAVE_SUM_F64(pn);
+    return;
+  }
   if (WMODE == W_TERMS8) {
     const unsigned long long *tab = (const unsigned long long *)T.edges;
     for (uint32_t e = es; e < ee; e += WALK_BATCH) {
@@ -617,6 +650,19 @@ DWX_DEV void bool_potentials_both(const KernelParams &P, const TileView &T, uint
                                   double &ppf, double &pnf, double &ppe, double &pne) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   ppf = 0.0; pnf = 0.0; ppe = 0.0; pne = 0.0;
+  if (WMODE == W_COOP) {
+    for (uint32_t e = es + wave_lane(); e < ee; e += 64u) {
+      const EdgeRec er = T.edges[e - T.edge_bias];
+      const double w = (double)P.w32[er.wid];
+      ppf += w * edge_term<false>(P, er, e, P.assign_free, me, 1u, true);
+      pnf += w * edge_term<false>(P, er, e, P.assign_free, me, 0u, false);
+      ppe += w * edge_term<false>(P, er, e, P.assign_evid, me, 1u, true);
+      pne += w * edge_term<false>(P, er, e, P.assign_evid, me, 0u, false);
+    }
+    ppf = DWX_WAVE_SUM_F64(ppf); pnf = DWX_WAVE_SUM_F64(pnf);
+    ppe = DWX_WAVE_SUM_F64(ppe); pne = DWX_WAVE_SUM_F64(pne);
+    return;
+  }
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     const double w = edge_weight<WMODE>(P, T, er, e);
@@ -777,12 +823,13 @@ DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row
 // static and were folded into T_static on the host (dwx_sampler_create).
 // hit_value: the proposal that "hits" a pre-signed record of this row (1 for a boolean
 // variable, the row's value for a categorical one).
-template <bool SIMPLE>
+// COOP: the 64 lanes of the wave share the row's records (wide_kernel).
+template <bool SIMPLE, bool COOP = false>
 DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uint32_t me,
                      uint32_t evid_value, uint32_t free_value, uint32_t hit_value, double t,
                      const bool count_t) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
-  for (uint32_t e = es; e < ee; ++e) {
+  for (uint32_t e = es + (COOP ? wave_lane() : 0u); e < ee; e += (COOP ? 64u : 1u)) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     if (er.packed & EDGE_FIXED_FLAG) continue;   // weights_isfixed (src/factor_graph.cc:247)
     double pot_evid, pot_free;
@@ -854,6 +901,11 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
   const bool is_evid = meta & VM_EVIDENCE;
   const uint32_t card = meta >> VM_CARD_SHIFT;
   const uint32_t row0 = pre.row0;
+  // W_COOP: all 64 lanes of the wave run this function for the SAME variable; the potentials
+  // are wave-wide sums (identical in every lane), so every lane takes the same decisions;
+  // stores and tallies happen once, the gradient rows are shared out over the lanes
+  constexpr bool COOP = WMODE == W_COOP;
+  const bool leader = !COOP || wave_lane() == 0u;
   if (!LEARN) {
     // sample_single_variable (src/gibbs_sampler.h:151-169)
     if (is_evid && !(P.flags & OPT_SAMPLE_EVIDENCE)) return 0;
@@ -864,13 +916,13 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
       prop = bool_draw(A, pp, pn);
       // single owner per row: a no-return atomic is a fire-and-forget increment the
       // wave never waits for (a load-add-store would stall on the load)
-      if (prop) atomicAdd(&P.tally[row0], 1u);
+      if (prop && leader) atomicAdd(&P.tally[row0], 1u);
     } else {
       prop = cat_draw<WMODE, SIMPLE>(P, T, row0, card, P.assign_evid, p, A);
-      atomicAdd(&P.tally[row0 + prop], 1u);
+      if (leader) atomicAdd(&P.tally[row0 + prop], 1u);
     }
     // (a variable of an all-unary tile has no neighbours: nobody re-reads its assignment)
-    if (SIMPLE) DWX_NT_STORE(prop, &P.assign_evid[p]); else P.assign_evid[p] = prop;
+    if (SIMPLE) DWX_NT_STORE(prop, &P.assign_evid[p]); else if (leader) P.assign_evid[p] = prop;
     return 0;
   }
   // sample_sgd_single_variable (src/gibbs_sampler.h:127-149)
@@ -889,7 +941,7 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
   } else {
     p_free = cat_draw<WMODE, SIMPLE>(P, T, row0, card, P.assign_free, p, A);
   }
-  if (SIMPLE) DWX_NT_STORE(p_free, &P.assign_free[p]); else P.assign_free[p] = p_free;
+  if (SIMPLE) DWX_NT_STORE(p_free, &P.assign_free[p]); else if (leader) P.assign_free[p] = p_free;
   // evidence chain: sample_evid (src/gibbs_sampler.h:171-190)
   const uint32_t evid_value = pre.init;
   uint32_t p_evid;
@@ -910,7 +962,7 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
   } else {
     p_evid = cat_draw<WMODE, SIMPLE>(P, T, row0, card, P.assign_evid, p, B);
   }
-  if (SIMPLE) DWX_NT_STORE(p_evid, &P.assign_evid[p]); else P.assign_evid[p] = p_evid;
+  if (SIMPLE) DWX_NT_STORE(p_evid, &P.assign_evid[p]); else if (leader) P.assign_evid[p] = p_evid;
   // src/gibbs_sampler.h:144-146
   if (!(P.flags & OPT_LEARN_NON_EVIDENCE) &&
       ((!noise_aware && !is_evid) || (noise_aware && !has_truth)))
@@ -922,7 +974,7 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
     const bool dyn_t = P.flags & OPT_DYNAMIC_T;
     if (SIMPLE && !dyn_t && p_free == evid_value) return 0;
     if (SIMPLE && want_delta) return (int)p_free - (int)evid_value;
-    sgd_row<SIMPLE>(P, T, row0, p, evid_value, p_free, 1u, 1.0, dyn_t);
+    sgd_row<SIMPLE, COOP>(P, T, row0, p, evid_value, p_free, 1u, 1.0, dyn_t);
     return 0;
   }
   for (uint32_t val = 0; val < card; ++val) {
@@ -932,9 +984,9 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
       t = P.row_truth ? P.row_truth[row0 + val] : 0.0;
       if (is_linear_zero(t)) continue;
     }
-    sgd_row<SIMPLE>(P, T, row0 + val, p, val, p_free, val, t, true);
+    sgd_row<SIMPLE, COOP>(P, T, row0 + val, p, val, p_free, val, t, true);
     if (val == p_free) continue;
-    sgd_row<SIMPLE>(P, T, row0 + p_free, p, val, p_free, p_free, t, true);
+    sgd_row<SIMPLE, COOP>(P, T, row0 + p_free, p, val, p_free, p_free, t, true);
   }
   return 0;
 }
@@ -1081,8 +1133,9 @@ DWX_DEV TileDesc scalarise(const TileDesc &v) {
   return d;
 }
 
-DWX_DEV bool tile_fits(const KernelParams &P, const TileDesc &d) {
-  return d.nrows <= P.rcap && d.nedges <= P.ecap;
+// (TILE_GIANT / TILE_WIDE: one variable, processed by giant_kernel / wide_kernel)
+DWX_DEV bool tile_fits(const KernelParams &, const TileDesc &d) {
+  return !(d.flags & TILE_OUTSIDE);
 }
 
 // Branch-free on purpose: a predicated load compiles to a divergent branch with an
@@ -1407,8 +1460,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
 // awaited while staging (config 4: 0.296 -> 0.246 ms); boolean graphs keep 2 (the extra
 // loads cost config 3's repeated inference 15 %).
 // (3 workgroups per CU also when learning: pull-gradient tiles stage 16-byte terms only)
+#ifndef DWX_S8_INFER_WG
+#define DWX_S8_INFER_WG 3
+#endif
+#ifndef DWX_S8_LEARN_WG
+#define DWX_S8_LEARN_WG 4
+#endif
 template <bool LEARN, int K, bool TAB = false, int RP = (int)ROWPTR_UNROLL>
-__global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : 3) sweep8_kernel(const KernelParams P) {
+__global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN_WG : DWX_S8_INFER_WG)) sweep8_kernel(const KernelParams P) {
   static_assert(!(LEARN && TAB), "the terms table serves inference sweeps only");
   DWX_DYN_LDS(dyn_lds);
   uint32_t *s_rowptr = (uint32_t *)dyn_lds;
@@ -1447,11 +1506,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : 3) sweep8_kernel(cons
       philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
       if (TAB) {
         // the table's entries go to LDS as they are (8 bytes per record: half the staging
-        // area of the other modes, one more workgroup per CU); the row walk decodes them
+        // area of the 16-byte modes, more workgroups per CU); the row walk decodes them
         EdgeRec8 *s_tab = (EdgeRec8 *)s_edges;
 #pragma unroll
         for (int k = 0; k < K; ++k) s_tab[t + k * BLOCK_THREADS] = f.rec[k];
-      } else if (!LEARN || pull) {
+      } else if (!LEARN) {
         // the two potential terms of every record, edge-parallel and straight-line:
         // t1 = w * (sign(hit) * f), t0 = w * (sign(miss) * f) -- the products of
         // FactorGraph::potential (src/factor_graph.h:127-145)
@@ -1464,6 +1523,23 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : 3) sweep8_kernel(cons
           tt.t1 = wv * (double)rec8_signed((c.key >> REC8_HIT_SHIFT) & 3u, c.f);
           tt.t0 = wv * (double)rec8_signed((c.key >> REC8_MISS_SHIFT) & 3u, c.f);
           s_terms[t + k * BLOCK_THREADS] = tt;
+        }
+      } else if (pull) {
+        // learning, pull-gradient tile: the same terms in the terms table's own 8-byte form --
+        // the exact f64 product w * f (two f32 factors: at most 48 significant bits, its lowest
+        // mantissa bits are zero) with sign(hit) + 1 and sign(miss) + 1 in those bits; the row
+        // walk rebuilds t1 = sign(hit) * (w f), t0 = sign(miss) * (w f) exactly (a sign flip is
+        // exact).  Half the staging area: a fourth workgroup per CU (config 3: 0.671 -> 0.660 ms;
+        // the inference sweep, which walks each row once, is 3 % faster with the 16-byte terms
+        // above and gains nothing from a fourth workgroup).
+        unsigned long long *s_tab = (unsigned long long *)s_edges;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const EdgeRec8 c = f.rec[k];
+          const double wf = (double)w[k] * (double)c.f;
+          unsigned long long u;
+          __builtin_memcpy(&u, &wf, 8);
+          s_tab[t + k * BLOCK_THREADS] = u | ((c.key >> REC8_HIT_SHIFT) & 15u);
         }
       } else {
         // learning with a gradient scatter: the records in their 16-byte form + f32 weights
@@ -1493,7 +1569,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : 3) sweep8_kernel(cons
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
       if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
-        delta = process_variable<LEARN, W_TERMS, true>(P, T, d.v0 + t, pre, A, B, true);
+        delta = process_variable<LEARN, W_TERMS8, true>(P, T, d.v0 + t, pre, A, B, true);
       else
         process_variable<LEARN, LEARN ? W_ARRAY : (TAB ? W_TERMS8 : W_TERMS), true>(P, T, d.v0 + t, pre, A, B, false);
     }
@@ -1612,6 +1688,31 @@ __global__ void __launch_bounds__(BLOCK_THREADS) giant_kernel(const KernelParams
         atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)(long long)FIX_SCALE);
     }
   }
+}
+
+// Degree bin between the lane-per-variable tiles and giant_kernel: a variable
+// with hundreds to thousands of records -- it fits a tile, but one lane would walk its row
+// record after record while the 255 other lanes of the workgroup wait at the barrier.  ONE WAVE
+// per such variable (four per workgroup, no barrier anywhere): the 64 lanes stride over the
+// row's records straight from HBM (coalesced 16-byte loads, all weight gathers of a step in
+// flight), the partial potentials meet in a xor butterfly (wave_sum_f64: every lane holds the
+// total), and from there all lanes run the very code of the tiles (process_variable) in
+// lockstep -- every factor function, both variable types, the evidence chain, noise-aware
+// truthiness -- with W_COOP doing stores and tallies once and sharing the gradient rows out.
+// As in giant_kernel the potential is a re-associated f64 sum: it can differ from the
+// sequential one in its last bits; a draw flips only within ~1e-16 of its threshold.
+template <bool LEARN>
+__global__ void __launch_bounds__(BLOCK_THREADS) wide_kernel(const KernelParams P, const uint32_t *wide_tiles,
+                                                             uint32_t n) {
+  const uint32_t idx = blockIdx.x * (BLOCK_THREADS / 64u) + (threadIdx.x >> 6);
+  if (idx >= n) return;                                   // (the whole wave leaves)
+  const TileDesc d = P.tiles[wide_tiles[idx]];            // nv == 1 by construction
+  const uint32_t p = d.v0;
+  const VarPre vp = load_var_pre<LEARN>(P, p);
+  double A, B;
+  philox_uniforms(P.seed, P.vid_offset + vp.orig, P.sweep, A, B);
+  const TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr, nullptr};
+  process_variable<LEARN, W_COOP, false>(P, T, p, vp, A, B);
 }
 
 // Pull-based weight gradient for TILE_PULL tiles (replaces their gradient atomics).

@@ -45,7 +45,7 @@ class DwxError(RuntimeError):
 class CompileOpts(C.Structure):
     _fields_ = [("tile_vars", C.c_uint32), ("tile_edges", C.c_uint32), ("tile_rows", C.c_uint32),
                 ("conflict_arity_cap", C.c_uint32), ("n_threads", C.c_uint32),
-                ("no_compact_records", C.c_uint32)]
+                ("no_compact_records", C.c_uint32), ("wide_min_records", C.c_uint32)]
 
 
 class GraphInfo(C.Structure):
@@ -53,7 +53,7 @@ class GraphInfo(C.Structure):
         "num_variables", "num_factors", "num_edges", "num_weights", "num_owned_variables", "num_values",
         "num_index_entries", "num_vif_entries", "num_colors", "num_launches", "num_tiles",
         "num_giant_tiles", "max_cardinality", "num_query_variables", "device_bytes")] + [
-        ("has_categorical", C.c_uint32), ("order_is_identity", C.c_uint32)]
+        ("has_categorical", C.c_uint32), ("order_is_identity", C.c_uint32), ("num_wide_tiles", C.c_uint64)]
 
 
 class Options(C.Structure):

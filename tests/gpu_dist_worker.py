@@ -52,7 +52,7 @@ def main():
     torch.cuda.synchronize()
     # the halo lists of the C ABI (dwx_halo_*): gather both chains of 1000 scattered variables
     # into the list's device buffer on the sampler's stream, change them, scatter them back
-    ids = np.arange(3, 200_000, 199, dtype=np.uint64)[:1000]
+    ids = np.arange(13, 200_000, 199, dtype=np.uint64)[:1000]    # (not the ten variables flipped above)
     h = eng.halo_list(ids)
     assert h.n == 1000 and h.tensor.numel() == 2000 and h.tensor.dtype == torch.int32
     fr0, ev0 = a.assignments("free")[ids.astype(np.int64)], a.assignments("evid")[ids.astype(np.int64)]

@@ -75,6 +75,31 @@ unsigned long long ballot(bool pred) {
   return m;
 }
 
+// Wave-level exchange without a workgroup barrier: a lane deposits its value and yields until
+// the 64th lane of its wave has arrived (the waves of a workgroup may be in different places).
+double wave_sum(double v) {
+  static double slot[16][64], result[16];
+  static unsigned arrived[16], gen[16];
+  const unsigned w = threadIdx_.x >> 6, l = threadIdx_.x & 63u;
+  const unsigned lanes = blockDim_.x - w * 64 < 64 ? blockDim_.x - w * 64 : 64;
+  slot[w][l] = v;
+  const unsigned my_gen = gen[w];
+  if (++arrived[w] == lanes) {
+    double x[64];
+    for (unsigned i = 0; i < 64; ++i) x[i] = i < lanes ? slot[w][i] : 0.0;
+    for (unsigned m = 32; m >= 1; m >>= 1) {      // the device's butterfly, lane 0's view
+      double y[64];
+      for (unsigned i = 0; i < 64; ++i) y[i] = x[i] + x[i ^ m];
+      for (unsigned i = 0; i < 64; ++i) x[i] = y[i];
+    }
+    result[w] = x[0];
+    arrived[w] = 0;
+    ++gen[w];
+  }
+  while (gen[w] == my_gen) to_sched(false);
+  return result[w];
+}
+
 void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::function<void()> &body) {
   // one launch at a time: the emulated "device" state above is global, and the multi-rank host
   // drivers (dw gibbs --gpus N: one host thread per rank) launch from several threads

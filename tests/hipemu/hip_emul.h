@@ -27,6 +27,9 @@ extern unsigned char *g_lds;
 void syncthreads();
 // wave64 ballot; must be reached by every thread of the workgroup
 unsigned long long ballot(bool pred);
+// sum over the 64 lanes of the calling thread's wave in the xor-butterfly association of the
+// device code (wave_sum_f64); only the lanes of ONE wave have to reach it together
+double wave_sum(double v);
 // run `body` once per (block, thread) of the grid, blocks sequentially
 void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::function<void()> &body);
 }  // namespace emu
@@ -46,6 +49,7 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::functi
 #define DWX_FAST_EXPF(x) expf(x)
 #define __shared__ static
 #define DWX_BALLOT(pred) (::emu::ballot(pred))
+#define DWX_WAVE_SUM_F64(v) (::emu::wave_sum(v))
 #define DWX_UNIFORM(x) (x)
 #define DWX_NT_LOAD(p) (*(p))
 #define DWX_LOAD_ROW_NT 1

@@ -283,6 +283,45 @@ def test_high_degree_hub_variables(lib):
     run_parity(lib, hub_graph(4, W=2000), n_learn=3, n_infer=3, stepsize=0.001, sample_evidence=True)
 
 
+def test_degree_bins_lane_wave_workgroup(lib):
+    import test_kernels_emu as E
+    E.test_degree_bins_lane_wave_workgroup(lib)
+
+
+def test_degree_histogram_1_to_1e5_exact_and_faster_than_lane_per_variable(lib):
+    """A power-law-shaped graph: 200k variables with 1-8 factors, 3000 with 16 ... 100 000
+    (log-uniform), 37 M edge records.  Exact against the oracle through learning and inference
+    sweeps -- lanes, waves and workgroups per variable side by side -- and, the point of the
+    wave bin, at least 3x faster per sweep than the same graph with every
+    variable that fits a tile walked by ONE lane."""
+    import time
+    from randgraph import degree_graph_fast
+    raw = degree_graph_fast(7)
+    s, _ = run_parity(lib, raw, n_learn=2, n_infer=2, stepsize=0.0005, check_index=False)
+    info = s.graph.info
+    assert info.num_wide_tiles > 500 and info.num_giant_tiles > 100
+    deg = np.bincount(raw.edge_vid.astype(np.int64), minlength=raw.num_variables)
+    assert deg.min() >= 1 and deg.max() > 50_000
+
+    def sweep_ms(sampler, learn):
+        for _ in range(2):
+            sampler.sample_sgd(0.0005) if learn else sampler.sample()
+        sampler.wait()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            sampler.sample_sgd(0.0005) if learn else sampler.sample()
+        sampler.wait()
+        return (time.perf_counter() - t0) / 5 * 1e3
+
+    off = dwx.GibbsSampler(dwx.Graph(raw, lib=lib, wide_min_records=0xFFFFFFFF), device=0, seed=77)
+    assert off.graph.info.num_wide_tiles == 0
+    t_on = (sweep_ms(s, False), sweep_ms(s, True))
+    t_off = (sweep_ms(off, False), sweep_ms(off, True))
+    print("degree bins: inference %.3f ms vs %.3f ms lane-per-variable; learning %.3f vs %.3f"
+          % (t_on[0], t_off[0], t_on[1], t_off[1]))
+    assert t_off[0] >= 3 * t_on[0] and t_off[1] >= 3 * t_on[1], (t_on, t_off)
+
+
 def test_full_pipeline_learn_infer_vs_reference_live(lib):
     """Config-3 shape at 1M variables, the WHOLE pipeline on both sides (the real
     reference binary vs this build's `dw` drop-in, same files, same flags).  Learned

@@ -204,6 +204,37 @@ def test_high_degree_hub_variables(lib):
     run_parity(lib, hub_graph(4, W=2000), n_learn=3, n_infer=3, stepsize=0.001, sample_evidence=True)
 
 
+def test_degree_bins_lane_wave_workgroup(lib):
+    """Degrees from 1 to thousands in one graph: low-degree variables in lane-per-variable
+    tiles, mid-degree ones walked by a wave each (TILE_WIDE, wide_kernel), the largest by a
+    workgroup each (giant_kernel) -- boolean and categorical, unary and pairwise factors, both
+    chains, every learning flag; and the same graph with the wave bin switched off."""
+    from sampler_amd import dwx
+    from randgraph import degree_graph
+    raw = degree_graph(5, n_low=1500, n_high=60, max_degree=6000, W=120)
+    g = dwx.Graph(raw, lib=lib)
+    assert g.info.num_wide_tiles >= 10 and g.info.num_giant_tiles >= 2
+    run_parity(lib, raw, n_learn=3, n_infer=3, stepsize=0.002)
+    run_parity(lib, raw, n_learn=2, n_infer=2, stepsize=0.002, learn_non_evidence=True, sample_evidence=True)
+    run_parity(lib, raw, n_learn=2, n_infer=1, stepsize=0.002, noise_aware=True)
+    g_off = dwx.Graph(raw, lib=lib, wide_min_records=0xFFFFFFFF)
+    assert g_off.info.num_wide_tiles == 0 and g_off.info.num_tiles < g.info.num_tiles
+    run_parity(lib, raw, n_learn=2, n_infer=2, stepsize=0.002, compile_opts=dict(wide_min_records=0xFFFFFFFF))
+    # a lower threshold moves more variables into the bin; an all-unary graph keeps its compact
+    # record stream next to wide tiles
+    run_parity(lib, raw, n_learn=2, n_infer=2, stepsize=0.002, compile_opts=dict(wide_min_records=40))
+    un = degree_graph(6, n_low=800, n_high=40, max_degree=3000, W=2000, p_cat=0.0)
+    keep = np.diff(un.fac_edge_offset.astype(np.int64)) == 1
+    from sampler_amd.rawgraph import RawGraph
+    off = np.zeros(int(keep.sum()) + 1, np.uint64); off[1:] = np.arange(1, int(keep.sum()) + 1)
+    first = un.fac_edge_offset[:-1].astype(np.int64)[keep]
+    un = RawGraph(un.var_role, un.var_init_value, un.var_dtype, un.var_cardinality, un.fac_func[keep], off,
+                  un.fac_weight_id[keep], un.fac_feature_value[keep], un.edge_vid[first], un.edge_equal_to[first],
+                  un.w_initial_value, un.w_is_fixed)
+    s, _ = run_parity(lib, un, n_learn=3, n_infer=3, stepsize=0.002)
+    assert s.graph.info.num_wide_tiles > 0
+
+
 def test_split_sweep_parity_and_heavy_tying_learns_like_the_reference(lib):
     """Heavily tied weights (hundreds of SGD updates per weight and sweep, every variable
     couples 10 weights) with a large step: one batched update per sweep would be outside
