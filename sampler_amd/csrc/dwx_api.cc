@@ -174,6 +174,10 @@ struct dwx_sampler {
   std::map<uint32_t, std::unique_ptr<Level>> levels;
   Level *plan_level = nullptr;        // level of the current plan
   bool plan_force_dynamic = false;    // dwx_sgd_plan_force_dynamic (multi-GPU agreement)
+  // split learning sweeps as HIP graphs, one per batch count (dwx_sample_sgd_async)
+  std::map<uint32_t, rt::graph_exec_t> sgd_graphs;
+  SweepDyn *d_dyn = nullptr;
+  bool capturing = false, graphs_enabled = true;
   uint32_t cur_chunk = 0;             // last chunk handed to dwx_sgd_accumulate_async
   uint8_t *d_w_fixed = nullptr;
   long long *d_grad = nullptr;
@@ -188,6 +192,8 @@ struct dwx_sampler {
   uint64_t t_launches[3] = {0, 0, 0}, t_sweeps[3] = {0, 0, 0};
 
   ~dwx_sampler() {
+    for (auto &g : sgd_graphs) rt::graph_destroy(g.second);
+    rt::dfree(d_dyn);
     for (auto &sp : spans) { rt::event_destroy(sp.a); rt::event_destroy(sp.b); rt::event_destroy(sp.c); }
     rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
     rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_wide); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
@@ -260,7 +266,7 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   const uint32_t g0 = (uint32_t)(std::lower_bound(gb, ge, t0) - c.giant_tiles.data());
   const uint32_t g1 = (uint32_t)(std::lower_bound(gb, ge, t1) - c.giant_tiles.data());
   if (g1 > g0) {
-    rt::launch(giant_kernel<LEARN>, g1 - g0, BLOCK_THREADS, 0, s->stream, P,
+    rt::launch(giant_kernel<LEARN>, g1 - g0, GIANT_THREADS, 0, s->stream, P,
                (const uint32_t *)(s->d_giant + g0), g1 - g0);
     ++launches;
   }
@@ -899,18 +905,20 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
   const dwx_sampler::Chunk &ch = s->plan_chunks[chunk];
   KernelParams P = s->base;
   P.sweep = s->sweep;
+  P.dyn = s->capturing ? s->d_dyn : nullptr;
   const dwx_sampler::Level &L = *s->plan_level;
   const bool split = s->plan_batches > 1;
   // a split sweep without per-chunk tables falls back to per-record atomics and counts
   const bool fast = L.fast && !(split && s->plan_force_dynamic);
   if (split && !fast) P.flags |= OPT_DYNAMIC_T | OPT_NO_PULL;
   TimedSpan sp{};
-  if (s->timing) {
+  const bool timing = s->timing && !s->capturing;
+  if (timing) {
     sp.a = rt::event_create(); sp.b = rt::event_create(); sp.c = rt::event_create(); sp.kind = 1;
     rt::event_record(sp.a, s->stream);
   }
   const uint32_t launches = launch_tiles<true>(s, P, ch.launch, ch.t0, ch.t1);
-  if (s->timing) rt::event_record(sp.b, s->stream);
+  if (timing) rt::event_record(sp.b, s->stream);
   bool pulled = false;
   // the pull-based gradient of the TILE_PULL tiles: un-split sweeps once, after the last
   // chunk (= colour launch), over the whole list; split sweeps per chunk over its part
@@ -948,7 +956,7 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
                (const unsigned long long *)s->d_delta, s->d_grad);
     pulled = true;
   }
-  if (s->timing) {
+  if (timing) {
     rt::event_record(sp.c, s->stream);
     sp.launches = launches; sp.has_pull = pulled; sp.new_sweep = chunk == 0;
     s->spans.push_back(sp);
@@ -978,7 +986,7 @@ void enqueue_apply(dwx_sampler *s) {
   }
   rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
              (const uint8_t *)s->d_w_fixed, s->d_grad, ts, hs, W, s->plan_eta, s->opts.reg_param,
-             (int)(s->opts.regularization == 1));
+             (int)(s->opts.regularization == 1), (const SweepDyn *)(s->capturing ? s->d_dyn : nullptr));
 }
 
 void drain_spans(dwx_sampler *s) {
@@ -1097,6 +1105,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     s->device = opts->device;
     const CompiledGraph &c = *s->cg;
     s->stream = rt::stream_create();
+    s->graphs_enabled = getenv("DWX_NO_GRAPH") == nullptr;     // (A/B and test switch)
     rt::stream_t st = s->stream;
     const bool timing = getenv("DWX_TIMING") != nullptr;   // wall time of every phase on stderr
     auto t_phase = std::chrono::steady_clock::now();
@@ -1126,7 +1135,13 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     s->d_edges = upload(c.edges, st, 1);
     s->rec8 = c.edges8.size() != 0;
     if (s->rec8) s->d_edges8 = upload(c.edges8, st, 1);
-    s->d_vifs = upload(c.vifs, st);
+    {
+      // the batched walks load a factor's first entries branch-free (a unary record reads entry
+      // 0 and ignores it): the array is never empty, entry 0 names a real variable
+      std::vector<VifRec> vifs = c.vifs;
+      if (vifs.size() < 4) vifs.resize(4, VifRec{0u, 0u});
+      s->d_vifs = upload(vifs, st, 4);
+    }
     // InferenceResult init (src/inference_result.cc:24-42): both chains start at the
     // evidence value or 0, tallies zero, weights at their initial values
     std::vector<uint32_t> a0(c.V);
@@ -1344,6 +1359,8 @@ int dwx_sgd_plan_rows(dwx_sampler *s, uint32_t n_rows) {
     rt::dfree(L.d_t_static);
     L.d_t_static = grown;
     L.rows = n_rows;
+    for (auto &g : s->sgd_graphs) rt::graph_destroy(g.second);   // (they captured the old table)
+    s->sgd_graphs.clear();
   });
 }
 
@@ -1391,10 +1408,42 @@ int dwx_sample_sgd_async(dwx_sampler *s, double stepsize) {
   return guarded([&]() {
     make_plan(s, stepsize, 0);
     const size_t n = s->plan_chunks.size();
-    for (size_t c = 0; c < n; ++c) {
-      s->cur_chunk = (uint32_t)c;
-      enqueue_learn_chunk(s, (uint32_t)c);
-      if (s->plan_batches > 1 || c + 1 == n) enqueue_apply(s);
+    auto enqueue_all = [&]() {
+      for (size_t c = 0; c < n; ++c) {
+        s->cur_chunk = (uint32_t)c;
+        enqueue_learn_chunk(s, (uint32_t)c);
+        if (s->plan_batches > 1 || c + 1 == n) enqueue_apply(s);
+      }
+    };
+    // A sweep cut into many mini-batches is thousands of small launches (64 batches x colours x
+    // {sweep, oversized, wide, pull, apply}): launch-bound.  Capture it once per batch count --
+    // every table and range of a plan level is fixed -- and replay it; the sweep counter and the
+    // step come from device memory (SweepDyn), set by one tiny launch in front.
+    const bool graph = rt::kGraphs && s->graphs_enabled && !s->timing && s->plan_batches > 1 && n >= 8;
+    if (graph) {
+      rt::set_device(s->device);
+      if (!s->d_dyn) s->d_dyn = (SweepDyn *)rt::dmalloc(sizeof(SweepDyn));
+      auto it = s->sgd_graphs.find(s->plan_batches);
+      if (it == s->sgd_graphs.end()) {
+        s->capturing = true;
+        rt::graph_exec_t ge = nullptr;
+        try {
+          rt::capture_begin(s->stream);
+          enqueue_all();
+          ge = rt::capture_end(s->stream);
+        } catch (...) {
+          s->capturing = false;
+          throw;
+        }
+        s->capturing = false;
+        it = s->sgd_graphs.emplace(s->plan_batches, ge).first;
+      }
+      rt::launch(set_dyn_kernel, 1, 1, 0, s->stream, s->d_dyn, (uint64_t)s->sweep, s->plan_eta);
+      rt::graph_launch(it->second, s->stream);
+      s->terms_state = 0;    // (what enqueue_apply does on the host: the weights change)
+      s->cur_chunk = (uint32_t)(n ? n - 1 : 0);
+    } else {
+      enqueue_all();
     }
     ++s->sweep;
     s->plan_valid = false;

@@ -79,6 +79,10 @@ DWX_DEV void philox_uniforms(uint64_t seed, uint64_t vid, uint64_t sweep, double
   B = (double)(b >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// the sweep counter of this launch (Philox counter word): by value, or -- inside a replayed HIP
+// graph -- from device memory
+DWX_DEV uint64_t current_sweep(const KernelParams &P) { return P.dyn ? P.dyn->sweep : P.sweep; }
+
 // ---------------------------------------------------------------- math
 // src/common.h:118-132
 DWX_DEV double logadd(double a, double b) {
@@ -358,7 +362,11 @@ DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const Vif
 //              records l, l + 64, ... of a row, the 64 partial sums are combined by a butterfly
 //              (all lanes get the total); every lane then follows the same decisions, side
 //              effects happen once
-enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4, W_COOP = 5 };
+//   W_COOPB    (giant_kernel) the same with a whole WORKGROUP of GIANT_THREADS lanes and an
+//              LDS tree for the sums
+enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4, W_COOP = 5, W_COOPB = 6 };
+constexpr uint32_t GIANT_THREADS = 1024;   // lanes per oversized variable (giant_kernel)
+constexpr uint32_t COOP_U = 4;             // records per lane and step of a cooperative walk
 
 // sum over the 64 lanes of a wave, the same value (and the same association: the xor
 // butterfly) in every lane
@@ -371,6 +379,31 @@ DWX_DEV double wave_sum_f64(double v) {
 #define DWX_WAVE_SUM_F64(v) wave_sum_f64(v)
 #endif
 DWX_DEV uint32_t wave_lane() { return threadIdx.x & 63u; }
+
+// sum over all lanes of the workgroup through an LDS tree (every lane gets the total; must be
+// reached by every lane of the workgroup)
+DWX_DEV double block_sum_all(double v) {
+  __shared__ double s_red[GIANT_THREADS];
+  const uint32_t t = threadIdx.x;
+  s_red[t] = v;
+  __syncthreads();
+  for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (t < s) s_red[t] += s_red[t + s];
+    __syncthreads();
+  }
+  const double r = s_red[0];
+  __syncthreads();
+  return r;
+}
+
+// the cooperating group of a W_COOP / W_COOPB walk
+template <int WMODE>
+struct Coop {
+  static constexpr bool on = WMODE == W_COOP || WMODE == W_COOPB;
+  static DWX_DEV uint32_t lane() { return WMODE == W_COOPB ? threadIdx.x : wave_lane(); }
+  static DWX_DEV uint32_t stride() { return WMODE == W_COOPB ? blockDim.x : 64u; }
+  static DWX_DEV double sum(double v) { return WMODE == W_COOPB ? block_sum_all(v) : DWX_WAVE_SUM_F64(v); }
+};
 
 struct alignas(16) EdgeTerms { double t1, t0; };
 // Table entry of a record of a TILE_INLINE2 tile (build_terms_kernel), overlaying an EdgeRec:
@@ -450,6 +483,77 @@ DWX_DEV void record_signs(const KernelParams &P, const EdgeRec &er, uint32_t me,
   }
 }
 
+// A cooperative walk over records [es, ee) (W_COOP / W_COOPB): the group's lanes stride over
+// them, COOP_U records per lane and step, in four phases so that every phase's loads -- of all
+// COOP_U records -- are in flight together: the records; their weights and the first GEN_ARITY
+// factor->variable entries of the non-unary ones; those variables' assignments on every chain;
+// then the arithmetic.  A record is evaluated in NS scenarios at once: scenario j = the owner
+// takes prop[j] (hit[j]: that value "hits" a pre-signed record), everybody else its value on
+// chain chain[j] of chains[].  fn(record, index, weight, term[NS]) gets sign * feature value
+// per scenario (Factor::potential, src/factor.h:59-86).  Factors wider than GEN_ARITY walk
+// memory as everywhere else.
+template <int WMODE, int NS, int NCHAIN, class Fn>
+DWX_DEV void coop_for_records(const KernelParams &P, const TileView &T, uint32_t es, uint32_t ee, uint32_t me,
+                              const uint32_t *const (&chains)[NCHAIN], const int (&chain)[NS],
+                              const uint32_t (&prop)[NS], const bool (&hit)[NS], Fn &&fn) {
+  const uint32_t stride = Coop<WMODE>::stride();
+  for (uint32_t e0 = es + Coop<WMODE>::lane(); e0 < ee; e0 += stride * COOP_U) {
+    EdgeRec er[COOP_U];
+    float w[COOP_U];
+    VifRec vf[COOP_U][GEN_ARITY];
+    uint32_t val[COOP_U][NCHAIN][GEN_ARITY];
+#pragma unroll
+    for (uint32_t u = 0; u < COOP_U; ++u) {
+      const uint32_t e = e0 + u * stride;
+      er[u] = T.edges[(e < ee ? e : es) - T.edge_bias];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < COOP_U; ++u) {
+      w[u] = P.w32[er[u].wid];
+      const bool generic = !(er[u].packed & EDGE_PRESIGNED);
+      const uint32_t ar = generic ? edge_arity(er[u]) : 1u, base = (generic && ar >= 2u) ? er[u].aux : 0u;
+#pragma unroll
+      for (uint32_t i = 0; i < GEN_ARITY; ++i) vf[u][i] = P.vifs[base + umin(i, ar - 1u)];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < COOP_U; ++u)
+#pragma unroll
+      for (int c = 0; c < NCHAIN; ++c)
+#pragma unroll
+        for (uint32_t i = 0; i < GEN_ARITY; ++i) val[u][c][i] = chains[c][vf[u][i].vid];
+#pragma unroll
+    for (uint32_t u = 0; u < COOP_U; ++u) {
+      const uint32_t e = e0 + u * stride;
+      if (e >= ee) continue;
+      double term[NS];
+      if (er[u].packed & EDGE_PRESIGNED) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) term[j] = (double)(hit[j] ? er[u].fval : bits_to_float(er[u].aux));
+      } else {
+        const double fv = (er[u].packed & EDGE_F64_FLAG) ? P.edge_fval64[e] : (double)er[u].fval;
+        const uint32_t func = edge_func(er[u]), ar = edge_arity(er[u]);
+        double sg[NS];
+        if (ar == 1u) {
+#pragma unroll
+          for (int j = 0; j < NS; ++j) sg[j] = unary_sign(func, prop[j] == er[u].aux);
+        } else if (ar <= GEN_ARITY) {
+          const VifsPreloaded<NS, NCHAIN> src{vf[u], val[u], chain};
+          factor_signs_from<NS>(func, ar, src, me, prop, sg);
+        } else {
+          const uint32_t *arr[NS];
+#pragma unroll
+          for (int j = 0; j < NS; ++j) arr[j] = chains[chain[j]];
+          const uint32_t *const (&carr)[NS] = arr;
+          factor_signs<NS>(func, ar, er[u].aux, P.vifs, me, carr, prop, sg);
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) term[j] = sg[j] * fv;
+      }
+      fn(er[u], e, (double)w[u], term);
+    }
+  }
+}
+
 // SIMPLE (a per-tile, workgroup-uniform property, TILE_SIMPLE): every record is a
 // unary factor with an f32-exact feature value.  The SIMPLE variants below contain no
 // global load, so nothing in the compute phase waits on vmcnt -- which retires in
@@ -487,12 +591,14 @@ template <int WMODE, bool SIMPLE>
 DWX_DEV double range_potential(const KernelParams &P, const TileView &T, uint32_t es, uint32_t ee,
                                const uint32_t *assign, uint32_t me, uint32_t proposal) {
   double pot = 0.0;
-  if (WMODE == W_COOP) {
-    for (uint32_t e = es + wave_lane(); e < ee; e += 64u) {
-      const EdgeRec er = T.edges[e - T.edge_bias];
-      pot += (double)P.w32[er.wid] * edge_term<SIMPLE>(P, er, e, assign, me, proposal, true);
-    }
-    return DWX_WAVE_SUM_F64(pot);
+  if (Coop<WMODE>::on) {
+    const uint32_t *const chains[1] = {assign};
+    const int chain[1] = {0};
+    const uint32_t prop[1] = {proposal};
+    const bool hit[1] = {true};
+    coop_for_records<WMODE, 1, 1>(P, T, es, ee, me, chains, chain, prop, hit,
+                                  [&](const EdgeRec &, uint32_t, double w, const double (&term)[1]) { pot += w * term[0]; });
+    return Coop<WMODE>::sum(pot);
   }
   if (WMODE == W_TERMS8) {
     const unsigned long long *tab = (const unsigned long long *)T.edges;
@@ -543,14 +649,17 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
                              const uint32_t *assign, uint32_t me, double &pp, double &pn) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   pp = 0.0; pn = 0.0;
-  if (WMODE == W_COOP) {
-    for (uint32_t e = es + wave_lane(); e < ee; e += 64u) {
-      const EdgeRec er = T.edges[e - T.edge_bias];
-      const double w = (double)P.w32[er.wid];
-      pp += w * edge_term<SIMPLE>(P, er, e, assign, me, 1u, true);
-      pn += w * edge_term<SIMPLE>(P, er, e, assign, me, 0u, false);
-    }
-    pp = DWX_WAVE_SUM_F64(pp); pn = DWX_WAVE_SUM_F64(pn);
+  if (Coop<WMODE>::on) {
+    const uint32_t *const chains[1] = {assign};
+    const int chain[2] = {0, 0};
+    const uint32_t prop[2] = {1u, 0u};
+    const bool hit[2] = {true, false};
+    coop_for_records<WMODE, 2, 1>(P, T, es, ee, me, chains, chain, prop, hit,
+                                  [&](const EdgeRec &, uint32_t, double w, const double (&term)[2]) {
+                                    pp += w * term[0];
+                                    pn += w * term[1];
+                                  });
+    pp = Coop<WMODE>::sum(pp); pn = Coop<WMODE>::sum(pn);
     return;
   }
   if (WMODE == W_TERMS8) {
@@ -650,17 +759,18 @@ DWX_DEV void bool_potentials_both(const KernelParams &P, const TileView &T, uint
                                   double &ppf, double &pnf, double &ppe, double &pne) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   ppf = 0.0; pnf = 0.0; ppe = 0.0; pne = 0.0;
-  if (WMODE == W_COOP) {
-    for (uint32_t e = es + wave_lane(); e < ee; e += 64u) {
-      const EdgeRec er = T.edges[e - T.edge_bias];
-      const double w = (double)P.w32[er.wid];
-      ppf += w * edge_term<false>(P, er, e, P.assign_free, me, 1u, true);
-      pnf += w * edge_term<false>(P, er, e, P.assign_free, me, 0u, false);
-      ppe += w * edge_term<false>(P, er, e, P.assign_evid, me, 1u, true);
-      pne += w * edge_term<false>(P, er, e, P.assign_evid, me, 0u, false);
-    }
-    ppf = DWX_WAVE_SUM_F64(ppf); pnf = DWX_WAVE_SUM_F64(pnf);
-    ppe = DWX_WAVE_SUM_F64(ppe); pne = DWX_WAVE_SUM_F64(pne);
+  if (Coop<WMODE>::on) {
+    const uint32_t *const chains[2] = {P.assign_free, P.assign_evid};
+    const int chain[4] = {0, 0, 1, 1};
+    const uint32_t prop[4] = {1u, 0u, 1u, 0u};
+    const bool hit[4] = {true, false, true, false};
+    coop_for_records<WMODE, 4, 2>(P, T, es, ee, me, chains, chain, prop, hit,
+                                  [&](const EdgeRec &, uint32_t, double w, const double (&term)[4]) {
+                                    ppf += w * term[0]; pnf += w * term[1];
+                                    ppe += w * term[2]; pne += w * term[3];
+                                  });
+    ppf = Coop<WMODE>::sum(ppf); pnf = Coop<WMODE>::sum(pnf);
+    ppe = Coop<WMODE>::sum(ppe); pne = Coop<WMODE>::sum(pne);
     return;
   }
   for (uint32_t e = es; e < ee; ++e) {
@@ -823,13 +933,27 @@ DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row
 // static and were folded into T_static on the host (dwx_sampler_create).
 // hit_value: the proposal that "hits" a pre-signed record of this row (1 for a boolean
 // variable, the row's value for a categorical one).
-// COOP: the 64 lanes of the wave share the row's records (wide_kernel).
-template <bool SIMPLE, bool COOP = false>
+// W_COOP / W_COOPB: the lanes of the cooperating group share the row's records.
+template <bool SIMPLE, int WMODE = W_GLOBAL>
 DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uint32_t me,
                      uint32_t evid_value, uint32_t free_value, uint32_t hit_value, double t,
                      const bool count_t) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
-  for (uint32_t e = es + (COOP ? wave_lane() : 0u); e < ee; e += (COOP ? 64u : 1u)) {
+  if (Coop<WMODE>::on) {
+    const uint32_t *const chains[2] = {P.assign_evid, P.assign_free};
+    const int chain[2] = {0, 1};
+    const uint32_t prop[2] = {evid_value, free_value};
+    const bool hit[2] = {evid_value == hit_value, free_value == hit_value};
+    coop_for_records<WMODE, 2, 2>(P, T, es, ee, me, chains, chain, prop, hit,
+                                  [&](const EdgeRec &er, uint32_t, double, const double (&term)[2]) {
+      if (er.packed & EDGE_FIXED_FLAG) return;
+      const long long gi = llrint(FIX_SCALE * (t * (term[1] - term[0])));
+      if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
+      if (count_t) atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)llrint(FIX_SCALE * t));
+    });
+    return;
+  }
+  for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     if (er.packed & EDGE_FIXED_FLAG) continue;   // weights_isfixed (src/factor_graph.cc:247)
     double pot_evid, pot_free;
@@ -904,8 +1028,8 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
   // W_COOP: all 64 lanes of the wave run this function for the SAME variable; the potentials
   // are wave-wide sums (identical in every lane), so every lane takes the same decisions;
   // stores and tallies happen once, the gradient rows are shared out over the lanes
-  constexpr bool COOP = WMODE == W_COOP;
-  const bool leader = !COOP || wave_lane() == 0u;
+  constexpr bool COOP = Coop<WMODE>::on;
+  const bool leader = !COOP || Coop<WMODE>::lane() == 0u;
   if (!LEARN) {
     // sample_single_variable (src/gibbs_sampler.h:151-169)
     if (is_evid && !(P.flags & OPT_SAMPLE_EVIDENCE)) return 0;
@@ -974,7 +1098,7 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
     const bool dyn_t = P.flags & OPT_DYNAMIC_T;
     if (SIMPLE && !dyn_t && p_free == evid_value) return 0;
     if (SIMPLE && want_delta) return (int)p_free - (int)evid_value;
-    sgd_row<SIMPLE, COOP>(P, T, row0, p, evid_value, p_free, 1u, 1.0, dyn_t);
+    sgd_row<SIMPLE, WMODE>(P, T, row0, p, evid_value, p_free, 1u, 1.0, dyn_t);
     return 0;
   }
   for (uint32_t val = 0; val < card; ++val) {
@@ -984,9 +1108,9 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
       t = P.row_truth ? P.row_truth[row0 + val] : 0.0;
       if (is_linear_zero(t)) continue;
     }
-    sgd_row<SIMPLE, COOP>(P, T, row0 + val, p, val, p_free, val, t, true);
+    sgd_row<SIMPLE, WMODE>(P, T, row0 + val, p, val, p_free, val, t, true);
     if (val == p_free) continue;
-    sgd_row<SIMPLE, COOP>(P, T, row0 + p_free, p, val, p_free, p_free, t, true);
+    sgd_row<SIMPLE, WMODE>(P, T, row0 + p_free, p, val, p_free, p_free, t, true);
   }
   return 0;
 }
@@ -1223,7 +1347,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
         for (int k = 0; k < K; ++k) w[k] = 0.0f;
       }
       // ... and draw this lane's uniforms while the gathers are in flight
-      philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
+      philox_uniforms(P.seed, P.vid_offset + pre.orig, current_sweep(P), A, B);
       // unconditional LDS writes: slots past the tile's last record receive copies of
       // it and are never read
       // (TILE_TERMS2 staging keeps two vif records and the neighbour values per staged
@@ -1503,7 +1627,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
         for (int k = 0; k < K; ++k) w[k] = P.w32[f.rec[k].key & REC8_WID_MASK];
       }
       // ... and this lane's uniforms while the gathers are in flight
-      philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
+      philox_uniforms(P.seed, P.vid_offset + pre.orig, current_sweep(P), A, B);
       if (TAB) {
         // the table's entries go to LDS as they are (8 bytes per record: half the staging
         // area of the 16-byte modes, more workgroups per CU); the row walk decodes them
@@ -1596,98 +1720,25 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
 }
 
 // Variables too big for one tile (rows > rcap or edge records > ecap), e.g. the few
-// very-high-degree variables of a power-law graph: ONE WORKGROUP per such variable.
-// Boolean: the 256 lanes stride over the variable's records straight from HBM (coalesced
-// 16-byte loads, weights gathered per lane), accumulate partial potentials, and an LDS
-// tree reduction hands the totals to lane 0, which draws; then all lanes scatter the
-// gradient.  (The partial sums re-associate the f64 additions, so a potential can differ
-// from the sequential sum in its last bits; a decision flips only if r*(1+e^x) is within
-// ~1e-16 of 1.)  Categorical: lane 0 walks the rows sequentially.
-DWX_DEV double block_sum(double v, double *scratch) {
-  const uint32_t t = threadIdx.x;
-  scratch[t] = v;
-  __syncthreads();
-  for (uint32_t s = BLOCK_THREADS / 2; s > 0; s >>= 1) {
-    if (t < s) scratch[t] += scratch[t + s];
-    __syncthreads();
-  }
-  const double r = scratch[0];
-  __syncthreads();
-  return r;
-}
-
+// very-high-degree variables of a power-law graph: ONE WORKGROUP of GIANT_THREADS lanes per such
+// variable.  The lanes stride over the variable's records straight from HBM (COOP_U coalesced
+// 16-byte loads per lane and step, then their weight gathers, all in flight together), keep
+// partial potentials, and an LDS tree hands the totals to every lane (block_sum_all); from
+// there all lanes run the code of the tiles (process_variable, W_COOPB) in lockstep: stores and
+// tallies once, the gradient rows shared out.  (The partial sums re-associate the f64
+// additions: a potential can differ from the sequential sum in its last bits; a decision flips
+// only if r*(1+e^x) is within ~1e-16 of 1.)
 template <bool LEARN>
-__global__ void __launch_bounds__(BLOCK_THREADS) giant_kernel(const KernelParams P, const uint32_t *giant_tiles,
+__global__ void __launch_bounds__(GIANT_THREADS) giant_kernel(const KernelParams P, const uint32_t *giant_tiles,
                                                               uint32_t n) {
-  __shared__ double s_red[BLOCK_THREADS];
-  __shared__ uint32_t s_pick[2];
-  const uint32_t t = threadIdx.x;
   if (blockIdx.x >= n) return;
-  const TileDesc d = P.tiles[giant_tiles[blockIdx.x]];
-  TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr, nullptr};
-  for (uint32_t p = d.v0; p < d.v0 + d.nv; ++p) {   // nv == 1 by construction
-    const VarPre vp = load_var_pre<LEARN>(P, p);
-    double A, B;
-    philox_uniforms(P.seed, P.vid_offset + vp.orig, P.sweep, A, B);
-    if (vp.meta & VM_CATEGORICAL) {
-      if (t == 0) process_variable<LEARN, W_GLOBAL, false>(P, T, p, vp, A, B);
-      continue;
-    }
-    const bool is_evid = vp.meta & VM_EVIDENCE;
-    if (!LEARN && is_evid && !(P.flags & OPT_SAMPLE_EVIDENCE)) continue;
-    const bool noise_aware = P.flags & OPT_NOISE_AWARE;
-    const uint32_t es = P.row_ptr[vp.row0], ee = P.row_ptr[vp.row0 + 1];
-    // partial potentials of this lane: chain c = 0 free (learning) / evid (inference),
-    // c = 1 evidence chain while learning
-    double pp0 = 0.0, pn0 = 0.0, pp1 = 0.0, pn1 = 0.0;
-    const bool draw_evid = LEARN && (noise_aware || !is_evid);
-    for (uint32_t e = es + t; e < ee; e += BLOCK_THREADS) {
-      const EdgeRec er = P.edges[e];
-      const double w = (double)P.w32[er.wid];
-      const uint32_t *a0 = LEARN ? P.assign_free : P.assign_evid;
-      pp0 += w * edge_term<false>(P, er, e, a0, p, 1u, true);
-      pn0 += w * edge_term<false>(P, er, e, a0, p, 0u, false);
-      if (draw_evid) {
-        pp1 += w * edge_term<false>(P, er, e, P.assign_evid, p, 1u, true);
-        pn1 += w * edge_term<false>(P, er, e, P.assign_evid, p, 0u, false);
-      }
-    }
-    pp0 = block_sum(pp0, s_red); pn0 = block_sum(pn0, s_red);
-    if (draw_evid) { pp1 = block_sum(pp1, s_red); pn1 = block_sum(pn1, s_red); }
-    if (!LEARN) {
-      if (t == 0) {
-        const uint32_t prop = bool_draw(A, pp0, pn0);
-        if (prop) atomicAdd(&P.tally[vp.row0], 1u);
-        P.assign_evid[p] = prop;
-      }
-      continue;
-    }
-    if (t == 0) {
-      const uint32_t p_free = bool_draw(A, pp0, pn0);
-      const uint32_t p_evid = draw_evid ? bool_draw(B, pp1, pn1) : vp.init;
-      P.assign_free[p] = p_free;
-      P.assign_evid[p] = p_evid;
-      s_pick[0] = p_free;
-    }
-    __syncthreads();
-    const uint32_t p_free = s_pick[0];
-    __syncthreads();
-    if (!(P.flags & OPT_LEARN_NON_EVIDENCE) && (noise_aware || !is_evid)) continue;
-    // sgd_on_variable (src/factor_graph.cc:265-273); the boolean update counts are static.
-    // edge_term reads the owner's own value only through `proposal`, so the freshly
-    // written assignments need not be visible to the other lanes.
-    const uint32_t evid_value = vp.init;
-    for (uint32_t e = es + t; e < ee; e += BLOCK_THREADS) {
-      const EdgeRec er = P.edges[e];
-      if (er.packed & EDGE_FIXED_FLAG) continue;
-      const double pot_evid = edge_term<false>(P, er, e, P.assign_evid, p, evid_value, evid_value == 1u);
-      const double pot_free = edge_term<false>(P, er, e, P.assign_free, p, p_free, p_free == 1u);
-      const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
-      if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
-      if (P.flags & OPT_DYNAMIC_T)
-        atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)(long long)FIX_SCALE);
-    }
-  }
+  const TileDesc d = P.tiles[giant_tiles[blockIdx.x]];    // nv == 1 by construction
+  const uint32_t p = d.v0;
+  const VarPre vp = load_var_pre<LEARN>(P, p);
+  double A, B;
+  philox_uniforms(P.seed, P.vid_offset + vp.orig, current_sweep(P), A, B);
+  const TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr, nullptr};
+  process_variable<LEARN, W_COOPB, false>(P, T, p, vp, A, B);
 }
 
 // Degree bin between the lane-per-variable tiles and giant_kernel: a variable
@@ -1710,7 +1761,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) wide_kernel(const KernelParams 
   const uint32_t p = d.v0;
   const VarPre vp = load_var_pre<LEARN>(P, p);
   double A, B;
-  philox_uniforms(P.seed, P.vid_offset + vp.orig, P.sweep, A, B);
+  philox_uniforms(P.seed, P.vid_offset + vp.orig, current_sweep(P), A, B);
   const TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr, nullptr};
   process_variable<LEARN, W_COOP, false>(P, T, p, vp, A, B);
 }
@@ -1895,7 +1946,8 @@ DWX_DEV double saturating_step(double c, double stepsize) {
 __global__ void __launch_bounds__(BLOCK_THREADS)
 apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *grad,
              const long long *t_static, const long long *t_hess, uint32_t W, double stepsize,
-             double reg_param, int l2) {
+             double reg_param, int l2, const SweepDyn *dyn) {
+  if (dyn) stepsize = dyn->stepsize;     // (graph replay: this sweep's step)
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride) {
     const long long G = grad[i], Td = grad[W + i];
@@ -1971,6 +2023,11 @@ build_terms8_kernel(const EdgeRec8 *edges8, uint64_t n, const float *w32, unsign
     __builtin_memcpy(&u, &wf, 8);
     terms[i] = u | ((c.key >> REC8_HIT_SHIFT) & 15u);   // hit code in bits 0-1, miss code in bits 2-3
   }
+}
+
+// the per-sweep scalars of a captured learning sweep (see SweepDyn)
+__global__ void set_dyn_kernel(SweepDyn *dyn, uint64_t sweep, double stepsize) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { dyn->sweep = sweep; dyn->stepsize = stepsize; }
 }
 
 // f64 master weights -> f32 sampling copy (after dwx_set_weights)

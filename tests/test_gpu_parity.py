@@ -283,6 +283,31 @@ def test_high_degree_hub_variables(lib):
     run_parity(lib, hub_graph(4, W=2000), n_learn=3, n_infer=3, stepsize=0.001, sample_evidence=True)
 
 
+def test_captured_learning_sweeps_equal_direct_launches(lib, monkeypatch):
+    """A learning sweep cut into many mini-batches is captured into a HIP graph per batch count
+    and replayed with the sweep counter and the step read from device memory: same weights and
+    chains, bit for bit, as the direct launches (DWX_NO_GRAPH), through a decaying step that
+    walks down the batch counts; and exact against the oracle (run_parity takes the same path)."""
+    raw = synthetic.cfg4(60_000, card=8, seed=3, learn=True)
+
+    def run():
+        s = dwx.GibbsSampler(dwx.Graph(raw, lib=lib), device=0, seed=19)
+        batches = [s.sgd_plan(0.01 * 0.5 ** k)[0] for k in range(8)]
+        cur = 0.01
+        for _ in range(8):
+            s.sample_sgd(cur); cur *= 0.5
+        s.sample(); s.wait()
+        return batches, s.weights, s.assignments("free"), s.assignments("evid")
+
+    b1, w1, f1, e1 = run()
+    monkeypatch.setenv("DWX_NO_GRAPH", "1")
+    b2, w2, f2, e2 = run()
+    assert b1 == b2 and b1[0] >= 8 and b1[-1] < b1[0]
+    assert np.array_equal(w1, w2) and np.abs(w1).max() > 0
+    assert np.array_equal(f1, f2) and np.array_equal(e1, e2)
+    run_parity(lib, raw, n_learn=4, n_infer=2, stepsize=0.01, decay=0.5, check_index=False)
+
+
 def test_degree_bins_lane_wave_workgroup(lib):
     import test_kernels_emu as E
     E.test_degree_bins_lane_wave_workgroup(lib)

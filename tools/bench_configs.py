@@ -34,10 +34,25 @@ def run(name, raw, n_learn, n_infer, stepsize=0.001, **kw):
     ms_i, nl_i, ns_i = s.kernel_time("infer")
     ms_l, nl_l, ns_l = s.kernel_time("learn")
     ms_p, nl_p, ns_p = s.kernel_time("pull")
-    # (kernel_time counts a learning sweep once per chunk of its plan: report per SWEEP; the
-    # figure includes the pull-gradient kernels, not apply_kernel)
+    # (per SWEEP: all its colour launches and mini-batches; the figure includes the pull-gradient
+    # kernels, not apply_kernel)
     ns_l = n_learn
     ms_l = ms_l + ms_p
+    # wall time per sweep with the event timing off: what `dw gibbs` sees -- split learning
+    # sweeps then run as captured HIP graphs
+    s.kernel_time_reset(False)
+    wall = {}
+    for kind, n in (("learn", n_learn), ("infer", n_infer)):
+        if not n:
+            continue
+        for _ in range(2):
+            s.sample_sgd(stepsize) if kind == "learn" else s.sample()
+        s.wait()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            s.sample_sgd(stepsize) if kind == "learn" else s.sample()
+        s.wait()
+        wall[kind] = (time.perf_counter() - t1) / n * 1e3
     batches, n_chunks, eta = s.sgd_plan(stepsize) if n_learn else (None, None, None)
     V = raw.num_variables
     out = {"config": name, "V": V, "colors": int(g.info.num_colors), "tiles": int(g.info.num_tiles),
@@ -46,7 +61,9 @@ def run(name, raw, n_learn, n_infer, stepsize=0.001, **kw):
            "infer_ms_per_sweep": ms_i / max(ns_i, 1), "infer_vars_per_s": V / (ms_i / max(ns_i, 1) * 1e-3) if ns_i else None,
            "learn_ms_per_sweep": ms_l / max(ns_l, 1) if ns_l else None,
            "learn_vars_per_s": V / (ms_l / ns_l * 1e-3) if ns_l else None,
-           "sgd_batches": batches, "sgd_chunks": n_chunks, "effective_stepsize": eta}
+           "learn_wall_ms_per_sweep": wall.get("learn"), "infer_wall_ms_per_sweep": wall.get("infer"),
+           "hip_graphs": os.environ.get("DWX_NO_GRAPH") is None,
+           "sgd_batches": batches, "sgd_chunks": n_chunks, "min_weight_stepsize": eta}
     print(json.dumps(out), flush=True)
     s.close()
 
