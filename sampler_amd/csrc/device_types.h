@@ -167,14 +167,6 @@ constexpr uint32_t BP_LDS_BYTES = BP_TILES * 64 + BP_DELTA_SLOTS * 8;
 constexpr uint32_t ROWPTR_UNROLL = 2;                       // row pointers prefetched per lane
 constexpr uint32_t ROWPTR_UNROLL_CAT = 7;                   // ... for categorical all-unary graphs (sweep8_kernel)                       // row pointers prefetched per lane
 
-// The two scalars that change from sweep to sweep, in device memory: a learning sweep that was
-// captured into a HIP graph (many mini-batches: thousands of small launches) is replayed with
-// new values without touching its nodes.
-struct SweepDyn {
-  uint64_t sweep;
-  double stepsize;
-};
-
 // Everything one sweep launch needs; passed by value.
 struct KernelParams {
   // graph (read only)
@@ -200,7 +192,6 @@ struct KernelParams {
   unsigned long long *delta;  // [n_tiles*4*2] per wave: {chains disagree, free < evid} ballots
   // launch
   uint64_t seed, sweep;
-  const SweepDyn *dyn;        // non-null (graph replay): the sweep counter comes from here
   uint64_t vid_offset;        // global id of local variable 0 (Philox counter)
   uint32_t tile_begin;        // first tile of this launch
   uint32_t tile_end;          // one past the last tile of this launch

@@ -106,6 +106,13 @@ struct dwx_sampler {
   uint32_t *d_row_ptr = nullptr;
   TileDesc *d_tiles = nullptr;
   uint32_t *d_giant = nullptr, *d_wide = nullptr;
+  // oversized variables: categorical ones -> giant_kernel (one workgroup each, d_giant);
+  // boolean ones -> pieces of GIANT_PIECE records over several workgroups (giant_pot_kernel,
+  // giant_decide_kernel, giant_grad_kernel)
+  std::vector<uint32_t> cgiant_tiles, bgiant_tiles, bgiant_piece_off;
+  uint32_t *d_bgiant = nullptr, *d_bgiant_piece_off = nullptr, *d_bgiant_decision = nullptr;
+  GiantPiece *d_bgiant_pieces = nullptr;
+  double *d_bgiant_partial = nullptr;
   int stage_k = 12;
   // learning-sweep plan (dwx_sgd_plan)
   struct Chunk { uint32_t launch, t0, t1; };
@@ -174,10 +181,6 @@ struct dwx_sampler {
   std::map<uint32_t, std::unique_ptr<Level>> levels;
   Level *plan_level = nullptr;        // level of the current plan
   bool plan_force_dynamic = false;    // dwx_sgd_plan_force_dynamic (multi-GPU agreement)
-  // split learning sweeps as HIP graphs, one per batch count (dwx_sample_sgd_async)
-  std::map<uint32_t, rt::graph_exec_t> sgd_graphs;
-  SweepDyn *d_dyn = nullptr;
-  bool capturing = false, graphs_enabled = true;
   uint32_t cur_chunk = 0;             // last chunk handed to dwx_sgd_accumulate_async
   uint8_t *d_w_fixed = nullptr;
   long long *d_grad = nullptr;
@@ -192,11 +195,10 @@ struct dwx_sampler {
   uint64_t t_launches[3] = {0, 0, 0}, t_sweeps[3] = {0, 0, 0};
 
   ~dwx_sampler() {
-    for (auto &g : sgd_graphs) rt::graph_destroy(g.second);
-    rt::dfree(d_dyn);
     for (auto &sp : spans) { rt::event_destroy(sp.a); rt::event_destroy(sp.b); rt::event_destroy(sp.c); }
     rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
-    rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_wide); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
+    rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_wide); rt::dfree(d_bgiant); rt::dfree(d_bgiant_piece_off);
+    rt::dfree(d_bgiant_decision); rt::dfree(d_bgiant_pieces); rt::dfree(d_bgiant_partial); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
     rt::dfree(d_edges); rt::dfree(d_edges8); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
     rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_terms); rt::dfree(d_delta);
     rt::dfree(d_w_fixed); rt::dfree(d_grad);
@@ -261,14 +263,37 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
     }
   }
   ++launches;
-  // oversized variables among these tiles (giant_tiles is sorted by tile index)
-  const uint32_t *gb = c.giant_tiles.data() + c.launch_giant[l], *ge = c.giant_tiles.data() + c.launch_giant[l + 1];
-  const uint32_t g0 = (uint32_t)(std::lower_bound(gb, ge, t0) - c.giant_tiles.data());
-  const uint32_t g1 = (uint32_t)(std::lower_bound(gb, ge, t1) - c.giant_tiles.data());
-  if (g1 > g0) {
-    rt::launch(giant_kernel<LEARN>, g1 - g0, GIANT_THREADS, 0, s->stream, P,
-               (const uint32_t *)(s->d_giant + g0), g1 - g0);
-    ++launches;
+  // oversized variables among these tiles (the lists are sorted by tile index); categorical: a
+  // workgroup each
+  {
+    const auto &gt = s->cgiant_tiles;
+    const uint32_t g0 = (uint32_t)(std::lower_bound(gt.begin(), gt.end(), t0) - gt.begin());
+    const uint32_t g1 = (uint32_t)(std::lower_bound(gt.begin(), gt.end(), t1) - gt.begin());
+    if (g1 > g0) {
+      rt::launch(giant_kernel<LEARN>, g1 - g0, GIANT_THREADS, 0, s->stream, P,
+                 (const uint32_t *)(s->d_giant + g0), g1 - g0);
+      ++launches;
+    }
+  }
+  // boolean: the pieces' partial potentials, the decisions, (learning) the pieces' gradients
+  {
+    const auto &gt = s->bgiant_tiles;
+    const uint32_t g0 = (uint32_t)(std::lower_bound(gt.begin(), gt.end(), t0) - gt.begin());
+    const uint32_t g1 = (uint32_t)(std::lower_bound(gt.begin(), gt.end(), t1) - gt.begin());
+    if (g1 > g0) {
+      const uint32_t p0 = s->bgiant_piece_off[g0], np = s->bgiant_piece_off[g1] - p0;
+      rt::launch(giant_pot_kernel<LEARN>, np, GIANT_THREADS, 0, s->stream, P, (const uint32_t *)s->d_bgiant,
+                 (const GiantPiece *)s->d_bgiant_pieces, p0, np, s->d_bgiant_partial);
+      rt::launch(giant_decide_kernel<LEARN>, (g1 - g0 + BLOCK_THREADS - 1) / BLOCK_THREADS, BLOCK_THREADS, 0, s->stream, P,
+                 (const uint32_t *)s->d_bgiant, (const uint32_t *)s->d_bgiant_piece_off, g0, g1 - g0,
+                 (const double *)s->d_bgiant_partial, s->d_bgiant_decision);
+      launches += 2;
+      if (LEARN) {
+        rt::launch(giant_grad_kernel, np, GIANT_THREADS, 0, s->stream, P, (const uint32_t *)s->d_bgiant,
+                   (const GiantPiece *)s->d_bgiant_pieces, p0, np, (const uint32_t *)s->d_bgiant_decision);
+        ++launches;
+      }
+    }
   }
   // mid-degree variables among these tiles: a wave each
   const uint32_t *wb = c.wide_tiles.data() + c.launch_wide[l], *we = c.wide_tiles.data() + c.launch_wide[l + 1];
@@ -905,14 +930,13 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
   const dwx_sampler::Chunk &ch = s->plan_chunks[chunk];
   KernelParams P = s->base;
   P.sweep = s->sweep;
-  P.dyn = s->capturing ? s->d_dyn : nullptr;
   const dwx_sampler::Level &L = *s->plan_level;
   const bool split = s->plan_batches > 1;
   // a split sweep without per-chunk tables falls back to per-record atomics and counts
   const bool fast = L.fast && !(split && s->plan_force_dynamic);
   if (split && !fast) P.flags |= OPT_DYNAMIC_T | OPT_NO_PULL;
   TimedSpan sp{};
-  const bool timing = s->timing && !s->capturing;
+  const bool timing = s->timing;
   if (timing) {
     sp.a = rt::event_create(); sp.b = rt::event_create(); sp.c = rt::event_create(); sp.kind = 1;
     rt::event_record(sp.a, s->stream);
@@ -986,7 +1010,7 @@ void enqueue_apply(dwx_sampler *s) {
   }
   rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
              (const uint8_t *)s->d_w_fixed, s->d_grad, ts, hs, W, s->plan_eta, s->opts.reg_param,
-             (int)(s->opts.regularization == 1), (const SweepDyn *)(s->capturing ? s->d_dyn : nullptr));
+             (int)(s->opts.regularization == 1));
 }
 
 void drain_spans(dwx_sampler *s) {
@@ -1105,7 +1129,6 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     s->device = opts->device;
     const CompiledGraph &c = *s->cg;
     s->stream = rt::stream_create();
-    s->graphs_enabled = getenv("DWX_NO_GRAPH") == nullptr;     // (A/B and test switch)
     rt::stream_t st = s->stream;
     const bool timing = getenv("DWX_TIMING") != nullptr;   // wall time of every phase on stderr
     auto t_phase = std::chrono::steady_clock::now();
@@ -1128,8 +1151,26 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       if (c.ecap > 6 * BLOCK_THREADS) for (auto &t : tiles) t.flags &= ~TILE_TERMS2;
       s->d_tiles = upload(tiles, st);
     }
-    s->d_giant = upload(c.giant_tiles, st);
+    for (uint32_t ti : c.giant_tiles) ((c.tiles[ti].flags & TILE_CATEGORICAL) ? s->cgiant_tiles : s->bgiant_tiles).push_back(ti);
+    s->d_giant = upload(s->cgiant_tiles, st);
     s->d_wide = upload(c.wide_tiles, st);
+    {
+      std::vector<GiantPiece> pieces;
+      s->bgiant_piece_off.assign(1, 0u);
+      for (uint32_t slot = 0; slot < s->bgiant_tiles.size(); ++slot) {
+        const TileDesc &td = c.tiles[s->bgiant_tiles[slot]];
+        for (uint32_t e = td.e0; e < td.e0 + td.nedges; e += GIANT_PIECE)
+          pieces.push_back(GiantPiece{slot, e, std::min(e + GIANT_PIECE, td.e0 + td.nedges), 0u});
+        if (!td.nedges) pieces.push_back(GiantPiece{slot, td.e0, td.e0, 0u});
+        s->bgiant_piece_off.push_back((uint32_t)pieces.size());
+      }
+      s->d_bgiant = upload(s->bgiant_tiles, st);
+      s->d_bgiant_piece_off = upload(s->bgiant_piece_off, st);
+      s->d_bgiant_pieces = upload(pieces, st);
+      s->d_bgiant_partial = (double *)rt::dmalloc(std::max<size_t>(1, pieces.size()) * 4 * 8);
+      rt::dmemset(s->d_bgiant_partial, 0, std::max<size_t>(1, pieces.size()) * 4 * 8, st);
+      s->d_bgiant_decision = (uint32_t *)rt::dmalloc(std::max<size_t>(1, s->bgiant_tiles.size()) * 16);
+    }
     if (!c.row_truth.empty()) s->d_row_truth = upload(c.row_truth, st);
     if (!c.edge_fval64.empty()) s->d_edge_fval64 = upload(c.edge_fval64, st);
     s->d_edges = upload(c.edges, st, 1);
@@ -1359,8 +1400,6 @@ int dwx_sgd_plan_rows(dwx_sampler *s, uint32_t n_rows) {
     rt::dfree(L.d_t_static);
     L.d_t_static = grown;
     L.rows = n_rows;
-    for (auto &g : s->sgd_graphs) rt::graph_destroy(g.second);   // (they captured the old table)
-    s->sgd_graphs.clear();
   });
 }
 
@@ -1408,42 +1447,10 @@ int dwx_sample_sgd_async(dwx_sampler *s, double stepsize) {
   return guarded([&]() {
     make_plan(s, stepsize, 0);
     const size_t n = s->plan_chunks.size();
-    auto enqueue_all = [&]() {
-      for (size_t c = 0; c < n; ++c) {
-        s->cur_chunk = (uint32_t)c;
-        enqueue_learn_chunk(s, (uint32_t)c);
-        if (s->plan_batches > 1 || c + 1 == n) enqueue_apply(s);
-      }
-    };
-    // A sweep cut into many mini-batches is thousands of small launches (64 batches x colours x
-    // {sweep, oversized, wide, pull, apply}): launch-bound.  Capture it once per batch count --
-    // every table and range of a plan level is fixed -- and replay it; the sweep counter and the
-    // step come from device memory (SweepDyn), set by one tiny launch in front.
-    const bool graph = rt::kGraphs && s->graphs_enabled && !s->timing && s->plan_batches > 1 && n >= 8;
-    if (graph) {
-      rt::set_device(s->device);
-      if (!s->d_dyn) s->d_dyn = (SweepDyn *)rt::dmalloc(sizeof(SweepDyn));
-      auto it = s->sgd_graphs.find(s->plan_batches);
-      if (it == s->sgd_graphs.end()) {
-        s->capturing = true;
-        rt::graph_exec_t ge = nullptr;
-        try {
-          rt::capture_begin(s->stream);
-          enqueue_all();
-          ge = rt::capture_end(s->stream);
-        } catch (...) {
-          s->capturing = false;
-          throw;
-        }
-        s->capturing = false;
-        it = s->sgd_graphs.emplace(s->plan_batches, ge).first;
-      }
-      rt::launch(set_dyn_kernel, 1, 1, 0, s->stream, s->d_dyn, (uint64_t)s->sweep, s->plan_eta);
-      rt::graph_launch(it->second, s->stream);
-      s->terms_state = 0;    // (what enqueue_apply does on the host: the weights change)
-      s->cur_chunk = (uint32_t)(n ? n - 1 : 0);
-    } else {
-      enqueue_all();
+    for (size_t c = 0; c < n; ++c) {
+      s->cur_chunk = (uint32_t)c;
+      enqueue_learn_chunk(s, (uint32_t)c);
+      if (s->plan_batches > 1 || c + 1 == n) enqueue_apply(s);
     }
     ++s->sweep;
     s->plan_valid = false;

@@ -101,23 +101,6 @@ inline unsigned cu_count() {
   return (unsigned)std::max(1, cus);
 }
 
-// HIP graphs: a launch-bound sequence (a learning sweep cut into dozens of mini-batches) is
-// captured once from the stream and replayed
-typedef hipGraphExec_t graph_exec_t;
-constexpr bool kGraphs = true;
-inline void capture_begin(stream_t s) { DWX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal)); }
-inline graph_exec_t capture_end(stream_t s) {
-  hipGraph_t g = nullptr;
-  DWX_HIP(hipStreamEndCapture(s, &g));
-  hipGraphExec_t e = nullptr;
-  hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(g);
-  check(rc, "hipGraphInstantiate");
-  return e;
-}
-inline void graph_launch(graph_exec_t e, stream_t s) { DWX_HIP(hipGraphLaunch(e, s)); }
-inline void graph_destroy(graph_exec_t e) { if (e) (void)hipGraphExecDestroy(e); }
-
 template <class K, class... A>
 inline void launch(K kernel, unsigned grid, unsigned block, size_t lds, stream_t s, A... args) {
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, args...);

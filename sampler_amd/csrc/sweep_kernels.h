@@ -79,10 +79,6 @@ DWX_DEV void philox_uniforms(uint64_t seed, uint64_t vid, uint64_t sweep, double
   B = (double)(b >> 11) * (1.0 / 9007199254740992.0);
 }
 
-// the sweep counter of this launch (Philox counter word): by value, or -- inside a replayed HIP
-// graph -- from device memory
-DWX_DEV uint64_t current_sweep(const KernelParams &P) { return P.dyn ? P.dyn->sweep : P.sweep; }
-
 // ---------------------------------------------------------------- math
 // src/common.h:118-132
 DWX_DEV double logadd(double a, double b) {
@@ -364,7 +360,10 @@ DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const Vif
 //              effects happen once
 //   W_COOPB    (giant_kernel) the same with a whole WORKGROUP of GIANT_THREADS lanes and an
 //              LDS tree for the sums
-enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4, W_COOP = 5, W_COOPB = 6 };
+//   W_PRESUM   (giant_decide_kernel) the potentials of a boolean variable are already summed
+//              (TileView::presum); one lane decides, the gradient rows are walked elsewhere
+enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4, W_COOP = 5, W_COOPB = 6, W_PRESUM = 7 };
+constexpr uint32_t GIANT_PIECE = 8192;     // records per workgroup of a boolean oversized variable
 constexpr uint32_t GIANT_THREADS = 1024;   // lanes per oversized variable (giant_kernel)
 constexpr uint32_t COOP_U = 4;             // records per lane and step of a cooperative walk
 
@@ -446,6 +445,11 @@ struct TileView {
   const float *w;          // W_ARRAY: staged weights, indexed like edges
   long long *agg;          // LDS gradient accumulators [2W] (learning, small W) or null
   double *pot;             // per-row potential scratch (row - row_bias), or null
+  // W_PRESUM (giant_decide_kernel): the boolean variable's four potentials {free 1, free 0,
+  // evidence 1, evidence 0} were summed by other workgroups; its gradient walk is left to them
+  // too -- the decision goes here: {evidence value, free value, 1 | count_t << 1, -}
+  const double *presum = nullptr;
+  uint32_t *decision = nullptr;
 };
 
 DWX_DEV uint32_t edge_func(const EdgeRec &e) { return e.packed & EDGE_FUNC_MASK; }
@@ -649,6 +653,11 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
                              const uint32_t *assign, uint32_t me, double &pp, double &pn) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   pp = 0.0; pn = 0.0;
+  if (WMODE == W_PRESUM) {   // (inference: the evidence chain's sums; learning, free chain only: the free chain's)
+    const bool evid = assign == P.assign_evid;
+    pp = T.presum[evid ? 2 : 0]; pn = T.presum[evid ? 3 : 1];
+    return;
+  }
   if (Coop<WMODE>::on) {
     const uint32_t *const chains[1] = {assign};
     const int chain[2] = {0, 0};
@@ -759,6 +768,10 @@ DWX_DEV void bool_potentials_both(const KernelParams &P, const TileView &T, uint
                                   double &ppf, double &pnf, double &ppe, double &pne) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   ppf = 0.0; pnf = 0.0; ppe = 0.0; pne = 0.0;
+  if (WMODE == W_PRESUM) {
+    ppf = T.presum[0]; pnf = T.presum[1]; ppe = T.presum[2]; pne = T.presum[3];
+    return;
+  }
   if (Coop<WMODE>::on) {
     const uint32_t *const chains[2] = {P.assign_free, P.assign_evid};
     const int chain[4] = {0, 0, 1, 1};
@@ -933,24 +946,35 @@ DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row
 // static and were folded into T_static on the host (dwx_sampler_create).
 // hit_value: the proposal that "hits" a pre-signed record of this row (1 for a boolean
 // variable, the row's value for a categorical one).
+// sgd_on_factor over records [es, ee), shared out over the lanes of a cooperating group
+template <int WMODE>
+DWX_DEV void coop_sgd_range(const KernelParams &P, const TileView &T, uint32_t es, uint32_t ee, uint32_t me,
+                            uint32_t evid_value, uint32_t free_value, uint32_t hit_value, double t, bool count_t) {
+  const uint32_t *const chains[2] = {P.assign_evid, P.assign_free};
+  const int chain[2] = {0, 1};
+  const uint32_t prop[2] = {evid_value, free_value};
+  const bool hit[2] = {evid_value == hit_value, free_value == hit_value};
+  coop_for_records<WMODE, 2, 2>(P, T, es, ee, me, chains, chain, prop, hit,
+                                [&](const EdgeRec &er, uint32_t, double, const double (&term)[2]) {
+    if (er.packed & EDGE_FIXED_FLAG) return;   // weights_isfixed (src/factor_graph.cc:247)
+    const long long gi = llrint(FIX_SCALE * (t * (term[1] - term[0])));
+    if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
+    if (count_t) atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)llrint(FIX_SCALE * t));
+  });
+}
+
 // W_COOP / W_COOPB: the lanes of the cooperating group share the row's records.
 template <bool SIMPLE, int WMODE = W_GLOBAL>
 DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uint32_t me,
                      uint32_t evid_value, uint32_t free_value, uint32_t hit_value, double t,
                      const bool count_t) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
+  if (WMODE == W_PRESUM) {   // boolean only (hit_value 1, t 1): the pieces' workgroups walk the row
+    T.decision[0] = evid_value; T.decision[1] = free_value; T.decision[2] = 1u | (count_t ? 2u : 0u);
+    return;
+  }
   if (Coop<WMODE>::on) {
-    const uint32_t *const chains[2] = {P.assign_evid, P.assign_free};
-    const int chain[2] = {0, 1};
-    const uint32_t prop[2] = {evid_value, free_value};
-    const bool hit[2] = {evid_value == hit_value, free_value == hit_value};
-    coop_for_records<WMODE, 2, 2>(P, T, es, ee, me, chains, chain, prop, hit,
-                                  [&](const EdgeRec &er, uint32_t, double, const double (&term)[2]) {
-      if (er.packed & EDGE_FIXED_FLAG) return;
-      const long long gi = llrint(FIX_SCALE * (t * (term[1] - term[0])));
-      if (gi) atomicAdd((unsigned long long *)&P.grad[er.wid], (unsigned long long)gi);
-      if (count_t) atomicAdd((unsigned long long *)&P.grad[P.num_weights + er.wid], (unsigned long long)llrint(FIX_SCALE * t));
-    });
+    coop_sgd_range<WMODE>(P, T, es, ee, me, evid_value, free_value, hit_value, t, count_t);
     return;
   }
   for (uint32_t e = es; e < ee; ++e) {
@@ -1347,7 +1371,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
         for (int k = 0; k < K; ++k) w[k] = 0.0f;
       }
       // ... and draw this lane's uniforms while the gathers are in flight
-      philox_uniforms(P.seed, P.vid_offset + pre.orig, current_sweep(P), A, B);
+      philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
       // unconditional LDS writes: slots past the tile's last record receive copies of
       // it and are never read
       // (TILE_TERMS2 staging keeps two vif records and the neighbour values per staged
@@ -1627,7 +1651,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
         for (int k = 0; k < K; ++k) w[k] = P.w32[f.rec[k].key & REC8_WID_MASK];
       }
       // ... and this lane's uniforms while the gathers are in flight
-      philox_uniforms(P.seed, P.vid_offset + pre.orig, current_sweep(P), A, B);
+      philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
       if (TAB) {
         // the table's entries go to LDS as they are (8 bytes per record: half the staging
         // area of the 16-byte modes, more workgroups per CU); the row walk decodes them
@@ -1736,9 +1760,92 @@ __global__ void __launch_bounds__(GIANT_THREADS) giant_kernel(const KernelParams
   const uint32_t p = d.v0;
   const VarPre vp = load_var_pre<LEARN>(P, p);
   double A, B;
-  philox_uniforms(P.seed, P.vid_offset + vp.orig, current_sweep(P), A, B);
+  philox_uniforms(P.seed, P.vid_offset + vp.orig, P.sweep, A, B);
   const TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr, nullptr};
   process_variable<LEARN, W_COOPB, false>(P, T, p, vp, A, B);
+}
+
+// BOOLEAN oversized variables, several workgroups each.  One workgroup sits on one CU, and a CU
+// turns around one scattered request every ~2.3 cycles (tools/gather_bench): a hub with 10^5
+// records kept its workgroup busy for 0.3 ms while the rest of the chip idled, once per colour.
+// So the row is cut into pieces of GIANT_PIECE records and the variable handled in three steps:
+//   giant_pot_kernel     one workgroup per piece: the piece's share of the four potentials
+//                        (free / evidence chain x proposal 1 / 0) -> partial[piece][4]
+//   giant_decide_kernel  one lane per variable: adds its pieces' shares IN PIECE ORDER and runs
+//                        process_variable<W_PRESUM> -- draws, stores, tallies; the gradient walk
+//                        is only decided ({evidence value, free value}) -> decision[variable]
+//   giant_grad_kernel    (learning) one workgroup per piece again: sgd_on_factor over the piece
+// Categorical oversized variables (a row per value) keep the single workgroup of giant_kernel.
+struct GiantPiece { uint32_t slot, e0, e1, pad; };   // slot: index into the boolean-giant list
+
+template <bool LEARN>
+__global__ void __launch_bounds__(GIANT_THREADS)
+giant_pot_kernel(const KernelParams P, const uint32_t *bgiant_tiles, const GiantPiece *pieces, uint32_t piece0,
+                 uint32_t n, double *partial) {
+  if (blockIdx.x >= n) return;
+  const GiantPiece pc = pieces[piece0 + blockIdx.x];
+  const uint32_t p = P.tiles[bgiant_tiles[pc.slot]].v0;
+  const TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr, nullptr};
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (LEARN) {
+    const uint32_t *const chains[2] = {P.assign_free, P.assign_evid};
+    const int chain[4] = {0, 0, 1, 1};
+    const uint32_t prop[4] = {1u, 0u, 1u, 0u};
+    const bool hit[4] = {true, false, true, false};
+    coop_for_records<W_COOPB, 4, 2>(P, T, pc.e0, pc.e1, p, chains, chain, prop, hit,
+                                    [&](const EdgeRec &, uint32_t, double w, const double (&term)[4]) {
+#pragma unroll
+                                      for (int j = 0; j < 4; ++j) acc[j] += w * term[j];
+                                    });
+  } else {
+    const uint32_t *const chains[1] = {P.assign_evid};
+    const int chain[2] = {0, 0};
+    const uint32_t prop[2] = {1u, 0u};
+    const bool hit[2] = {true, false};
+    coop_for_records<W_COOPB, 2, 1>(P, T, pc.e0, pc.e1, p, chains, chain, prop, hit,
+                                    [&](const EdgeRec &, uint32_t, double w, const double (&term)[2]) {
+                                      acc[2] += w * term[0];
+                                      acc[3] += w * term[1];
+                                    });
+  }
+#pragma unroll
+  for (int j = LEARN ? 0 : 2; j < 4; ++j) {
+    const double v = block_sum_all(acc[j]);
+    if (threadIdx.x == 0) partial[(size_t)(piece0 + blockIdx.x) * 4 + j] = v;
+  }
+}
+
+template <bool LEARN>
+__global__ void __launch_bounds__(BLOCK_THREADS)
+giant_decide_kernel(const KernelParams P, const uint32_t *bgiant_tiles, const uint32_t *piece_off, uint32_t slot0,
+                    uint32_t n, const double *partial, uint32_t *decision) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t slot = slot0 + i, p = P.tiles[bgiant_tiles[slot]].v0;
+  double sums[4] = {0.0, 0.0, 0.0, 0.0};
+  for (uint32_t k = piece_off[slot]; k < piece_off[slot + 1]; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sums[j] += partial[(size_t)k * 4 + j];
+  uint32_t *dec = decision + (size_t)slot * 4;
+  dec[2] = 0u;
+  const VarPre vp = load_var_pre<LEARN>(P, p);
+  double A, B;
+  philox_uniforms(P.seed, P.vid_offset + vp.orig, P.sweep, A, B);
+  TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr, nullptr};
+  T.presum = sums; T.decision = dec;
+  process_variable<LEARN, W_PRESUM, false>(P, T, p, vp, A, B);
+}
+
+__global__ void __launch_bounds__(GIANT_THREADS)
+giant_grad_kernel(const KernelParams P, const uint32_t *bgiant_tiles, const GiantPiece *pieces, uint32_t piece0,
+                  uint32_t n, const uint32_t *decision) {
+  if (blockIdx.x >= n) return;
+  const GiantPiece pc = pieces[piece0 + blockIdx.x];
+  const uint32_t *dec = decision + (size_t)pc.slot * 4;
+  if (!(dec[2] & 1u)) return;      // (uniform over the workgroup) this variable does not learn now
+  const uint32_t p = P.tiles[bgiant_tiles[pc.slot]].v0;
+  const TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr, nullptr};
+  coop_sgd_range<W_COOPB>(P, T, pc.e0, pc.e1, p, dec[0], dec[1], 1u, 1.0, (dec[2] & 2u) != 0);
 }
 
 // Degree bin between the lane-per-variable tiles and giant_kernel: a variable
@@ -1761,7 +1868,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) wide_kernel(const KernelParams 
   const uint32_t p = d.v0;
   const VarPre vp = load_var_pre<LEARN>(P, p);
   double A, B;
-  philox_uniforms(P.seed, P.vid_offset + vp.orig, current_sweep(P), A, B);
+  philox_uniforms(P.seed, P.vid_offset + vp.orig, P.sweep, A, B);
   const TileView T{P.row_ptr, 0u, P.edges, 0u, nullptr, nullptr, nullptr};
   process_variable<LEARN, W_COOP, false>(P, T, p, vp, A, B);
 }
@@ -1946,8 +2053,7 @@ DWX_DEV double saturating_step(double c, double stepsize) {
 __global__ void __launch_bounds__(BLOCK_THREADS)
 apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *grad,
              const long long *t_static, const long long *t_hess, uint32_t W, double stepsize,
-             double reg_param, int l2, const SweepDyn *dyn) {
-  if (dyn) stepsize = dyn->stepsize;     // (graph replay: this sweep's step)
+             double reg_param, int l2) {
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride) {
     const long long G = grad[i], Td = grad[W + i];
@@ -2023,11 +2129,6 @@ build_terms8_kernel(const EdgeRec8 *edges8, uint64_t n, const float *w32, unsign
     __builtin_memcpy(&u, &wf, 8);
     terms[i] = u | ((c.key >> REC8_HIT_SHIFT) & 15u);   // hit code in bits 0-1, miss code in bits 2-3
   }
-}
-
-// the per-sweep scalars of a captured learning sweep (see SweepDyn)
-__global__ void set_dyn_kernel(SweepDyn *dyn, uint64_t sweep, double stepsize) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { dyn->sweep = sweep; dyn->stepsize = stepsize; }
 }
 
 // f64 master weights -> f32 sampling copy (after dwx_set_weights)

@@ -46,14 +46,6 @@ inline unsigned resident_blocks(K, unsigned, size_t) { return 3; }
 
 inline unsigned cu_count() { return 5; }
 
-// no graphs under emulation: learning sweeps always take the direct path
-typedef void *graph_exec_t;
-constexpr bool kGraphs = false;
-inline void capture_begin(stream_t) {}
-inline graph_exec_t capture_end(stream_t) { return nullptr; }
-inline void graph_launch(graph_exec_t, stream_t) {}
-inline void graph_destroy(graph_exec_t) {}
-
 template <class K, class... A>
 inline void launch(K kernel, unsigned grid, unsigned block, size_t lds, stream_t, A... args) {
   emu::run_grid(grid, block, lds, [&]() { kernel(args...); });

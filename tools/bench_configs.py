@@ -38,8 +38,7 @@ def run(name, raw, n_learn, n_infer, stepsize=0.001, **kw):
     # kernels, not apply_kernel)
     ns_l = n_learn
     ms_l = ms_l + ms_p
-    # wall time per sweep with the event timing off: what `dw gibbs` sees -- split learning
-    # sweeps then run as captured HIP graphs
+    # wall time per sweep with the event timing off: what `dw gibbs` sees
     s.kernel_time_reset(False)
     wall = {}
     for kind, n in (("learn", n_learn), ("infer", n_infer)):
@@ -62,7 +61,6 @@ def run(name, raw, n_learn, n_infer, stepsize=0.001, **kw):
            "learn_ms_per_sweep": ms_l / max(ns_l, 1) if ns_l else None,
            "learn_vars_per_s": V / (ms_l / ns_l * 1e-3) if ns_l else None,
            "learn_wall_ms_per_sweep": wall.get("learn"), "infer_wall_ms_per_sweep": wall.get("infer"),
-           "hip_graphs": os.environ.get("DWX_NO_GRAPH") is None,
            "sgd_batches": batches, "sgd_chunks": n_chunks, "min_weight_stepsize": eta}
     print(json.dumps(out), flush=True)
     s.close()
