@@ -409,7 +409,7 @@ def main():
         if wl == "cfg3":
             gathers = RECORDS_PER_VAR[wl] * units
             peak = None if args.no_gather_ceiling else gather_ceiling()
-            committed = 1.87e11     # profiles/r02/gather_bench.jsonl: stream mode, 4 MB, 3 waves/SIMD
+            committed = 1.874e11    # profiles/r02/gather_bench.jsonl: stream mode, 4 MB, 3 waves/SIMD
             g_ach = gathers / (per_sweep_ms * 1e-3)
             roofline["secondary"] = {"bound": "l2_req", "what": "random 4-byte weight gathers (one 128-byte L2 "
                                      "request per record) next to the 8-byte record stream",

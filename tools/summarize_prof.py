@@ -25,7 +25,8 @@ def short(name):
         return "sweep_kernel<LEARN=true>"
     if "sweep_kernel<false" in name or "sweep_kernelILb0" in name:
         return "sweep_kernel<LEARN=false>"
-    for k in ("apply_kernel", "giant_kernel", "refresh_w32_kernel"):
+    for k in ("apply_kernel", "giant_pot_kernel", "giant_decide_kernel", "giant_grad_kernel", "giant_kernel",
+              "wide_kernel", "build_terms8_kernel", "build_terms_kernel", "refresh_w32_kernel"):
         if k in name:
             return k
     return name[:60]
