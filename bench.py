@@ -239,13 +239,22 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the dwx sampler has no CPU fallback")
-    if torch.cuda.device_count() <= local_rank:
+    if torch.cuda.device_count() <= local_rank and os.environ.get("DWX_BENCH_STACK_ON_GPU0") != "1":
         sys.exit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, local_rank, torch.cuda.device_count()))
+    # DWX_BENCH_BACKEND=gloo + DWX_BENCH_STACK_ON_GPU0=1: a rehearsal of the multi-rank control
+    # flow (plan agreement, collectives, halo exchange) on a box with ONE GPU, which RCCL
+    # cannot do (it refuses two ranks on one device); tests only -- the line says so
+    backend = os.environ.get("DWX_BENCH_BACKEND", "nccl")
+    if os.environ.get("DWX_BENCH_STACK_ON_GPU0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     rccl_ranks = 1
     if use_dist:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         t = torch.ones(1, device="cuda")
         dist.all_reduce(t)
         rccl_ranks = int(t.item())          # how many ranks RCCL actually joined
@@ -296,7 +305,7 @@ def main():
         engine.wait()
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     cur = stepsize
@@ -422,7 +431,7 @@ def main():
             "metric": "variables sampled/sec (whole node)",
             "value": total_vars / elapsed,
             "unit": "variables/s",
-            "n_gpus": n_gpus, "rccl_ranks": rccl_ranks if use_dist else None,
+            "n_gpus": n_gpus, "rccl_ranks": rccl_ranks if use_dist else None, "backend": backend if use_dist else None,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "repeats": repeats,

@@ -364,7 +364,10 @@ DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const Vif
 //              (TileView::presum); one lane decides, the gradient rows are walked elsewhere
 enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4, W_COOP = 5, W_COOPB = 6, W_PRESUM = 7 };
 constexpr uint32_t GIANT_PIECE = 8192;     // records per workgroup of a boolean oversized variable
-constexpr uint32_t GIANT_THREADS = 1024;   // lanes per oversized variable (giant_kernel)
+#ifndef DWX_GIANT_THREADS
+#define DWX_GIANT_THREADS 1024
+#endif
+constexpr uint32_t GIANT_THREADS = DWX_GIANT_THREADS;   // lanes per oversized variable (giant kernels)
 constexpr uint32_t COOP_U = 4;             // records per lane and step of a cooperative walk
 
 // sum over the 64 lanes of a wave, the same value (and the same association: the xor

@@ -70,3 +70,31 @@ def test_bench_cfg5b_workload_runs_the_pairwise_kernels_and_the_collective_path(
     d = _check(r.stdout, 1)
     assert d["config"]["colours"] >= 2 and "cfg5b" in d["config"]["workload"]
     assert d["roofline"]["kernel"].startswith("sweep_kernel") and d["roofline"]["launches_per_sweep"] >= 2
+
+
+@pytest.mark.gpu
+def test_bench_cfg5b_two_ranks_rehearsal_on_one_gpu_over_gloo():
+    """The multi-rank control flow of bench.py with the product engine -- self-launch, global
+    mini-batch plan, gradient all-reduce per mini-batch, per-shard config-5b generator, halo lists
+    of the C ABI, ghost refresh after every sweep, per-block MAX over ranks -- with two ranks
+    stacked on the one GPU of the test box over gloo (RCCL refuses two ranks per device; the line
+    names its backend, nobody will mistake it for a measurement)."""
+    env = dict(os.environ, DWX_BENCH_BACKEND="gloo", DWX_BENCH_STACK_ON_GPU0="1",
+               DWX_BENCH_SKIP_DEVICE_COUNT_CHECK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for wl in ("cfg5b", "cfg3"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", wl,
+                            "--steps", "3", "--warmup", "1", "--vars-per-gpu", "200000", "--min-time", "0.05"],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        d = _check(r.stdout, 2)
+        assert d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["launcher"] == "self"
+        assert d["allreduce_calls_per_step"] >= 1
+        if wl == "cfg5b":
+            # the V/8 + 3 offset of a 400k-variable graph crosses the block boundary for 50k
+            # variables each way, the small offsets for a handful
+            assert d["config"]["ghost_variables_per_gpu"] > 50_000
+            assert d["halo_ms_per_step"] > 0 and d["halo_bytes_per_step"] > 4 * 3 * 50_000
+        else:
+            assert d["config"]["ghost_variables_per_gpu"] == 0 and d["halo_bytes_per_step"] == 0
