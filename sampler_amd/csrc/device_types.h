@@ -104,6 +104,11 @@ constexpr uint32_t TILE_INLINE2 = 1u << 4;
 //   TILE_WIDE   fits, but has more than wide_min_records records (a lane-per-variable walk
 //               would serialise them while its 255 neighbours idle); one WAVE per variable,
 //               four variables per workgroup (wide_kernel)
+// Boolean tile whose records are pre-signed or factors of arity 2 or 3 (f32-exact values) with at
+// least one of arity 3: evaluated edge-parallel in the staging pass like TILE_TERMS2, through the
+// general sign functions on batched loads (three factor->variable entries per record, then their
+// assignments).  K <= 6 builds.
+constexpr uint32_t TILE_TERMS3 = 1u << 7;
 constexpr uint32_t TILE_GIANT = 1u << 5;
 constexpr uint32_t TILE_WIDE = 1u << 6;
 constexpr uint32_t TILE_OUTSIDE = TILE_GIANT | TILE_WIDE;

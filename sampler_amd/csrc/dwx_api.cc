@@ -1148,7 +1148,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       // edge-parallel evaluation of binary factors is compiled for K <= 6 only (register
       // budget): with 3072-record tiles such tiles take the generic path
       std::vector<TileDesc> tiles = c.tiles;
-      if (c.ecap > 6 * BLOCK_THREADS) for (auto &t : tiles) t.flags &= ~TILE_TERMS2;
+      if (c.ecap > 6 * BLOCK_THREADS) for (auto &t : tiles) t.flags &= ~(TILE_TERMS2 | TILE_TERMS3);
       s->d_tiles = upload(tiles, st);
     }
     for (uint32_t ti : c.giant_tiles) ((c.tiles[ti].flags & TILE_CATEGORICAL) ? s->cgiant_tiles : s->bgiant_tiles).push_back(ti);

@@ -501,20 +501,26 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       t.v0 = v0; t.nv = v1 - v0;
       t.r0 = g.v_row[v0]; t.nrows = g.v_row[v1] - g.v_row[v0];
       t.e0 = g.row_ptr[g.v_row[v0]]; t.nedges = g.row_ptr[g.v_row[v1]] - g.row_ptr[g.v_row[v0]];
-      bool simple = true, terms2 = true;
+      bool simple = true, terms2 = true, terms3 = true;
       for (uint32_t e = t.e0; e < t.e0 + t.nedges; ++e) {
         const uint32_t pk = g.edges[e].packed;
         const bool pre = (pk & EDGE_PRESIGNED) != 0;
+        const uint32_t ar = (pk >> EDGE_ARITY_SHIFT) & EDGE_ARITY_MASK;
         simple = simple && pre;
-        terms2 = terms2 && (pre || (((pk >> EDGE_ARITY_SHIFT) & EDGE_ARITY_MASK) == 2 && !(pk & EDGE_F64_FLAG)));
+        terms2 = terms2 && (pre || (ar == 2 && !(pk & EDGE_F64_FLAG)));
+        // (the staged sign * feature value products must be f32-exact: every sign function is
+        // integer-valued at arity <= 3 except RATIO, log2(3) with two unsatisfied body atoms)
+        terms3 = terms3 && (pre || (!(pk & EDGE_F64_FLAG) &&
+                                    (ar == 2 || (ar == 3 && (pk & EDGE_FUNC_MASK) != FUNC_RATIO))));
       }
       const bool cat = g.v_meta[v0] & VM_CATEGORICAL;
       const bool giant = t.nrows > g.rcap || t.nedges > g.ecap;
       const uint32_t outside = giant ? TILE_GIANT : (tile_wide[i] ? TILE_WIDE : 0u);
       t.flags = (simple ? TILE_SIMPLE : 0u) | (cat ? TILE_CATEGORICAL : 0u) | outside |
                 ((simple && !cat && W > LDS_AGG_MAX_W && !outside) ? TILE_PULL : 0u) |
-                ((terms2 && !simple && !cat && t.nv <= 256 && !outside) ? TILE_TERMS2 : 0u);
-      if (t.flags & TILE_TERMS2) ++n_terms2;
+                ((terms2 && !simple && !cat && t.nv <= 256 && !outside) ? TILE_TERMS2 : 0u) |
+                ((terms3 && !terms2 && !simple && !cat && t.nv <= 256 && !outside) ? TILE_TERMS3 : 0u);
+      if (t.flags & (TILE_TERMS2 | TILE_TERMS3)) ++n_terms2;
       // arity-2 records carry their two vif entries themselves where the kernels that will
       // see the tile implement it (the K <= 6 builds; not the oversized-variable kernel) and
       // the predicates fit 7 bits

@@ -1320,6 +1320,48 @@ DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t
   f.pre = load_var_pre<LEARN, NT>(P, d.v0 + umin(t, d.nv - 1));
 }
 
+// Edge-parallel evaluation of a tile's staged records whose factors have arity <= GEN_ARITY
+// (TILE_TERMS3): the lane's K records in three batched phases -- all their first three
+// factor->variable entries, then those variables' assignments on every chain, then the sign
+// functions on registers -- in NS scenarios at once (as coop_for_records).  out(k, term[NS]).
+template <int K, int NS, int NCHAIN, class Out>
+DWX_DEV void stage_generic_records(const KernelParams &P, const TileDesc &d, const EdgeRec (&rec)[K],
+                                   const uint32_t *const (&chains)[NCHAIN], const int (&chain)[NS],
+                                   const uint32_t (&prop)[NS], const bool (&hit)[NS], Out &&out) {
+  VifRec vf[K][GEN_ARITY];
+  uint32_t val[K][NCHAIN][GEN_ARITY];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const bool generic = !(rec[k].packed & EDGE_PRESIGNED);
+    const uint32_t ar = generic ? edge_arity(rec[k]) : 1u, base = (generic && ar >= 2u) ? rec[k].aux : 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < GEN_ARITY; ++i) vf[k][i] = P.vifs[base + umin(i, ar - 1u)];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int c = 0; c < NCHAIN; ++c)
+#pragma unroll
+      for (uint32_t i = 0; i < GEN_ARITY; ++i) val[k][c][i] = chains[c][vf[k][i].vid];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const EdgeRec r = rec[k];
+    double term[NS];
+    if (r.packed & EDGE_PRESIGNED) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) term[j] = (double)(hit[j] ? r.fval : bits_to_float(r.aux));
+    } else {
+      const uint32_t me = d.v0 + edge_owner_lane(r);
+      double sg[NS];
+      const VifsPreloaded<NS, NCHAIN> src{vf[k], val[k], chain};
+      factor_signs_from<NS>(edge_func(r), edge_arity(r), src, me, prop, sg);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) term[j] = sg[j] * (double)r.fval;
+    }
+    out(k, term);
+  }
+}
+
 // Persistent, software-pipelined sweep: workgroup b handles tiles b, b + gridDim.x, ...
 // of the launch.  While a tile is processed out of LDS, the NEXT tile's edge records,
 // row pointers and per-variable inputs are already in flight into registers, so the
@@ -1379,7 +1421,21 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
       // it and are never read
       // (TILE_TERMS2 staging keeps two vif records and the neighbour values per staged
       // record live: only instantiated for K <= 6; the host clears the flag for K = 12)
-      if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
+      if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS3)) {
+        // arity <= 3: the four sign * feature value products of every record (free / evidence
+        // chain x proposal 1 / 0) through the general sign functions on batched loads
+        LearnRec *s_lrec = (LearnRec *)s_edges;
+        const uint32_t *const chains[2] = {P.assign_free, P.assign_evid};
+        const int chain[4] = {0, 0, 1, 1};
+        const uint32_t prop[4] = {1u, 0u, 1u, 0u};
+        const bool hit[4] = {true, false, true, false};
+        stage_generic_records<K, 4, 2>(P, d, rec, chains, chain, prop, hit, [&](int k, const double (&term)[4]) {
+          LearnRec lr;
+          lr.wid = rec[k].wid; lr.packed = rec[k].packed; lr.w = w[k]; lr.pad = 0;
+          lr.sf1 = (float)term[0]; lr.sf0 = (float)term[1]; lr.se1 = (float)term[2]; lr.se0 = (float)term[3];
+          s_lrec[t + k * BLOCK_THREADS] = lr;
+        });
+      } else if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
         LearnRec *s_lrec = (LearnRec *)s_edges;
         VifRec va[K], vb[K];
         if (d.flags & TILE_INLINE2) {   // workgroup-uniform
@@ -1425,6 +1481,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
           }
           s_lrec[t + k * BLOCK_THREADS] = lr;
         }
+      } else if (K <= 6 && !LEARN && (d.flags & TILE_TERMS3)) {
+        // inference, arity <= 3: both proposals' terms of every record, edge-parallel
+        EdgeTerms *s_terms = (EdgeTerms *)s_edges;
+        const uint32_t *const chains[1] = {P.assign_evid};
+        const int chain[2] = {0, 0};
+        const uint32_t prop[2] = {1u, 0u};
+        const bool hit[2] = {true, false};
+        stage_generic_records<K, 2, 1>(P, d, rec, chains, chain, prop, hit, [&](int k, const double (&term)[2]) {
+          const double wv = (double)w[k];
+          EdgeTerms tt;
+          tt.t1 = wv * term[0];
+          tt.t0 = wv * term[1];
+          s_terms[t + k * BLOCK_THREADS] = tt;
+        });
       } else if (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)) {
         // inference, boolean tile with pre-signed and arity-2 records: evaluate every
         // record here.  Three batched phases so that a lane's K vif-pair loads, then its K
@@ -1556,11 +1626,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
     int delta = 0;
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
-      if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2))
+      if (K <= 6 && LEARN && WIDE && (d.flags & (TILE_TERMS2 | TILE_TERMS3)))
         learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B);
       else if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
         delta = process_variable<LEARN, W_TERMS, true>(P, T, d.v0 + t, pre, A, B, true);
-      else if ((d.flags & TILE_SIMPLE) || (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)))
+      else if ((d.flags & TILE_SIMPLE) || (K <= 6 && !LEARN && (d.flags & (TILE_TERMS2 | TILE_TERMS3))))
         delta = process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B, false);
       else
         process_variable<LEARN, WMODE, false>(P, T, d.v0 + t, pre, A, B);

@@ -204,6 +204,21 @@ def test_high_degree_hub_variables(lib):
     run_parity(lib, hub_graph(4, W=2000), n_learn=3, n_infer=3, stepsize=0.001, sample_evidence=True)
 
 
+def test_arity3_tiles_evaluated_edge_parallel(lib):
+    """TILE_TERMS3: tiles whose factors have arity <= 3 (the IMPLY-with-two-body-atoms shape of
+    DeepDive rules) evaluate every record in the staging pass through the general sign functions
+    on batched loads -- inference (two scenarios) and learning (four: both chains), every boolean
+    function, owners appearing twice in a factor, mixed with pre-signed and arity-2 records."""
+    from randgraph import random_graph
+    run_parity(lib, synthetic.cfg3c(3000, n_weights=60, seed=3), n_learn=3, n_infer=3, stepsize=0.01)
+    run_parity(lib, synthetic.cfg3c(1500, n_weights=40, seed=4), n_learn=3, n_infer=2, stepsize=0.01,
+               learn_non_evidence=True, sample_evidence=True)
+    for seed in (31, 32, 33):
+        raw = random_graph(seed, V=800, F=4000, W=30, p_cat=0.0, max_arity=3, exact_fvals=True)
+        run_parity(lib, raw, n_learn=3, n_infer=4, stepsize=0.05, learn_non_evidence=seed == 32,
+                   sample_evidence=seed == 33, compile_opts=dict(tile_vars=64))
+
+
 def test_degree_bins_lane_wave_workgroup(lib):
     """Degrees from 1 to thousands in one graph: low-degree variables in lane-per-variable
     tiles, mid-degree ones walked by a wave each (TILE_WIDE, wide_kernel), the largest by a
