@@ -318,7 +318,9 @@ def main():
     # blocks of EXACTLY --steps steps, fenced on both sides; at least one, until --min-time
     # seconds are timed.  The number of blocks must be the same on every rank: rank 0 decides.
     blocks_local, total = [], 0.0
-    while True:
+    cur_block = cur          # every block starts from the step the warm-up left: the same --steps
+    while True:              # steps of a run `-l K` each time (the mini-batch plan follows the step)
+        cur = cur_block
         t_start = time.perf_counter()
         for _ in range(args.steps):
             step(cur); cur *= decay
