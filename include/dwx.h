@@ -80,6 +80,9 @@ typedef struct dwx_compile_opts {
   uint32_t n_threads;          /* host threads for the build (0 = all cores)           */
   uint32_t no_compact_records; /* 1: keep 16-byte records even for all-unary graphs
                                   (default 0: such graphs stream 8-byte records)       */
+  uint32_t no_weight_order;    /* 1: keep variables in id order inside a class (default 0: an
+                                  all-unary graph orders them by the weight id of their first
+                                  factor -- locality for the weight gathers)              */
   uint32_t wide_min_records;   /* degree binning: a variable with more edge records than this
                                   is walked by a whole wave instead of one lane (default 192;
                                   0xFFFFFFFF: never)                                   */

@@ -306,15 +306,44 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     for (uint64_t v = 0; v < Vo; ++v) ++key_start[key_of(v) + 1];
     for (uint32_t k = 0; k < nkeys; ++k) key_start[k + 1] += key_start[k];
     g.perm.resize(V); g.pos.resize(V);
-    {
+    // All-unary graphs (no factor links two variables: the order inside a class is free, and the
+    // only locality a sweep can have is in its weight gathers): inside a class, variables are
+    // ordered by the weight id of their FIRST record.  The lanes that stage first records then
+    // gather neighbouring weights -- one or two L2 lines per wave-instruction instead of one per
+    // lane -- while every weight's records stay spread over the whole order but for that one
+    // (the sweeps are bound by L2 requests, one per gathered weight).  Only for
+    // lightly tied weights (<= 256 factors per weight on average): the order also puts a tenth of
+    // every weight's factors into one stretch of the sweep, and a learning sweep that has to be cut
+    // into mini-batches (heavily tied weights, section 3.5) wants every batch to see every weight's
+    // factors evenly -- there the gathers hit few lines anyway.
+    const bool by_weight = E == F && F > 0 && W <= (1u << 24) && F / std::max<uint64_t>(W, 1) <= 256 &&
+                           !o.no_weight_order;
+    if (by_weight) {
+      std::vector<uint32_t> first_wid(Vo, 0);
+      parallel_ranges(Vo, nth, [&](uint64_t vb, uint64_t ve) {
+        for (uint64_t v = vb; v < ve; ++v) {
+          const uint64_t r0 = g.ref_row_ptr[g.ref_var_val_base[v]], r1 = g.ref_row_ptr[g.ref_var_val_base[v] + (is_cat[v] ? card[v] : 1)];
+          first_wid[v] = r1 > r0 ? (uint32_t)d.fac_weight_id[g.ref_fidx[r0]] : 0u;
+        }
+      });
+      // stable counting sort by (class, first weight)
+      std::vector<uint32_t> cnt((size_t)nkeys * (W + 1) + 1, 0);
+      for (uint64_t v = 0; v < Vo; ++v) ++cnt[(size_t)key_of(v) * (W + 1) + first_wid[v] + 1];
+      for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+      for (uint64_t v = 0; v < Vo; ++v) {
+        const uint64_t p = cnt[(size_t)key_of(v) * (W + 1) + first_wid[v]]++;
+        g.perm[p] = (uint32_t)v; g.pos[v] = (uint32_t)p;
+        if (p != v) g.order_is_identity = false;
+      }
+    } else {
       std::vector<uint64_t> cur(key_start.begin(), key_start.end() - 1);
       for (uint64_t v = 0; v < Vo; ++v) {
         uint64_t p = cur[key_of(v)]++;
         g.perm[p] = (uint32_t)v; g.pos[v] = (uint32_t)p;
         if (p != v) g.order_is_identity = false;
       }
-      for (uint64_t v = Vo; v < V; ++v) { g.perm[v] = (uint32_t)v; g.pos[v] = (uint32_t)v; }  // ghosts last
     }
+    for (uint64_t v = Vo; v < V; ++v) { g.perm[v] = (uint32_t)v; g.pos[v] = (uint32_t)v; }  // ghosts last
     g.launch_off.clear();
     for (uint32_t c = 0; c < g.n_colors; ++c) g.launch_off.push_back(key_start[4 * c]);
     g.launch_off.push_back(Vo);
