@@ -398,9 +398,14 @@ void Rank::plan(double stepsize, uint32_t &batches, uint32_t &n_chunks, double &
       // no rank can cut finer than its tile count; the search ends at the largest (<= 64)
       max_batches_ = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, sh_.agree->max_u64(rank_, info_.num_tiles)));
     }
-    const double need = stepsize * global_curvature(1) / cap;
-    while ((double)batches < need && batches < max_batches_) batches *= 2;
-    while (batches < max_batches_ && stepsize * global_curvature(batches) > cap) batches *= 2;
+    // (the rule of dwx_sgd_plan on the global estimate: cut finer while it is above the cap and
+    // a finer cut still lowers it by a fifth)
+    while (batches < max_batches_ && stepsize * global_curvature(batches) > cap) {
+      if (global_curvature(2 * batches) > 0.8 * global_curvature(batches) &&
+          (4 * batches > max_batches_ || global_curvature(4 * batches) > 0.64 * global_curvature(batches)))
+        break;
+      batches *= 2;
+    }
   }
   if (!level_chunks_.count(batches)) {
     // first use of this batch count: agree on the slowest rank's chunk count and share the

@@ -30,6 +30,10 @@
 
 #include "sweep_kernels.h"
 
+// a finer cut must lower the batches' curvature estimate to this fraction, else the plan stops
+// (dwx_sgd_plan; multi-GPU drivers apply the same rule to the global estimate)
+constexpr double PLAN_MIN_GAIN = 0.8;
+
 #ifndef DWX_PULL_GRID
 #define DWX_PULL_GRID 16u   // pull_grad_kernel workgroups per CU (grid-stride beyond)
 #endif
@@ -122,6 +126,7 @@ struct dwx_sampler {
   bool plan_valid = false;
   std::map<uint32_t, double> row_sum_cache;   // batches -> R
   std::vector<uint64_t> sgd_work;             // [tiles + 1] prefix sums of SGD-visited records
+  uint64_t sgd_work_max_launch = 0;           // ... of the colour launch with the most
   bool wide_learn = false;   // the graph has TILE_TERMS2 tiles: 32-byte staged records when learning
   unsigned persistent_blocks[2] = {1, 1};
   bool rec8 = false;                    // the graph streams 8-byte records (CompiledGraph::edges8)
@@ -363,8 +368,14 @@ std::vector<uint32_t> cut_launch(const dwx_sampler *s, size_t l, uint32_t nb) {
   const uint32_t t0 = c.launch_tile[l], t1 = c.launch_tile[l + 1];
   std::vector<uint32_t> cut{t0};
   if (t1 == t0) return cut;
-  nb = std::max(1u, std::min(nb, t1 - t0));
   const uint64_t w0 = s->sgd_work[t0], total = s->sgd_work[t1] - w0;
+  // nb pieces for the colour with the MOST work; a colour with less gets as many as keep its
+  // pieces no bigger than that colour's (a greedy colouring leaves most of the work in the first
+  // colours: cutting the small late colours nb-fold too only multiplies dependent launches --
+  // 20 colours x 64 batches x 6 kernels on the power-law test graph)
+  if (nb > 1 && s->sgd_work_max_launch > 0)
+    nb = (uint32_t)std::max<uint64_t>(1, (total * nb + s->sgd_work_max_launch - 1) / s->sgd_work_max_launch);
+  nb = std::max(1u, std::min(nb, t1 - t0));
   for (uint32_t b = 1; b < nb; ++b) {
     uint32_t t;
     if (total == 0) {
@@ -888,10 +899,17 @@ void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
   if (force_batches) {
     B = std::min(force_batches, max_tiles);
   } else if (cap > 0 && stepsize > 0) {
-    // lambda(1) <= B * lambda(B): no split below stepsize * lambda(1) / cap can do
-    const double need = stepsize * row_sum_bound(s, 1) / cap;
-    while (B < max_tiles && (double)B < need) B *= 2;
-    while (B < max_tiles && stepsize * row_sum_bound(s, B) > cap) B *= 2;
+    // Double the cut while the batches' curvature is above the cap AND cutting still lowers it:
+    // a batch can be no finer than one variable, so a hub with 10^5 factors sets a floor no cut
+    // gets under (its own kappa |d|^2) -- past it more batches only cost dependent launches
+    // (the saturating step keeps the update stable there, section 3.5).
+    while (B < max_tiles && stepsize * row_sum_bound(s, B) > cap) {
+      // (looking two doublings ahead: one cut may fall on an unlucky boundary)
+      if (row_sum_bound(s, 2 * B) > PLAN_MIN_GAIN * row_sum_bound(s, B) &&
+          (4 * B > max_tiles || row_sum_bound(s, 4 * B) > PLAN_MIN_GAIN * PLAN_MIN_GAIN * row_sum_bound(s, B)))
+        break;
+      B *= 2;
+    }
     B = std::min(B, max_tiles);
   }
   s->plan_batches = B;
@@ -1315,6 +1333,9 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       }, 64);
       for (size_t i = 0; i < c.tiles.size(); ++i) work[i + 1] += work[i];
       s->sgd_work.swap(work);
+      for (size_t l = 0; l + 1 < c.launch_off.size(); ++l)
+        s->sgd_work_max_launch = std::max(s->sgd_work_max_launch,
+                                          s->sgd_work[c.launch_tile[l + 1]] - s->sgd_work[c.launch_tile[l]]);
     }
     phase("kernel setup");
     (void)build_level(s.get(), 1);

@@ -386,11 +386,14 @@ class ShardedDimmWitted:
         cap = float(self.e.step_cap)
         batches, eta = 1, stepsize
         if cap > 0 and stepsize > 0:
-            need = stepsize * self._global_curvature(1, world) / cap
             limit = self._batch_limit()
-            while batches < need and batches < limit:
-                batches *= 2
+            # the rule of dwx_sgd_plan on the global estimate: cut finer while it is above the cap
+            # and a finer cut still lowers it by a fifth (a hub variable sets a floor no cut beats)
             while batches < limit and stepsize * self._global_curvature(batches, world) > cap:
+                lam = self._global_curvature(batches, world)
+                if self._global_curvature(2 * batches, world) > 0.8 * lam and (
+                        4 * batches > limit or self._global_curvature(4 * batches, world) > 0.64 * lam):
+                    break           # (two doublings ahead: one cut may fall on an unlucky boundary)
                 batches *= 2
         # this rank's plan with the common batch count.  The step itself is never shortened:
         # every weight's step saturates at the inverse of its own (all-reduced) curvature bound

@@ -335,10 +335,12 @@ def test_split_sweep_with_pull_tiles_and_static_counts(lib, monkeypatch):
                compile_opts=dict(tile_vars=64))
     run_parity(lib, random_graph(8, V=1500, F=9000, W=1300, p_cat=0.3), n_learn=4, n_infer=2, stepsize=0.2,
                learn_non_evidence=True, compile_opts=dict(tile_vars=32))
-    # never more than 64 batches per launch; an absurd step just saturates
+    # never more than 64 batches per launch, and no finer than still lowers the batches'
+    # curvature (a batch cannot be smaller than a variable); an absurd step just saturates
     s2 = dwx.GibbsSampler(dwx.Graph(raw, lib=lib, tile_vars=16), seed=3)
     b2, n2, eta2 = s2.sgd_plan(5.0)
-    assert b2 == 64 and n2 <= 64 and eta2 < 5.0
+    assert 16 <= b2 <= 64 and n2 <= 64 and eta2 < 5.0
+    assert b2 == 64 or s2.sgd_curvature(2 * b2) > 0.8 * s2.sgd_curvature(b2)
     run_parity(lib, raw, n_learn=2, n_infer=1, stepsize=5.0, compile_opts=dict(tile_vars=16))
     # plans too large for the per-chunk tables: per-record atomics and dynamic counts
     monkeypatch.setenv("DWX_PLAN_TABLE_CHUNKS", "4")
