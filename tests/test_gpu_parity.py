@@ -307,8 +307,9 @@ def test_degree_histogram_1_to_1e5_exact_and_3x_faster_than_round_1(lib):
     third of that.  Where the time went: oversized variables now spread over one workgroup per
     8192 records (a single CU turns around one scattered request per ~2.3 cycles, so a 10^5-record
     hub kept ITS workgroup busy for 0.3 ms per colour), their walks batch four records' loads per
-    lane, and mid-degree variables left the tiles for a wave each (the wave bin alone: learning
-    sweep 1.3x on this graph, 2.6x on one without hubs)."""
+    lane, mid-degree variables left the tiles for a wave each (the wave bin alone: learning
+    sweep 1.3x on this graph, 2.6x on one without hubs), and the mini-batch plan cuts colours in
+    proportion to their work (1.3 ms / 16 ms per sweep at the end of round 2)."""
     import time
     from randgraph import degree_graph_fast
     raw = degree_graph_fast(7)
