@@ -1253,9 +1253,9 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     off += slots * sizeof(EdgeRec);
     P.lds_w_off = (uint32_t)off;     // f32 weights right behind the 16-byte records
     s->lds_bytes[0] = off;
-    // learning: 16-byte records + f32 weights (20 B per slot); TILE_TERMS2 / TILE_TERMS3 tiles
-    // use the same region for their four one-word arrays (LearnImage: 16 B per slot)
-    s->lds_bytes[1] = P.lds_edge_off + slots * 20;
+    // learning: 16-byte records + f32 weights (20 B per slot); with TILE_TERMS2 tiles the
+    // same region alternatively holds 32-byte LearnRecs (which carry their weight)
+    s->lds_bytes[1] = P.lds_edge_off + slots * (s->wide_learn ? 32 : 20);
     P.lds_agg_off = 0;
     if (c.W > 0 && c.W <= LDS_AGG_MAX_W) {
       P.lds_agg_off = (uint32_t)((s->lds_bytes[1] + 15) & ~(size_t)15);

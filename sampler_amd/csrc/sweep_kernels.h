@@ -1143,54 +1143,21 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
 }
 
 // ---------------------------------------------------------------- learning, TILE_TERMS2
-// Staged form of a record of a boolean TILE_TERMS2 / TILE_TERMS3 tile in a learning sweep: its
-// weight, ONE feature value F and the four signs (free / evidence chain x proposal 1 / 0) of the
-// sign * feature value products, evaluated edge-parallel in the staging pass.  Signs of factors
-// of arity <= 3 are integers in [-1, 2] (TILE_TERMS3 excludes RATIO), so sign + 1 fits two bits
-// and sign * F is exact.  In LDS the four 32-bit fields live in FOUR ARRAYS of one word per slot
-// (w | wid + fixed flag | F | sign codes), not as 16- or 32-byte structs: a lane walks its row
-// with a stride of the row length in WORDS -- 14 for config 3b: two lanes per bank -- where
-// 32-byte structs (stride 112 words = 48 mod 64) put sixteen lanes on four banks: 86 % of that
-// kernel's LDS cycles were bank conflicts (profiles/r02/summary_cfg3b.txt), 0.5 of its 1.2 ms.
-struct LearnImage {
-  float *w;          // [slots]
-  uint32_t *widf;    // [slots] weight id | fixed flag << 27
-  float *f;          // [slots]
-  uint32_t *codes;   // [slots] (sf1 + 1) | (sf0 + 1) << 2 | (se1 + 1) << 4 | (se0 + 1) << 6
+// Staged form of a record of a boolean TILE_TERMS2 tile in a learning sweep: the four
+// sign * feature_value products (free / evidence chain x proposal 1 / 0), evaluated
+// edge-parallel in the staging pass; exact in f32 (signs of unary and binary factors are
+// -1, 0, +1 and such a tile only holds f32-exact feature values).
+struct alignas(16) LearnRec {
+  uint32_t wid, packed;
+  float w, sf1, sf0, se1, se0;
+  uint32_t pad;
 };
-constexpr uint32_t LEARN_FIXED_BIT = 1u << 27;
-DWX_DEV LearnImage learn_image(unsigned char *base, uint32_t slots) {
-  LearnImage im;
-  im.w = (float *)base;
-  im.widf = (uint32_t *)(base + (size_t)slots * 4);
-  im.f = (float *)(base + (size_t)slots * 8);
-  im.codes = (uint32_t *)(base + (size_t)slots * 12);
-  return im;
-}
-DWX_DEV uint32_t sign_code(double sign) { return (uint32_t)((int)sign + 1) & 3u; }
-DWX_DEV double code_term(uint32_t codes, uint32_t shift, float f) {
-  return (double)((int)((codes >> shift) & 3u) - 1) * (double)f;
-}
-// (wid, fixed flag, w, F, four signs) -> slot i
-DWX_DEV void learn_store(const LearnImage &im, uint32_t i, const EdgeRec &r, float w, float F, uint32_t codes) {
-  im.w[i] = w;
-  im.widf[i] = r.wid | ((r.packed & EDGE_FIXED_FLAG) ? LEARN_FIXED_BIT : 0u);
-  im.f[i] = F;
-  im.codes[i] = codes;
-}
-// a pre-signed record (hit = s_hit * f, miss = s_miss * f) as (F, codes relative to F)
-DWX_DEV void learn_store_presigned(const LearnImage &im, uint32_t i, const EdgeRec &r, float w) {
-  const float hit = r.fval, miss = bits_to_float(r.aux);
-  const float F = hit != 0.0f ? hit : miss;
-  const uint32_t ch = hit != 0.0f ? 2u : 1u;                          // sign +1 / 0
-  const uint32_t cm = miss == 0.0f ? 1u : (miss == F ? 2u : 0u);      // 0 / +1 / -1
-  learn_store(im, i, r, w, F, ch | (cm << 2) | (ch << 4) | (cm << 6));
-}
+static_assert(sizeof(LearnRec) == 32, "LearnRec must be 32 bytes");
 
 // sample_sgd_single_variable (src/gibbs_sampler.h:127-149) + sgd_on_variable
 // (src/factor_graph.cc:262-275) for a boolean variable, everything out of LDS.
 DWX_DEV void learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr, uint32_t row_bias,
-                                   const LearnImage &im, uint32_t edge_bias, long long *agg,
+                                   const LearnRec *recs, uint32_t edge_bias, long long *agg,
                                    uint32_t p, const VarPre pre, double A, double B) {
   const bool is_evid = pre.meta & VM_EVIDENCE;
   const bool noise_aware = P.flags & OPT_NOISE_AWARE;
@@ -1199,19 +1166,15 @@ DWX_DEV void learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr
   // LEARN_BATCH staged records per step (all LDS reads in flight); sums stay sequential and in
   // row order, a slot past the end adds +0.0 (cannot change a running sum)
   for (uint32_t e = es; e < ee; e += LEARN_BATCH) {
-    float w[LEARN_BATCH], f[LEARN_BATCH];
-    uint32_t c[LEARN_BATCH];
+    LearnRec r[LEARN_BATCH];
 #pragma unroll
-    for (uint32_t u = 0; u < LEARN_BATCH; ++u) {
-      const uint32_t i = umin(e + u, ee - 1) - edge_bias;
-      w[u] = im.w[i]; f[u] = im.f[i]; c[u] = im.codes[i];
-    }
+    for (uint32_t u = 0; u < LEARN_BATCH; ++u) r[u] = recs[umin(e + u, ee - 1) - edge_bias];
 #pragma unroll
     for (uint32_t u = 0; u < LEARN_BATCH; ++u) {
       const bool in = e + u < ee;
-      const double wv = (double)w[u];
-      ppf += in ? wv * code_term(c[u], 0, f[u]) : 0.0; pnf += in ? wv * code_term(c[u], 2, f[u]) : 0.0;
-      ppe += in ? wv * code_term(c[u], 4, f[u]) : 0.0; pne += in ? wv * code_term(c[u], 6, f[u]) : 0.0;
+      const double w = (double)r[u].w;
+      ppf += in ? w * (double)r[u].sf1 : 0.0; pnf += in ? w * (double)r[u].sf0 : 0.0;
+      ppe += in ? w * (double)r[u].se1 : 0.0; pne += in ? w * (double)r[u].se0 : 0.0;
     }
   }
   const uint32_t p_free = bool_draw(A, ppf, pnf);
@@ -1222,17 +1185,15 @@ DWX_DEV void learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr
   P.assign_evid[p] = p_evid;
   if (!(P.flags & OPT_LEARN_NON_EVIDENCE) && (noise_aware || !is_evid)) return;
   for (uint32_t e = es; e < ee; ++e) {
-    const uint32_t i = e - edge_bias, widf = im.widf[i];
-    if (widf & LEARN_FIXED_BIT) continue;
-    const uint32_t wid = widf & (LEARN_FIXED_BIT - 1u), c = im.codes[i];
-    const float f = im.f[i];
-    const double pot_free = code_term(c, p_free ? 0 : 2, f);
-    const double pot_evid = code_term(c, evid_value ? 4 : 6, f);
+    const LearnRec r = recs[e - edge_bias];
+    if (r.packed & EDGE_FIXED_FLAG) continue;
+    const double pot_free = (double)(p_free ? r.sf1 : r.sf0);
+    const double pot_evid = (double)(evid_value ? r.se1 : r.se0);
     const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
     long long *dst = agg ? agg : P.grad;
-    if (gi) atomicAdd((unsigned long long *)&dst[wid], (unsigned long long)gi);
+    if (gi) atomicAdd((unsigned long long *)&dst[r.wid], (unsigned long long)gi);
     if (P.flags & OPT_DYNAMIC_T)
-      atomicAdd((unsigned long long *)&dst[P.num_weights + wid], (unsigned long long)(long long)FIX_SCALE);
+      atomicAdd((unsigned long long *)&dst[P.num_weights + r.wid], (unsigned long long)(long long)FIX_SCALE);
   }
 }
 
@@ -1401,41 +1362,6 @@ DWX_DEV void stage_generic_records(const KernelParams &P, const TileDesc &d, con
   }
 }
 
-// The same, handing out the raw signs (learning: they are stored as two-bit codes).
-template <int K, int NS, int NCHAIN, class Out>
-DWX_DEV void stage_generic_signs(const KernelParams &P, const TileDesc &d, const EdgeRec (&rec)[K],
-                                 const uint32_t *const (&chains)[NCHAIN], const int (&chain)[NS],
-                                 const uint32_t (&prop)[NS], Out &&out) {
-  VifRec vf[K][GEN_ARITY];
-  uint32_t val[K][NCHAIN][GEN_ARITY];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const bool generic = !(rec[k].packed & EDGE_PRESIGNED);
-    const uint32_t ar = generic ? edge_arity(rec[k]) : 1u, base = (generic && ar >= 2u) ? rec[k].aux : 0u;
-#pragma unroll
-    for (uint32_t i = 0; i < GEN_ARITY; ++i) vf[k][i] = P.vifs[base + umin(i, ar - 1u)];
-  }
-#pragma unroll
-  for (int k = 0; k < K; ++k)
-#pragma unroll
-    for (int c = 0; c < NCHAIN; ++c)
-#pragma unroll
-      for (uint32_t i = 0; i < GEN_ARITY; ++i) val[k][c][i] = chains[c][vf[k][i].vid];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const EdgeRec r = rec[k];
-    double sg[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) sg[j] = 0.0;
-    const bool presigned = r.packed & EDGE_PRESIGNED;
-    if (!presigned) {
-      const VifsPreloaded<NS, NCHAIN> src{vf[k], val[k], chain};
-      factor_signs_from<NS>(edge_func(r), edge_arity(r), src, d.v0 + edge_owner_lane(r), prop, sg);
-    }
-    out(k, presigned, sg);
-  }
-}
-
 // Persistent, software-pipelined sweep: workgroup b handles tiles b, b + gridDim.x, ...
 // of the launch.  While a tile is processed out of LDS, the NEXT tile's edge records,
 // row pointers and per-variable inputs are already in flight into registers, so the
@@ -1444,7 +1370,7 @@ DWX_DEV void stage_generic_signs(const KernelParams &P, const TileDesc &d, const
 // per lane (LDS holds K * 256 records).  Oversized variables are skipped here and
 // handled by giant_kernel.
 // WIDE (learning only): the graph has TILE_TERMS2 tiles; their records are staged as
-// four words per slot in separate arrays (LearnImage).
+// 32-byte LearnRec (LDS doubles, one workgroup per CU, so registers are plentiful).
 template <bool LEARN, int K, bool WIDE = false>
 // (the learning kernel's LDS footprint admits 2 workgroups per CU at K = 12: give the
 // register allocator the matching budget instead of spilling at the 3-per-CU limit)
@@ -1498,20 +1424,19 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
       if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS3)) {
         // arity <= 3: the four sign * feature value products of every record (free / evidence
         // chain x proposal 1 / 0) through the general sign functions on batched loads
-        const LearnImage im = learn_image((unsigned char *)s_edges, K * BLOCK_THREADS);
+        LearnRec *s_lrec = (LearnRec *)s_edges;
         const uint32_t *const chains[2] = {P.assign_free, P.assign_evid};
         const int chain[4] = {0, 0, 1, 1};
         const uint32_t prop[4] = {1u, 0u, 1u, 0u};
         const bool hit[4] = {true, false, true, false};
-        stage_generic_signs<K, 4, 2>(P, d, rec, chains, chain, prop, [&](int k, bool presigned, const double (&sg)[4]) {
-          const uint32_t i = t + k * BLOCK_THREADS;
-          if (presigned) learn_store_presigned(im, i, rec[k], w[k]);
-          else learn_store(im, i, rec[k], w[k], rec[k].fval,
-                           sign_code(sg[0]) | (sign_code(sg[1]) << 2) | (sign_code(sg[2]) << 4) | (sign_code(sg[3]) << 6));
+        stage_generic_records<K, 4, 2>(P, d, rec, chains, chain, prop, hit, [&](int k, const double (&term)[4]) {
+          LearnRec lr;
+          lr.wid = rec[k].wid; lr.packed = rec[k].packed; lr.w = w[k]; lr.pad = 0;
+          lr.sf1 = (float)term[0]; lr.sf0 = (float)term[1]; lr.se1 = (float)term[2]; lr.se0 = (float)term[3];
+          s_lrec[t + k * BLOCK_THREADS] = lr;
         });
-        (void)hit;
       } else if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
-        const LearnImage im = learn_image((unsigned char *)s_edges, K * BLOCK_THREADS);
+        LearnRec *s_lrec = (LearnRec *)s_edges;
         VifRec va[K], vb[K];
         if (d.flags & TILE_INLINE2) {   // workgroup-uniform
 #pragma unroll
@@ -1535,9 +1460,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const EdgeRec r = rec[k];
-          const uint32_t slot = t + k * BLOCK_THREADS;
+          LearnRec lr;
+          lr.wid = r.wid; lr.packed = r.packed; lr.w = w[k]; lr.pad = 0;
           if (r.packed & EDGE_PRESIGNED) {
-            learn_store_presigned(im, slot, r, w[k]);
+            lr.sf1 = lr.se1 = r.fval;
+            lr.sf0 = lr.se0 = bits_to_float(r.aux);
           } else {
             const uint32_t me = d.v0 + edge_owner_lane(r);
             const bool a_me = va[k].vid == me, b_me = vb[k].vid == me;
@@ -1546,12 +1473,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
             const bool af = of[k] == va[k].equal_to, bf = of[k] == vb[k].equal_to;
             const bool ae = oe[k] == va[k].equal_to, be = oe[k] == vb[k].equal_to;
             const uint32_t fn = edge_func(r);
-            learn_store(im, slot, r, w[k], r.fval,
-                        sign_code(binary_sign(fn, a_me ? a1 : af, b_me ? b1 : bf)) |
-                        (sign_code(binary_sign(fn, a_me ? a0 : af, b_me ? b0 : bf)) << 2) |
-                        (sign_code(binary_sign(fn, a_me ? a1 : ae, b_me ? b1 : be)) << 4) |
-                        (sign_code(binary_sign(fn, a_me ? a0 : ae, b_me ? b0 : be)) << 6));
+            const double fv = (double)r.fval;
+            lr.sf1 = (float)(binary_sign(fn, a_me ? a1 : af, b_me ? b1 : bf) * fv);
+            lr.sf0 = (float)(binary_sign(fn, a_me ? a0 : af, b_me ? b0 : bf) * fv);
+            lr.se1 = (float)(binary_sign(fn, a_me ? a1 : ae, b_me ? b1 : be) * fv);
+            lr.se0 = (float)(binary_sign(fn, a_me ? a0 : ae, b_me ? b0 : be) * fv);
           }
+          s_lrec[t + k * BLOCK_THREADS] = lr;
         }
       } else if (K <= 6 && !LEARN && (d.flags & TILE_TERMS3)) {
         // inference, arity <= 3: both proposals' terms of every record, edge-parallel
@@ -1699,8 +1627,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
       if (K <= 6 && LEARN && WIDE && (d.flags & (TILE_TERMS2 | TILE_TERMS3)))
-        learn_variable_terms2(P, s_rowptr, d.r0, learn_image((unsigned char *)s_edges, K * BLOCK_THREADS), d.e0, s_agg,
-                              d.v0 + t, pre, A, B);
+        learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B);
       else if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
         delta = process_variable<LEARN, W_TERMS, true>(P, T, d.v0 + t, pre, A, B, true);
       else if ((d.flags & TILE_SIMPLE) || (K <= 6 && !LEARN && (d.flags & (TILE_TERMS2 | TILE_TERMS3))))
