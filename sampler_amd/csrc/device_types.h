@@ -51,6 +51,9 @@ constexpr uint32_t EDGE_ARITY_SHIFT = 8;      // bits 8-23: arity (unless EDGE_I
 constexpr uint32_t EDGE_ARITY_MASK = 0xFFFFu;
 constexpr uint32_t EDGE_OWNER_SHIFT = 24;     // bits 24-31: lane of the owning variable in its tile
 constexpr uint32_t MAX_ARITY = EDGE_ARITY_MASK;
+// factors up to this arity keep their vif entries once per record, in record order (the
+// edge-parallel staging streams them); larger factors share one block of entries
+constexpr uint32_t VIF_PER_RECORD_ARITY = 3;
 
 // Compact form of a pre-signed record, 8 bytes: what the sweep kernels stream when EVERY
 // tile of the graph is TILE_SIMPLE (all-unary graphs: half the record stream of a sweep).

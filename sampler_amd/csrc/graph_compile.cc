@@ -378,40 +378,51 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
 
     phase("device rows");
     // ---- vifs of factors with arity >= 2 ----
-    // (parallel prefix sum over the factors: per-part totals, then per-part fills)
+    // Factors of arity > VIF_PER_RECORD_ARITY keep one block of entries per factor in g.vifs,
+    // shared by their records.  The entries of the small ones go to a scratch array first and
+    // are laid out again per RECORD, in record order, once the tiles are known (below): the
+    // edge-parallel staging then reads them as a stream beside the records instead of as one
+    // random 16/24-byte gather per record.
+    // (parallel prefix sums over the factors: per-part totals, then per-part fills)
     RawArray<uint32_t> vif_base(F);
-    uint64_t nvif = 0;
+    RawArray<VifRec> small_vifs;
+    uint64_t nvif = 0, nsmall = 0;
     {
       const uint32_t T = std::max(1u, nth);
-      std::vector<uint64_t> part(T + 1, 0);
+      std::vector<uint64_t> part(T + 1, 0), spart(T + 1, 0);
       parallel_parts(F, T, [&](uint32_t t, uint64_t fb, uint64_t fe) {
-        uint64_t n = 0;
+        uint64_t n = 0, m = 0;
         for (uint64_t f = fb; f < fe; ++f) {
           const uint64_t a = d.fac_edge_offset[f + 1] - d.fac_edge_offset[f];
-          if (a >= 2) n += a;
+          if (a > VIF_PER_RECORD_ARITY) n += a;
+          else if (a >= 2) m += a;
         }
         part[t + 1] = n;
+        spart[t + 1] = m;
       });
-      for (uint32_t t = 0; t < T; ++t) part[t + 1] += part[t];
+      for (uint32_t t = 0; t < T; ++t) { part[t + 1] += part[t]; spart[t + 1] += spart[t]; }
       nvif = part[T];
-      if (nvif >= kUnset) throw LimitError("vif entries exceed 2^32-1");
+      nsmall = spart[T];
+      if (nvif >= kUnset || nsmall >= kUnset) throw LimitError("vif entries exceed 2^32-1");
       parallel_parts(F, T, [&](uint32_t t, uint64_t fb, uint64_t fe) {
-        uint64_t n = part[t];
+        uint64_t n = part[t], m = spart[t];
         for (uint64_t f = fb; f < fe; ++f) {
           const uint64_t a = d.fac_edge_offset[f + 1] - d.fac_edge_offset[f];
-          vif_base[f] = a >= 2 ? (uint32_t)n : 0u;
-          if (a >= 2) n += a;
+          if (a > VIF_PER_RECORD_ARITY) { vif_base[f] = (uint32_t)n; n += a; }
+          else if (a >= 2) { vif_base[f] = (uint32_t)m; m += a; }
+          else vif_base[f] = 0u;
         }
       });
     }
-    g.NVif = nvif;
-    g.vifs.resize(nvif + 2);   // + 2 padding entries: branch-free pair loads of non-binary records
+    g.NVif = nvif + nsmall;   // (the tile sizes below ask whether there are any; final count after the tiles)
+    g.vifs.resize(nvif);
+    small_vifs.reset(nsmall);
     parallel_ranges(F, nth, [&](uint64_t fb, uint64_t fe) {
       for (uint64_t f = fb; f < fe; ++f) {
         uint64_t lo = d.fac_edge_offset[f], hi = d.fac_edge_offset[f + 1];
         if (hi - lo < 2) continue;
-        for (uint64_t e = lo; e < hi; ++e)
-          g.vifs[vif_base[f] + (e - lo)] = VifRec{g.pos[d.edge_vid[e]], edge_dense[e]};
+        VifRec *dst = hi - lo > VIF_PER_RECORD_ARITY ? &g.vifs[vif_base[f]] : &small_vifs[vif_base[f]];
+        for (uint64_t e = lo; e < hi; ++e) dst[e - lo] = VifRec{g.pos[d.edge_vid[e]], edge_dense[e]};
       }
     });
 
@@ -558,7 +569,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
         for (uint32_t e = t.e0; e < t.e0 + t.nedges && ok; ++e) {
           const EdgeRec &r = g.edges[e];
           if (r.packed & EDGE_PRESIGNED) continue;
-          const VifRec *vp = &g.vifs[r.aux];
+          const VifRec *vp = &small_vifs[r.aux];
           ok = vp[0].equal_to <= INLINE2_PRED_MASK && vp[1].equal_to <= INLINE2_PRED_MASK;
         }
         if (ok) {
@@ -567,7 +578,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
             for (uint32_t e = g.row_ptr[g.v_row[v0 + l]]; e < g.row_ptr[g.v_row[v0 + l + 1]]; ++e) {
               EdgeRec &r = g.edges[e];
               if (r.packed & EDGE_PRESIGNED) continue;
-              const VifRec a = g.vifs[r.aux], b = g.vifs[r.aux + 1];
+              const VifRec a = small_vifs[r.aux], b = small_vifs[r.aux + 1];
               const uint32_t me = v0 + l;
               const bool a_me = a.vid == me, b_me = b.vid == me;
               r.aux = !a_me ? a.vid : (!b_me ? b.vid : me);
@@ -585,6 +596,43 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     }
     }, 64);
     g.n_terms2_tiles = n_terms2;
+    // ---- vif entries of the small factors, per record in record order ----
+    // (records that became EDGE_INLINE2 carry theirs already and take no entries)
+    {
+      auto wants = [](const EdgeRec &r) -> uint32_t {
+        if (r.packed & (EDGE_PRESIGNED | EDGE_INLINE2)) return 0u;
+        const uint32_t a = (r.packed >> EDGE_ARITY_SHIFT) & EDGE_ARITY_MASK;
+        return a >= 2 && a <= VIF_PER_RECORD_ARITY ? a : 0u;
+      };
+      const size_t nt = g.tiles.size();
+      std::vector<uint64_t> tile_off(nt + 1, 0);
+      parallel_ranges(nt, nth, [&](uint64_t tb, uint64_t te) {
+        for (uint64_t i = tb; i < te; ++i) {
+          const TileDesc &t = g.tiles[i];
+          uint64_t n = 0;
+          for (uint64_t e = t.e0; e < (uint64_t)t.e0 + t.nedges; ++e) n += wants(g.edges[e]);
+          tile_off[i + 1] = n;
+        }
+      });
+      for (size_t i = 0; i < nt; ++i) tile_off[i + 1] += tile_off[i];
+      if (nvif + tile_off[nt] >= kUnset) throw LimitError("vif entries exceed 2^32-1");
+      g.NVif = nvif + tile_off[nt];
+      g.vifs.resize(g.NVif + 2);   // + 2 padding entries: branch-free pair loads of non-binary records
+      parallel_ranges(nt, nth, [&](uint64_t tb, uint64_t te) {
+        for (uint64_t i = tb; i < te; ++i) {
+          const TileDesc &t = g.tiles[i];
+          uint64_t at = nvif + tile_off[i];
+          for (uint64_t e = t.e0; e < (uint64_t)t.e0 + t.nedges; ++e) {
+            EdgeRec &r = g.edges[e];
+            const uint32_t a = wants(r);
+            if (!a) continue;
+            for (uint32_t k = 0; k < a; ++k) g.vifs[at + k] = small_vifs[r.aux + k];
+            r.aux = (uint32_t)at;
+            at += a;
+          }
+        }
+      });
+    }
     // All-unary graph (every record pre-signed): the sweeps stream 8-byte records instead
     // (the 16-byte ones stay for the oversized-variable kernel and the terms table).
     {
