@@ -103,6 +103,8 @@ typedef struct dwx_graph_info {
   uint32_t has_categorical, order_is_identity;
   uint64_t num_wide_tiles;     /* variables walked by a wave each (degree bin, see
                                   dwx_compile_opts.wide_min_records)                   */
+  uint64_t num_staged_tiles;   /* tiles whose non-unary factors (arity <= 3) are evaluated
+                                  edge-parallel while the tile is staged  */
 } dwx_graph_info;
 
 /* Runtime options of one sampler (the CmdParser fields the hot path reads:

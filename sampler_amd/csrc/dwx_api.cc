@@ -1092,6 +1092,7 @@ int dwx_graph_get_info(const dwx_graph *g, dwx_graph_info *out) {
   out->num_colors = c.n_colors; out->num_launches = c.launch_off.size() - 1;
   out->num_tiles = c.tile_v.size() - 1; out->num_giant_tiles = c.n_giant_tiles;
   out->num_wide_tiles = c.n_wide_tiles;
+  out->num_staged_tiles = c.ecap <= 6 * BLOCK_THREADS ? c.n_terms2_tiles : 0;
   out->max_cardinality = c.max_card; out->device_bytes = c.device_bytes();
   out->num_query_variables = c.n_query;
   out->has_categorical = c.has_categorical; out->order_is_identity = c.order_is_identity;

@@ -554,12 +554,24 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
                                     (ar == 2 || (ar == 3 && (pk & EDGE_FUNC_MASK) != FUNC_RATIO))));
       }
       const bool cat = g.v_meta[v0] & VM_CATEGORICAL;
+      // a categorical tile is staged edge-parallel with "the owner takes the value its own
+      // predicate names" as every record's proposal: the owner must sit in the factor once
+      bool cat_terms3 = cat && terms3 && !simple;
+      for (uint32_t l = 0; l < t.nv && cat_terms3; ++l)
+        for (uint32_t e = g.row_ptr[g.v_row[v0 + l]]; e < g.row_ptr[g.v_row[v0 + l + 1]] && cat_terms3; ++e) {
+          const EdgeRec &r = g.edges[e];
+          if (r.packed & EDGE_PRESIGNED) continue;
+          const uint32_t ar = (r.packed >> EDGE_ARITY_SHIFT) & EDGE_ARITY_MASK;
+          uint32_t mine = 0;
+          for (uint32_t k = 0; k < ar; ++k) mine += small_vifs[r.aux + k].vid == v0 + l;
+          cat_terms3 = mine == 1;
+        }
       const bool giant = t.nrows > g.rcap || t.nedges > g.ecap;
       const uint32_t outside = giant ? TILE_GIANT : (tile_wide[i] ? TILE_WIDE : 0u);
       t.flags = (simple ? TILE_SIMPLE : 0u) | (cat ? TILE_CATEGORICAL : 0u) | outside |
                 ((simple && !cat && W > LDS_AGG_MAX_W && !outside) ? TILE_PULL : 0u) |
                 ((terms2 && !simple && !cat && t.nv <= 256 && !outside) ? TILE_TERMS2 : 0u) |
-                ((terms3 && !terms2 && !simple && !cat && t.nv <= 256 && !outside) ? TILE_TERMS3 : 0u);
+                ((terms3 && !simple && (cat ? cat_terms3 : !terms2) && t.nv <= 256 && !outside) ? TILE_TERMS3 : 0u);
       if (t.flags & (TILE_TERMS2 | TILE_TERMS3)) ++n_terms2;
       // arity-2 records carry their two vif entries themselves where the kernels that will
       // see the tile implement it (the K <= 6 builds; not the oversized-variable kernel) and

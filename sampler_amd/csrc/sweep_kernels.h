@@ -194,6 +194,7 @@ DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const Vi
 // any arity, a loop) or registers filled by an earlier, batched load phase (VifsPreloaded:
 // arity <= GEN_ARITY, loops unrolled so that every register index is static).
 constexpr uint32_t GEN_ARITY = 3;   // positions of a factor the batched generic walk preloads
+constexpr uint32_t PROP_OWN = 0xFFFFFFFFu, PROP_OTHER = 0xFFFFFFFEu;   // see factor_signs_from
 #ifndef DWX_GEN_BATCH
 #define DWX_GEN_BATCH 1
 #endif
@@ -223,11 +224,17 @@ DWX_DEV void factor_signs_from(uint32_t func, uint32_t arity, const Src &src, ui
                                const uint32_t (&prop)[NS], double (&s)[NS]) {
   constexpr uint32_t MAXA = Src::MAXA;
   const uint32_t n = MAXA ? MAXA : arity;   // (MAXA: constant trip count, positions past the arity skipped)
+  // (PROP_OWN / PROP_OTHER: "the owner takes the value its own predicate names" / "any other
+  // value" -- what the edge-parallel staging of a categorical tile asks, where a record's
+  // proposal is its row's value)
   auto sat = [&](uint32_t i, bool (&a)[NS]) {
     const VifRec vf = src.vif(i);
     const bool mine = vf.vid == me;
 #pragma unroll
-    for (int j = 0; j < NS; ++j) a[j] = (mine ? prop[j] : src.value(j, i, vf.vid)) == vf.equal_to;
+    for (int j = 0; j < NS; ++j) {
+      const bool own = prop[j] == PROP_OWN || (prop[j] != PROP_OTHER && prop[j] == vf.equal_to);
+      a[j] = mine ? own : src.value(j, i, vf.vid) == vf.equal_to;
+    }
   };
   bool a[NS];
   switch (func) {
@@ -362,7 +369,9 @@ DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const Vif
 //              LDS tree for the sums
 //   W_PRESUM   (giant_decide_kernel) the potentials of a boolean variable are already summed
 //              (TileView::presum); one lane decides, the gradient rows are walked elsewhere
-enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4, W_COOP = 5, W_COOPB = 6, W_PRESUM = 7 };
+//   W_LREC     (learning, categorical TILE_TERMS3 tiles) the staged records are LearnRecs: weight and
+//              the four products per record come out of LDS, for the draws and the gradient alike
+enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4, W_COOP = 5, W_COOPB = 6, W_PRESUM = 7, W_LREC = 8 };
 constexpr uint32_t GIANT_PIECE = 8192;     // records per workgroup of a boolean oversized variable
 #ifndef DWX_GIANT_THREADS
 #define DWX_GIANT_THREADS 1024
@@ -408,6 +417,17 @@ struct Coop {
 };
 
 struct alignas(16) EdgeTerms { double t1, t0; };
+// Staged form of a record of a TILE_TERMS2 / TILE_TERMS3 tile in a learning sweep: the four
+// sign * feature_value products (free / evidence chain x the owner's proposal "hits" / "misses"
+// -- 1 / 0 for a boolean owner, the row's value / any other for a categorical one), evaluated
+// edge-parallel in the staging pass; exact in f32 (signs of factors of arity <= 3 are small
+// integers -- RATIO at arity 3 is kept out -- and such a tile only holds f32-exact feature values).
+struct alignas(16) LearnRec {
+  uint32_t wid, packed;
+  float w, sf1, sf0, se1, se0;
+  uint32_t pad;
+};
+static_assert(sizeof(LearnRec) == 32, "LearnRec must be 32 bytes");
 // Table entry of a record of a TILE_INLINE2 tile (build_terms_kernel), overlaying an EdgeRec:
 // wf = w * |f|-signed product (f64 of two f32: exact), `other` = device position of the other
 // endpoint (the owner's for a unary record), bits: func id in 0-3; unary: TAB2_UNARY, TAB2_C1
@@ -606,6 +626,19 @@ DWX_DEV double range_potential(const KernelParams &P, const TileView &T, uint32_
     coop_for_records<WMODE, 1, 1>(P, T, es, ee, me, chains, chain, prop, hit,
                                   [&](const EdgeRec &, uint32_t, double w, const double (&term)[1]) { pot += w * term[0]; });
     return Coop<WMODE>::sum(pot);
+  }
+  if (WMODE == W_LREC) {   // (the row's own value is proposed: every record "hits")
+    const LearnRec *recs = (const LearnRec *)T.edges;
+    const bool evid = assign == P.assign_evid;
+    for (uint32_t e = es; e < ee; e += LEARN_BATCH) {
+      LearnRec r[LEARN_BATCH];
+#pragma unroll
+      for (uint32_t u = 0; u < LEARN_BATCH; ++u) r[u] = recs[umin(e + u, ee - 1) - T.edge_bias];
+#pragma unroll
+      for (uint32_t u = 0; u < LEARN_BATCH; ++u)
+        pot += (e + u < ee) ? (double)r[u].w * (double)(evid ? r[u].se1 : r[u].sf1) : 0.0;
+    }
+    return pot;
   }
   if (WMODE == W_TERMS8) {
     const unsigned long long *tab = (const unsigned long long *)T.edges;
@@ -980,6 +1013,21 @@ DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uin
     coop_sgd_range<WMODE>(P, T, es, ee, me, evid_value, free_value, hit_value, t, count_t);
     return;
   }
+  if (WMODE == W_LREC) {
+    const LearnRec *recs = (const LearnRec *)T.edges;
+    const bool evid_hits = evid_value == hit_value, free_hits = free_value == hit_value;
+    for (uint32_t e = es; e < ee; ++e) {
+      const LearnRec r = recs[e - T.edge_bias];
+      if (r.packed & EDGE_FIXED_FLAG) continue;
+      const double g = (double)(free_hits ? r.sf1 : r.sf0) - (double)(evid_hits ? r.se1 : r.se0);
+      const long long gi = llrint(FIX_SCALE * (t * g));
+      const long long ti = count_t ? llrint(FIX_SCALE * t) : 0;
+      long long *dst = T.agg ? T.agg : P.grad;
+      if (gi) atomicAdd((unsigned long long *)&dst[r.wid], (unsigned long long)gi);
+      if (count_t) atomicAdd((unsigned long long *)&dst[P.num_weights + r.wid], (unsigned long long)ti);
+    }
+    return;
+  }
   for (uint32_t e = es; e < ee; ++e) {
     const EdgeRec er = T.edges[e - T.edge_bias];
     if (er.packed & EDGE_FIXED_FLAG) continue;   // weights_isfixed (src/factor_graph.cc:247)
@@ -1143,16 +1191,6 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
 }
 
 // ---------------------------------------------------------------- learning, TILE_TERMS2
-// Staged form of a record of a boolean TILE_TERMS2 tile in a learning sweep: the four
-// sign * feature_value products (free / evidence chain x proposal 1 / 0), evaluated
-// edge-parallel in the staging pass; exact in f32 (signs of unary and binary factors are
-// -1, 0, +1 and such a tile only holds f32-exact feature values).
-struct alignas(16) LearnRec {
-  uint32_t wid, packed;
-  float w, sf1, sf0, se1, se0;
-  uint32_t pad;
-};
-static_assert(sizeof(LearnRec) == 32, "LearnRec must be 32 bytes");
 
 // sample_sgd_single_variable (src/gibbs_sampler.h:127-149) + sgd_on_variable
 // (src/factor_graph.cc:262-275) for a boolean variable, everything out of LDS.
@@ -1427,7 +1465,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
         LearnRec *s_lrec = (LearnRec *)s_edges;
         const uint32_t *const chains[2] = {P.assign_free, P.assign_evid};
         const int chain[4] = {0, 0, 1, 1};
-        const uint32_t prop[4] = {1u, 0u, 1u, 0u};
+        const bool cat = d.flags & TILE_CATEGORICAL;   // (a record's proposal is its row's value)
+        const uint32_t p1 = cat ? PROP_OWN : 1u, p0 = cat ? PROP_OTHER : 0u;
+        const uint32_t prop[4] = {p1, p0, p1, p0};
         const bool hit[4] = {true, false, true, false};
         stage_generic_records<K, 4, 2>(P, d, rec, chains, chain, prop, hit, [&](int k, const double (&term)[4]) {
           LearnRec lr;
@@ -1486,7 +1526,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
         EdgeTerms *s_terms = (EdgeTerms *)s_edges;
         const uint32_t *const chains[1] = {P.assign_evid};
         const int chain[2] = {0, 0};
-        const uint32_t prop[2] = {1u, 0u};
+        const bool cat = d.flags & TILE_CATEGORICAL;   // (a record's proposal is its row's value; t0 unused)
+        const uint32_t prop[2] = {cat ? PROP_OWN : 1u, cat ? PROP_OTHER : 0u};
         const bool hit[2] = {true, false};
         stage_generic_records<K, 2, 1>(P, d, rec, chains, chain, prop, hit, [&](int k, const double (&term)[2]) {
           const double wv = (double)w[k];
@@ -1626,7 +1667,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
     int delta = 0;
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
-      if (K <= 6 && LEARN && WIDE && (d.flags & (TILE_TERMS2 | TILE_TERMS3)))
+      if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS3) && (d.flags & TILE_CATEGORICAL))
+        process_variable<LEARN, W_LREC, false>(P, T, d.v0 + t, pre, A, B);
+      else if (K <= 6 && LEARN && WIDE && (d.flags & (TILE_TERMS2 | TILE_TERMS3)))
         learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B);
       else if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
         delta = process_variable<LEARN, W_TERMS, true>(P, T, d.v0 + t, pre, A, B, true);

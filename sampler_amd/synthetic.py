@@ -189,6 +189,53 @@ def cfg4(V=5_000_000, card=8, seed=1234, learn=False, shard=0):
         w_initial_value=w0, w_is_fixed=fixed)
 
 
+def cfg4b(V=2_000_000, card=8, n_weights=None, seed=1234, learn=True):
+    """Config 4b (not in BASELINE.json; times categorical tiles with non-unary factors, the
+    linear-chain shape): V categorical variables of cardinality `card`; per (v, d) one unary
+    AND_CATEGORICAL factor and one binary agreement factor AND(v == d, v+1 == d).  Every value
+    row holds three records (one unary, two memberships): F = 2 V card, E = 3 V card.  Weights:
+    2 * card tied ones (None) or `n_weights` at random."""
+    rng = _rng(seed, 0)
+    F = 2 * V * card
+    arity = np.tile(np.array([1] * card + [2] * card, np.uint64), V)
+    off = np.zeros(F + 1, np.uint64)
+    np.cumsum(arity, out=off[1:])
+    E = int(off[-1])
+    v = np.arange(V, dtype=np.uint64)
+    d = np.arange(card, dtype=np.uint64)
+    per = 3 * card
+    ev = np.empty((V, per), np.uint64)
+    eq = np.empty((V, per), np.uint64)
+    ev[:, :card] = v[:, None]
+    eq[:, :card] = d[None, :]
+    ev[:, card::2] = v[:, None]
+    ev[:, card + 1::2] = ((v + np.uint64(1)) % np.uint64(V))[:, None]
+    eq[:, card::2] = d[None, :]
+    eq[:, card + 1::2] = d[None, :]
+    if n_weights is None:
+        W = 2 * card
+        wid = np.tile(np.arange(2 * card, dtype=np.uint64), V)
+    else:
+        W = n_weights
+        wid = rng.integers(0, W, size=F, dtype=np.uint64)
+    role = np.zeros(V, np.uint8)
+    init = np.zeros(V, np.uint64)
+    if learn:
+        role[: V // 2] = 1
+        init[: V // 2] = rng.integers(0, card, size=V // 2, dtype=np.uint64)
+        w0, fixed = np.zeros(W), np.zeros(W, np.uint8)
+    else:
+        w0, fixed = rng.normal(0.0, 0.5, W), np.ones(W, np.uint8)
+    return RawGraph(
+        var_role=role, var_init_value=init,
+        var_dtype=np.full(V, DTYPE_CATEGORICAL, np.uint16),
+        var_cardinality=np.full(V, card, np.uint64),
+        fac_func=np.full(F, FUNC_AND_CATEGORICAL, np.uint16), fac_edge_offset=off,
+        fac_weight_id=wid, fac_feature_value=np.ones(F),
+        edge_vid=ev.reshape(-1), edge_equal_to=eq.reshape(-1),
+        w_initial_value=w0, w_is_fixed=fixed)
+
+
 # ---- config 5b: the 3b mix over variable-block shards, generated shard by shard ----------
 # Every attribute is a pure function of a GLOBAL id (splitmix64 of (seed, kind, id)), so a rank
 # can build its own block -- and the factors other blocks own that touch it -- without anybody

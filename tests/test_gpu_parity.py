@@ -295,6 +295,15 @@ def test_arity3_tiles_evaluated_edge_parallel(lib):
     run_parity(lib, synthetic.cfg3c(2_000_000, seed=5), n_learn=2, n_infer=2, stepsize=0.001, check_index=False)
 
 
+def test_categorical_tiles_evaluated_edge_parallel(lib):
+    import test_kernels_emu as E
+    E.test_categorical_tiles_evaluated_edge_parallel(lib)
+    # and at size: 500 k categorical variables in a chain (12 M records), tied and untied weights
+    run_parity(lib, synthetic.cfg4b(500_000, seed=6), n_learn=2, n_infer=2, stepsize=0.001, check_index=False)
+    run_parity(lib, synthetic.cfg4b(300_000, n_weights=30_000, seed=7), n_learn=2, n_infer=2, stepsize=0.001,
+               check_index=False, learn_non_evidence=True)
+
+
 def test_degree_histogram_1_to_1e5_exact_and_3x_faster_than_round_1(lib):
     """A power-law-shaped graph: 200k variables with 1-8 factors, 3000 with 16 ... 100 000
     (log-uniform), 35 M factors, 20 colours.  Exact against the oracle through learning and

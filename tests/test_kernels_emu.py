@@ -210,13 +210,31 @@ def test_arity3_tiles_evaluated_edge_parallel(lib):
     on batched loads -- inference (two scenarios) and learning (four: both chains), every boolean
     function, owners appearing twice in a factor, mixed with pre-signed and arity-2 records."""
     from randgraph import random_graph
-    run_parity(lib, synthetic.cfg3c(3000, n_weights=60, seed=3), n_learn=3, n_infer=3, stepsize=0.01)
+    s, _ = run_parity(lib, synthetic.cfg3c(3000, n_weights=60, seed=3), n_learn=3, n_infer=3, stepsize=0.01)
+    assert s.graph.info.num_staged_tiles == s.graph.info.num_tiles
     run_parity(lib, synthetic.cfg3c(1500, n_weights=40, seed=4), n_learn=3, n_infer=2, stepsize=0.01,
                learn_non_evidence=True, sample_evidence=True)
     for seed in (31, 32, 33):
         raw = random_graph(seed, V=800, F=4000, W=30, p_cat=0.0, max_arity=3, exact_fvals=True)
         run_parity(lib, raw, n_learn=3, n_infer=4, stepsize=0.05, learn_non_evidence=seed == 32,
                    sample_evidence=seed == 33, compile_opts=dict(tile_vars=64))
+
+
+def test_categorical_tiles_evaluated_edge_parallel(lib):
+    """Categorical tiles whose factors have arity <= 3 take TILE_TERMS3 too: a record's proposal
+    is its row's value ("the owner's own predicate holds"), learning stages LearnRecs (hit / miss
+    x both chains) and runs the tiles' process_variable on them (W_LREC) -- every option, mixed
+    with boolean tiles, owners that sit twice in a factor kept on the generic path."""
+    from randgraph import random_graph
+    s, _ = run_parity(lib, synthetic.cfg4b(600, card=5), n_learn=3, n_infer=3, stepsize=0.01)
+    assert s.graph.info.num_staged_tiles == s.graph.info.num_tiles
+    run_parity(lib, synthetic.cfg4b(500, card=4, n_weights=2000, seed=9), n_learn=3, n_infer=2, stepsize=0.01,
+               learn_non_evidence=True, sample_evidence=True)
+    run_parity(lib, synthetic.cfg4b(400, card=3, learn=False), n_learn=0, n_infer=4)
+    for seed in (41, 42, 43, 44):
+        raw = random_graph(seed, V=600, F=3000, W=30, p_cat=0.6, max_arity=3, exact_fvals=True)
+        run_parity(lib, raw, n_learn=3, n_infer=3, stepsize=0.05, learn_non_evidence=seed == 42,
+                   sample_evidence=seed == 43, noise_aware=seed == 44, compile_opts=dict(tile_vars=64))
 
 
 def test_degree_bins_lane_wave_workgroup(lib):

@@ -34,4 +34,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     for shape in a.shapes.split(","):
         for W in [int(x) for x in a.weights.split(",")]:
-            run(shape, getattr(synthetic, shape)(a.V, n_weights=W), W, a.stepsize)
+            if shape == "cfg4b":   # W = 0: the 2 * card tied weights
+                run(shape, synthetic.cfg4b(a.V, n_weights=W or None), W or 16, a.stepsize)
+            else:
+                run(shape, getattr(synthetic, shape)(a.V, n_weights=W), W, a.stepsize)
