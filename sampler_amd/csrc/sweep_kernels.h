@@ -381,6 +381,10 @@ constexpr uint32_t COOP_U = 4;             // records per lane and step of a coo
 
 // sum over the 64 lanes of a wave, the same value (and the same association: the xor
 // butterfly) in every lane
+// the value of the neighbouring lane (lane ^ 1), both lanes of the pair calling together
+#ifndef DWX_PAIR_SWAP_U32
+#define DWX_PAIR_SWAP_U32(v) ((uint32_t)__shfl_xor((int)(v), 1, 64))
+#endif
 #ifndef DWX_WAVE_SUM_F64
 DWX_DEV double wave_sum_f64(double v) {
 #pragma unroll
@@ -449,6 +453,9 @@ constexpr uint32_t WALK_BATCH = DWX_WALK_BATCH;   // staged terms read per step 
 #define DWX_LEARN_BATCH 4
 #endif
 constexpr uint32_t LEARN_BATCH = DWX_LEARN_BATCH; // staged 32-byte learning records read per step
+#ifndef DWX_CHAIN_PAIRS
+#define DWX_CHAIN_PAIRS 1   // two lanes per variable in learning sweeps over small TERMS tiles
+#endif
 
 // entry of the 8-byte terms table (build_terms8_kernel): the f64 product w * f with sign(hit) + 1
 // in bits 0-1 and sign(miss) + 1 in bits 2-3 of its mantissa (always zero in such a product)
@@ -1235,6 +1242,62 @@ DWX_DEV void learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr
   }
 }
 
+// The same with TWO lanes per variable (tiles of at most 128 variables -- twelve and more records
+// each -- would leave half of the workgroup idle in this phase): lane 2j sums and draws the free
+// chain of variable j, lane 2j + 1 its evidence chain -- each sum in row order as before -- they
+// swap the free sample, and each takes every other record of the gradient walk.
+DWX_DEV void learn_variable_terms2_pair(const KernelParams &P, const uint32_t *rowptr, uint32_t row_bias,
+                                        const LearnRec *recs, uint32_t edge_bias, long long *agg,
+                                        uint32_t p, const VarPre pre, double A, double B, const uint32_t chain) {
+  const bool is_evid = pre.meta & VM_EVIDENCE;
+  const bool noise_aware = P.flags & OPT_NOISE_AWARE;
+  const uint32_t es = rowptr[pre.row0 - row_bias], ee = rowptr[pre.row0 + 1 - row_bias];
+  double pp = 0.0, pn = 0.0;
+  for (uint32_t e = es; e < ee; e += LEARN_BATCH) {
+    LearnRec r[LEARN_BATCH];
+#pragma unroll
+    for (uint32_t u = 0; u < LEARN_BATCH; ++u) r[u] = recs[umin(e + u, ee - 1) - edge_bias];
+#pragma unroll
+    for (uint32_t u = 0; u < LEARN_BATCH; ++u) {
+      const bool in = e + u < ee;
+      const double w = (double)r[u].w;
+      pp += in ? w * (double)(chain ? r[u].se1 : r[u].sf1) : 0.0;
+      pn += in ? w * (double)(chain ? r[u].se0 : r[u].sf0) : 0.0;
+    }
+  }
+  const uint32_t evid_value = pre.init;
+  uint32_t mine;
+  if (chain == 0u) {
+    mine = bool_draw(A, pp, pn);
+    P.assign_free[p] = mine;
+  } else {
+    mine = (!noise_aware && is_evid) ? evid_value : bool_draw(B, pp, pn);
+    P.assign_evid[p] = mine;
+  }
+  const uint32_t theirs = DWX_PAIR_SWAP_U32(mine);
+  const uint32_t p_free = chain == 0u ? mine : theirs;
+  if (!(P.flags & OPT_LEARN_NON_EVIDENCE) && (noise_aware || !is_evid)) return;
+  for (uint32_t e = es + chain; e < ee; e += 2u) {
+    const LearnRec r = recs[e - edge_bias];
+    if (r.packed & EDGE_FIXED_FLAG) continue;
+    const double pot_free = (double)(p_free ? r.sf1 : r.sf0);
+    const double pot_evid = (double)(evid_value ? r.se1 : r.se0);
+    const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
+    long long *dst = agg ? agg : P.grad;
+    if (gi) atomicAdd((unsigned long long *)&dst[r.wid], (unsigned long long)gi);
+    if (P.flags & OPT_DYNAMIC_T)
+      atomicAdd((unsigned long long *)&dst[P.num_weights + r.wid], (unsigned long long)(long long)FIX_SCALE);
+  }
+}
+
+// learning sweep over a boolean TILE_TERMS2 / TILE_TERMS3 tile of at most 128 variables: two
+// lanes per variable (workgroup-uniform)
+template <bool LEARN, int K, bool WIDE>
+DWX_DEV bool chain_pair_tile(const TileDesc &d) {
+  return K <= 6 && LEARN && WIDE && (d.flags & (TILE_TERMS2 | TILE_TERMS3)) && !(d.flags & TILE_CATEGORICAL) &&
+         !(d.flags & TILE_OUTSIDE) && 2u * d.nv <= BLOCK_THREADS && DWX_CHAIN_PAIRS;
+}
+
 // ---------------------------------------------------------------- kernels
 #ifndef DWX_DYN_LDS
 #define DWX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
@@ -1346,16 +1409,17 @@ DWX_DEV void issue_record_loads(const KernelParams &P, const TileDesc &d, uint32
   DWX_LOAD_TILE_RECORDS8(K, stream + d.e0, d.nedges, t, rec);
 }
 
+// pair: two lanes per variable (lanes 2j and 2j + 1 take variable j: chain_pair_tile)
 template <bool LEARN, int K, bool NT = true, class Rec, int RP>
 DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t t,
-                              TilePrefetch<K, Rec, RP> &f) {
+                              TilePrefetch<K, Rec, RP> &f, const bool pair = false) {
   issue_record_loads<LEARN, K>(P, d, t, f.rec);
 #pragma unroll
   for (uint32_t k = 0; k < (uint32_t)RP; ++k) {
     const uint32_t *rp = &P.row_ptr[d.r0 + umin(t + k * BLOCK_THREADS, d.nrows)];
     f.rp[k] = NT ? DWX_NT_LOAD(rp) : *rp;
   }
-  f.pre = load_var_pre<LEARN, NT>(P, d.v0 + umin(t, d.nv - 1));
+  f.pre = load_var_pre<LEARN, NT>(P, d.v0 + umin(pair ? t >> 1 : t, d.nv - 1));
 }
 
 // Edge-parallel evaluation of a tile's staged records whose factors have arity <= GEN_ARITY
@@ -1429,7 +1493,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
   bool has_next = next < P.tile_end;
   TileDesc dn = scalarise(P.tiles[has_next ? next : tile]);   // one descriptor ahead
   TilePrefetch<K> f;
-  issue_tile_loads<LEARN, K>(P, d, t, f);
+  issue_tile_loads<LEARN, K>(P, d, t, f, chain_pair_tile<LEARN, K, WIDE>(d));
   if (s_agg) {   // the first __syncthreads of the loop orders this before any use
     for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) s_agg[i] = 0;
   }
@@ -1662,10 +1726,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
     const TileDesc raw_nn = P.tiles[has_nn ? nn : tile];
     TileDesc dl = dn;
     if (!has_next) { dl.nedges = 0; dl.nrows = 0; dl.nv = 1; }
-    issue_tile_loads<LEARN, K>(P, dl, t, f);
+    issue_tile_loads<LEARN, K>(P, dl, t, f, has_next && chain_pair_tile<LEARN, K, WIDE>(dl));
     // process the current tile out of LDS
     int delta = 0;
-    if (fits && t < d.nv) {
+    if (fits && chain_pair_tile<LEARN, K, WIDE>(d)) {
+      if (t < 2u * d.nv)
+        learn_variable_terms2_pair(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + (t >> 1), pre, A, B, t & 1u);
+    } else if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
       if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS3) && (d.flags & TILE_CATEGORICAL))
         process_variable<LEARN, W_LREC, false>(P, T, d.v0 + t, pre, A, B);

@@ -32,6 +32,7 @@ ucontext_t g_sched;
 std::vector<Fiber> g_fibers;
 Fiber *g_cur = nullptr;
 const std::function<void()> *g_body = nullptr;
+unsigned g_bar_arrived = 0, g_bar_gen = 0;
 #if EMU_ASAN
 void *g_sched_fake = nullptr;
 const void *g_sched_bottom = nullptr;
@@ -61,7 +62,14 @@ void entry() {
 }
 }  // namespace
 
-void syncthreads() { to_sched(false); }
+// A counting barrier: a fiber waits until every LIVE fiber of the workgroup has arrived (the
+// scheduler opens it; fibers that returned do not count).  Yields for other reasons -- a lane
+// waiting for its wave or its pair partner -- therefore never pass for an arrival.
+void syncthreads() {
+  const unsigned my_gen = g_bar_gen;
+  ++g_bar_arrived;
+  while (g_bar_gen == my_gen) to_sched(false);
+}
 
 unsigned long long ballot(bool pred) {
   static unsigned char preds[1024];
@@ -100,6 +108,21 @@ double wave_sum(double v) {
   return result[w];
 }
 
+// A pair exchange (the device's __shfl_xor(v, 1)): deposit, yield until the partner has arrived.
+// Two slots per lane, by generation: the partner may run ahead into its next exchange.
+unsigned pair_swap(unsigned v) {
+  static unsigned slot[2][1024], arrived[512], gen[512];
+  const unsigned t = threadIdx_.x, pr = t >> 1;
+  const unsigned my_gen = gen[pr];
+  slot[my_gen & 1u][t] = v;
+  if (++arrived[pr] == 2) {
+    arrived[pr] = 0;
+    ++gen[pr];
+  }
+  while (gen[pr] == my_gen) to_sched(false);
+  return slot[my_gen & 1u][t ^ 1u];
+}
+
 void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::function<void()> &body) {
   // one launch at a time: the emulated "device" state above is global, and the multi-rank host
   // drivers (dw gibbs --gpus N: one host thread per rank) launch from several threads
@@ -128,6 +151,7 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::functi
       makecontext(&f.ctx, (void (*)())entry, 0);
     }
     unsigned alive = block;
+    g_bar_arrived = 0;
     while (alive) {
       for (unsigned t = 0; t < block; ++t) {
         Fiber &f = g_fibers[t];
@@ -143,6 +167,7 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::functi
         __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
 #endif
         if (f.done) --alive;
+        if (g_bar_arrived && g_bar_arrived >= alive) { g_bar_arrived = 0; ++g_bar_gen; }
       }
     }
   }

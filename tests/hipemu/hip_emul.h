@@ -30,6 +30,8 @@ unsigned long long ballot(bool pred);
 // sum over the 64 lanes of the calling thread's wave in the xor-butterfly association of the
 // device code (wave_sum_f64); only the lanes of ONE wave have to reach it together
 double wave_sum(double v);
+// the value of lane ^ 1; the two lanes of a pair have to reach it together
+unsigned pair_swap(unsigned v);
 // run `body` once per (block, thread) of the grid, blocks sequentially
 void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::function<void()> &body);
 }  // namespace emu
@@ -50,6 +52,7 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::functi
 #define __shared__ static
 #define DWX_BALLOT(pred) (::emu::ballot(pred))
 #define DWX_WAVE_SUM_F64(v) (::emu::wave_sum(v))
+#define DWX_PAIR_SWAP_U32(v) (::emu::pair_swap(v))
 #define DWX_UNIFORM(x) (x)
 #define DWX_NT_LOAD(p) (*(p))
 #define DWX_LOAD_ROW_NT 1
