@@ -281,9 +281,9 @@ int dwx_buffer_copy(dwx_sampler *s, void *dst, const void *src, uint64_t nbytes,
  * "exchange halo assignments ... grouped in one ncclGroupStart/End").  A halo list is one side
  * of the exchange with one peer: `vids` = local variable ids (owned variables a peer ghosts:
  * a SEND list; ghost variables a peer owns: a RECEIVE list, dwx_graph_desc.num_ghost_variables)
- * and a device buffer of 2 n uint32.  dwx_halo_pack_async gathers the listed variables'
+ * and a device buffer for both chains.  dwx_halo_pack_async gathers the listed variables'
  * assignments of the selected chains (bit 0: free chain, bit 1: evidence chain; selected
- * chains back to back, n values each) into the buffer; the caller moves buffers between
+ * chains back to back, see dwx_halo_message_bytes) into the buffer; the caller moves buffers between
  * ranks with its collective library on dwx_stream (ncclSend / ncclRecv); dwx_halo_unpack_async
  * scatters a received buffer into the ghosts.  All on the sampler's stream, no host
  * synchronisation.  (No reference counterpart: the reference's threads share one address
@@ -292,6 +292,12 @@ typedef struct dwx_halo dwx_halo;
 int dwx_halo_create(dwx_sampler *s, const uint64_t *vids, uint64_t n, dwx_halo **out);
 void dwx_halo_destroy(dwx_halo *h);
 int dwx_halo_buffer(dwx_halo *h, void **dev_ptr, uint64_t *nbytes);
+/* Bytes at the start of the buffer that dwx_halo_pack_async(h, chains) fills and
+ * dwx_halo_unpack_async(h, chains) reads -- what to send / receive.  Values travel as 1 bit
+ * (every listed variable boolean), 8 bits (every listed cardinality <= 256) or 32 bits each,
+ * the selected chains' blocks back to back, each padded to 8 bytes; the peer's list of the same
+ * variables gives the same number. */
+int dwx_halo_message_bytes(dwx_halo *h, int chains, uint64_t *nbytes);
 int dwx_halo_pack_async(dwx_halo *h, int chains);
 int dwx_halo_unpack_async(dwx_halo *h, int chains);
 

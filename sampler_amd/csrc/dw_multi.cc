@@ -369,13 +369,17 @@ void Rank::setup_halo() {
 }
 
 // chains: bit 0 free, bit 1 evidence.  Gather -> ONE grouped send/recv -> scatter, all on the
-// sampler's stream (4 B per boundary variable and chain).
+// sampler's stream (one bit per boolean boundary variable and chain: dwx_halo_message_bytes).
 void Rank::halo(int chains) {
   if (sh_.replicas || sh_.world == 1) return;
-  const uint64_t per = (chains == 3 ? 2 : 1) * 4;
+  auto bytes = [&](const Peer &p) {
+    uint64_t nb = 0;
+    ok(dwx_halo_message_bytes(p.h, chains, &nb));
+    return nb;
+  };
   std::vector<Xfer> sends, recvs;
-  for (auto &p : send_) { ok(dwx_halo_pack_async(p.h, chains)); sends.push_back({p.peer, p.buf, p.n * per}); }
-  for (auto &p : recv_) recvs.push_back({p.peer, p.buf, p.n * per});
+  for (auto &p : send_) { ok(dwx_halo_pack_async(p.h, chains)); sends.push_back({p.peer, p.buf, bytes(p)}); }
+  for (auto &p : recv_) recvs.push_back({p.peer, p.buf, bytes(p)});
   sh_.comm->exchange(rank_, s_, sends, recvs);    // (every rank takes part, also with empty lists)
   for (auto &p : recv_) ok(dwx_halo_unpack_async(p.h, chains));
 }

@@ -216,7 +216,10 @@ struct dwx_sampler {
 struct dwx_halo {
   dwx_sampler *s = nullptr;
   uint32_t n = 0;
-  uint32_t *d_pos = nullptr, *d_buf = nullptr;
+  uint32_t bits = 32;       // per value: 1 (all boolean), 8 (cardinalities <= 256) or 32
+  uint32_t block = 0;       // 8-byte words of one chain's block
+  uint32_t *d_pos = nullptr;
+  unsigned long long *d_buf = nullptr;
   ~dwx_halo() { rt::dfree(d_pos); rt::dfree(d_buf); }
 };
 
@@ -1635,14 +1638,20 @@ int dwx_halo_create(dwx_sampler *s, const uint64_t *vids, uint64_t n, dwx_halo *
     const CompiledGraph &c = *s->cg;
     rt::set_device(s->device);
     std::vector<uint32_t> pos(n);
+    uint32_t max_card = 0;
     for (uint64_t i = 0; i < n; ++i) {
       if (vids[i] >= c.V) throw std::invalid_argument("halo list: variable id out of range");
       pos[i] = c.pos[vids[i]];
+      max_card = std::max(max_card, c.v_meta[pos[i]] >> VM_CARD_SHIFT);
     }
     h->s = s; h->n = (uint32_t)n;
+    // (both ends list the same variables, so they choose the same width)
+    h->bits = max_card <= 2 ? 1u : (max_card <= 256 ? 8u : 32u);
+    h->block = (uint32_t)(((uint64_t)n * h->bits + 63) / 64);
     h->d_pos = upload(pos, s->stream);
-    h->d_buf = (uint32_t *)rt::dmalloc((size_t)2 * n * 4);
-    rt::dmemset(h->d_buf, 0, (size_t)2 * n * 4, s->stream);
+    const size_t bytes = std::max<size_t>((size_t)2 * h->block * 8, 8);
+    h->d_buf = (unsigned long long *)rt::dmalloc(bytes);
+    rt::dmemset(h->d_buf, 0, bytes, s->stream);
     rt::stream_sync(s->stream);
   });
   if (rc != DWX_OK) return rc;
@@ -1655,7 +1664,14 @@ void dwx_halo_destroy(dwx_halo *h) { delete h; }
 int dwx_halo_buffer(dwx_halo *h, void **dev_ptr, uint64_t *nbytes) {
   if (!h || !dev_ptr || !nbytes) return fail(DWX_E_INVALID, "null argument");
   *dev_ptr = h->d_buf;
-  *nbytes = (uint64_t)2 * h->n * 4;
+  *nbytes = (uint64_t)2 * h->block * 8;
+  return DWX_OK;
+}
+
+int dwx_halo_message_bytes(dwx_halo *h, int chains, uint64_t *nbytes) {
+  if (!h || !nbytes) return fail(DWX_E_INVALID, "null argument");
+  if (chains < 1 || chains > 3) return fail(DWX_E_INVALID, "chains: bit 0 = free chain, bit 1 = evidence chain");
+  *nbytes = (uint64_t)(chains == 3 ? 2 : 1) * h->block * 8;
   return DWX_OK;
 }
 
@@ -1668,12 +1684,18 @@ int halo_move(dwx_halo *h, int chains, bool pack) {
     dwx_sampler *s = h->s;
     rt::set_device(s->device);
     const unsigned grid = std::min<unsigned>((h->n + BLOCK_THREADS - 1) / BLOCK_THREADS, 4096u);
-    if (pack)
-      rt::launch(halo_pack_kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)h->d_pos, h->n,
-                 (const uint32_t *)s->d_assign_free, (const uint32_t *)s->d_assign_evid, (uint32_t)chains, h->d_buf);
-    else
-      rt::launch(halo_unpack_kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)h->d_pos, h->n,
-                 s->d_assign_free, s->d_assign_evid, (uint32_t)chains, (const uint32_t *)h->d_buf);
+    auto go = [&](auto pk, auto unpk) {
+      if (pack)
+        rt::launch(pk, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)h->d_pos, h->n,
+                   (const uint32_t *)s->d_assign_free, (const uint32_t *)s->d_assign_evid, (uint32_t)chains,
+                   h->d_buf, h->block);
+      else
+        rt::launch(unpk, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)h->d_pos, h->n,
+                   s->d_assign_free, s->d_assign_evid, (uint32_t)chains, (const unsigned long long *)h->d_buf, h->block);
+    };
+    if (h->bits == 1) go(halo_pack_kernel<1>, halo_unpack_kernel<1>);
+    else if (h->bits == 8) go(halo_pack_kernel<8>, halo_unpack_kernel<8>);
+    else go(halo_pack_kernel<32>, halo_unpack_kernel<32>);
   });
 }
 }  // namespace

@@ -2341,26 +2341,56 @@ average_weights_kernel(double *weights, float *w32, const uint8_t *w_fixed, cons
 // the selected chains into a contiguous buffer [chain][i] (what a peer receives), and the
 // reverse for the ghosts.  pos = device positions; chains = bit 0 free, bit 1 evidence chain;
 // the buffer holds the selected chains back to back.
+// BITS per value: 32, 8 (every listed cardinality <= 256) or 1 (every listed variable boolean:
+// a wave's 64 values are one ballot); block = 8-byte words per chain block.
+template <int BITS>
 __global__ void __launch_bounds__(BLOCK_THREADS)
 halo_pack_kernel(const uint32_t *pos, uint32_t n, const uint32_t *assign_free, const uint32_t *assign_evid,
-                 uint32_t chains, uint32_t *buf) {
+                 uint32_t chains, unsigned long long *buf, uint32_t block) {
   const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t second = (chains & 1u) ? n : 0u;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint32_t p = pos[i];
-    if (chains & 1u) buf[i] = assign_free[p];
-    if (chains & 2u) buf[second + i] = assign_evid[p];
+  const uint32_t n_round = (n + blockDim.x - 1) / blockDim.x * blockDim.x;   // (whole workgroups ballot together)
+  unsigned long long *second = buf + ((chains & 1u) ? block : 0u);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    const uint32_t p = pos[i < n ? i : n - 1];
+    const uint32_t vf = (chains & 1u) ? assign_free[p] : 0u, ve = (chains & 2u) ? assign_evid[p] : 0u;
+    if (BITS == 1) {
+      const unsigned long long mf = DWX_BALLOT(i < n && (vf & 1u)), me = DWX_BALLOT(i < n && (ve & 1u));
+      if ((threadIdx.x & 63u) == 0 && i < n) {
+        if (chains & 1u) buf[i >> 6] = mf;
+        if (chains & 2u) second[i >> 6] = me;
+      }
+    } else if (i < n) {
+      if (BITS == 8) {
+        if (chains & 1u) ((unsigned char *)buf)[i] = (unsigned char)vf;
+        if (chains & 2u) ((unsigned char *)second)[i] = (unsigned char)ve;
+      } else {
+        if (chains & 1u) ((uint32_t *)buf)[i] = vf;
+        if (chains & 2u) ((uint32_t *)second)[i] = ve;
+      }
+    }
   }
 }
+template <int BITS>
 __global__ void __launch_bounds__(BLOCK_THREADS)
 halo_unpack_kernel(const uint32_t *pos, uint32_t n, uint32_t *assign_free, uint32_t *assign_evid,
-                   uint32_t chains, const uint32_t *buf) {
+                   uint32_t chains, const unsigned long long *buf, uint32_t block) {
   const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t second = (chains & 1u) ? n : 0u;
+  const unsigned long long *second = buf + ((chains & 1u) ? block : 0u);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const uint32_t p = pos[i];
-    if (chains & 1u) assign_free[p] = buf[i];
-    if (chains & 2u) assign_evid[p] = buf[second + i];
+    uint32_t vf = 0, ve = 0;
+    if (BITS == 1) {
+      if (chains & 1u) vf = (uint32_t)(buf[i >> 6] >> (i & 63u)) & 1u;
+      if (chains & 2u) ve = (uint32_t)(second[i >> 6] >> (i & 63u)) & 1u;
+    } else if (BITS == 8) {
+      if (chains & 1u) vf = ((const unsigned char *)buf)[i];
+      if (chains & 2u) ve = ((const unsigned char *)second)[i];
+    } else {
+      if (chains & 1u) vf = ((const uint32_t *)buf)[i];
+      if (chains & 2u) ve = ((const uint32_t *)second)[i];
+    }
+    if (chains & 1u) assign_free[p] = vf;
+    if (chains & 2u) assign_evid[p] = ve;
   }
 }
 

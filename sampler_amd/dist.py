@@ -238,6 +238,7 @@ class HipEngine:
         holder = _CudaArray(ptr, max(nbytes, 4), "<i4", 4)
         h._holder = holder
         h.tensor = torch.as_tensor(holder, device=self.grad.device)[:nbytes // 4]
+        h.message = lambda mask: h.tensor[:h.message_bytes(mask) // 4]   # what travels (int32 words)
         return h
 
     def stream_context(self):
@@ -254,8 +255,8 @@ class HaloExchange:
     requested chains into the send buffers (index_select into the persistent buffer), ONE
     grouped send/recv for all peers and chains (ncclGroupStart/End under batch_isend_irecv; the
     returned works are waited on by the STREAM, which RCCL's work objects do without blocking
-    the host), scatter the received values into the ghost slots.  4 B per boundary variable and
-    chain.  Reads of ghosts between exchanges are stale by at most one sweep -- the reference's
+    the host), scatter the received values into the ghost slots.  One BIT per boundary variable
+    and chain between boolean blocks (a byte up to cardinality 256, else 4 B: dwx_halo_message_bytes).  Reads of ghosts between exchanges are stale by at most one sweep -- the reference's
     own Hogwild semantics across threads."""
 
     def __init__(self, engine, begin, end, ghost_global_ids, bounds, group=None):
@@ -289,21 +290,25 @@ class HaloExchange:
         self.bytes_per_exchange = 0      # of the last exchange: sent + received by this rank
 
     def exchange(self, chains=("free", "evid")):
-        nc = len(chains)
         mask = (1 if "free" in chains else 0) | (2 if "evid" in chains else 0)
+        moved = 0
         with self.e.stream_context():
             ops = []
             for k, h in self.send.items():
                 h.pack(mask)
-                ops.append(dist.P2POp(dist.isend, h.tensor[:nc * h.n], k, group=self.group))
+                msg = h.message(mask)
+                moved += msg.numel() * msg.element_size()
+                ops.append(dist.P2POp(dist.isend, msg, k, group=self.group))
             for k, h in self.recv.items():
-                ops.append(dist.P2POp(dist.irecv, h.tensor[:nc * h.n], k, group=self.group))
+                msg = h.message(mask)
+                moved += msg.numel() * msg.element_size()
+                ops.append(dist.P2POp(dist.irecv, msg, k, group=self.group))
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
             for h in self.recv.values():
                 h.unpack(mask)
-        self.bytes_per_exchange = 4 * nc * (self.n_boundary + self.n_ghost)
+        self.bytes_per_exchange = moved
 
 
 class ShardedDimmWitted:

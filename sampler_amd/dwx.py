@@ -30,7 +30,7 @@ SYMBOLS = [
     "dwx_get_weights", "dwx_set_weights", "dwx_average_weights_async",
     "dwx_clear_tallies", "dwx_get_tallies",
     "dwx_get_assignments", "dwx_set_assignments", "dwx_get_sweep", "dwx_set_sweep",
-    "dwx_device_buffer", "dwx_halo_create", "dwx_halo_destroy", "dwx_halo_buffer", "dwx_halo_pack_async",
+    "dwx_device_buffer", "dwx_halo_create", "dwx_halo_destroy", "dwx_halo_buffer", "dwx_halo_message_bytes", "dwx_halo_pack_async",
     "dwx_halo_unpack_async", "dwx_stream", "dwx_kernel_time", "dwx_kernel_time_reset",
     "dwx_test_factor_sign", "dwx_test_philox",
 ]
@@ -116,6 +116,7 @@ class Library:
         L.dwx_halo_create.argtypes = [vp, vp, u64, vp]
         L.dwx_halo_destroy.argtypes = [vp]; L.dwx_halo_destroy.restype = None
         L.dwx_halo_buffer.argtypes = [vp, vp, vp]
+        L.dwx_halo_message_bytes.argtypes = [vp, C.c_int, vp]
         L.dwx_halo_pack_async.argtypes = [vp, i32]
         L.dwx_halo_unpack_async.argtypes = [vp, i32]
         L.dwx_kernel_time.argtypes = [vp, i32, vp, vp, vp]
@@ -392,6 +393,12 @@ class HaloList:
         p, n = C.c_void_p(), C.c_uint64()
         self.lib.check(self.lib.L.dwx_halo_buffer(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def message_bytes(self, chains):
+        """bytes at the start of the buffer that pack(chains) fills / unpack(chains) reads."""
+        n = C.c_uint64()
+        self.lib.check(self.lib.L.dwx_halo_message_bytes(self.h, int(chains), C.byref(n)))
+        return n.value
 
     def pack(self, chains):
         self.lib.check(self.lib.L.dwx_halo_pack_async(self.h, int(chains)))

@@ -54,15 +54,21 @@ def main():
     # into the list's device buffer on the sampler's stream, change them, scatter them back
     ids = np.arange(13, 200_000, 199, dtype=np.uint64)[:1000]    # (not the ten variables flipped above)
     h = eng.halo_list(ids)
-    assert h.n == 1000 and h.tensor.numel() == 2000 and h.tensor.dtype == torch.int32
+    # boolean variables travel as one bit each, a chain's block padded to 8 bytes
+    assert h.n == 1000 and h.message_bytes(1) == 128 and h.message_bytes(3) == 256
+    assert h.tensor.numel() == 64 and h.tensor.dtype == torch.int32 and h.message(2).numel() == 32
+
+    def bits(words):
+        return np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")[:1000].astype(np.uint64)
+
     fr0, ev0 = a.assignments("free")[ids.astype(np.int64)], a.assignments("evid")[ids.astype(np.int64)]
     h.pack(3); a.wait()
-    assert np.array_equal(h.tensor[:1000].cpu().numpy().astype(np.uint64), fr0)
-    assert np.array_equal(h.tensor[1000:].cpu().numpy().astype(np.uint64), ev0)
+    assert np.array_equal(bits(h.tensor[:32]), fr0)
+    assert np.array_equal(bits(h.tensor[32:]), ev0)
     h.pack(2); a.wait()                         # one chain: its values come first
-    assert np.array_equal(h.tensor[:1000].cpu().numpy().astype(np.uint64), ev0)
+    assert np.array_equal(bits(h.tensor[:32]), ev0)
     with eng.stream_context():
-        h.tensor[:1000] = 1 - h.tensor[:1000]
+        h.tensor[:32] = ~h.tensor[:32]
     h.unpack(2); a.wait()
     assert np.array_equal(a.assignments("evid")[ids.astype(np.int64)], 1 - ev0)
     assert np.array_equal(a.assignments("free")[ids.astype(np.int64)], fr0)

@@ -93,6 +93,9 @@ class _HostHaloList:
         self.e, self.pos, self.n = engine, torch.as_tensor(ids), len(ids)
         self.tensor = torch.zeros(2 * len(ids), dtype=torch.int64)
 
+    def message(self, mask):
+        return self.tensor[:len(self._views(mask)) * self.n]
+
     def _views(self, mask):
         return [self.e._views[c] for c, bit in (("free", 1), ("evid", 2)) if mask & bit]
 

@@ -295,6 +295,11 @@ def test_arity3_tiles_evaluated_edge_parallel(lib):
     run_parity(lib, synthetic.cfg3c(2_000_000, seed=5), n_learn=2, n_infer=2, stepsize=0.001, check_index=False)
 
 
+def test_halo_lists_travel_as_bits_bytes_or_words(lib):
+    import test_kernels_emu as E
+    E.test_halo_lists_travel_as_bits_bytes_or_words(lib)
+
+
 def test_categorical_tiles_evaluated_edge_parallel(lib):
     import test_kernels_emu as E
     E.test_categorical_tiles_evaluated_edge_parallel(lib)

@@ -9,7 +9,7 @@ import pytest
 
 from conftest import FIXTURES, GOLDEN, parse_dw_args
 from parity import emu_library, run_parity
-from sampler_amd import binary_format, synthetic
+from sampler_amd import binary_format, dwx, synthetic
 
 
 @pytest.fixture(scope="module")
@@ -235,6 +235,65 @@ def test_categorical_tiles_evaluated_edge_parallel(lib):
         raw = random_graph(seed, V=600, F=3000, W=30, p_cat=0.6, max_arity=3, exact_fvals=True)
         run_parity(lib, raw, n_learn=3, n_infer=3, stepsize=0.05, learn_non_evidence=seed == 42,
                    sample_evidence=seed == 43, noise_aware=seed == 44, compile_opts=dict(tile_vars=64))
+
+
+def test_halo_lists_travel_as_bits_bytes_or_words(lib):
+    """dwx_halo_*: the listed variables' values are packed as 1 bit (all boolean), 8 bits
+    (cardinalities <= 256) or 32 bits each, chain blocks padded to 8 bytes; a list's own
+    unpack restores exactly what its pack wrote (what the peer's list of the same variables
+    receives)."""
+    import ctypes as C
+    from randgraph import random_graph
+    rng = np.random.default_rng(5)
+
+    def roundtrip(raw, ids, bits):
+        g = dwx.Graph(raw, lib=lib)
+        s = dwx.GibbsSampler(g, seed=3)
+        V = raw.num_variables
+        card = np.asarray(raw.var_cardinality, np.int64)
+        vals = {c: (rng.integers(0, 1 << 30, V) % card).astype(np.uint64) for c in ("free", "evid")}
+        for c in vals:
+            s.set_assignments(c, vals[c])
+        h = dwx.HaloList(s, ids)
+        n = len(ids)
+        block = (n * bits + 63) // 64 * 8
+        assert h.message_bytes(1) == block and h.message_bytes(2) == block and h.message_bytes(3) == 2 * block
+        ptr, nbytes = h.buffer()
+        assert nbytes == 2 * block
+        for mask in (3, 1, 2):
+            h.pack(mask)
+            host = np.zeros(nbytes, np.uint8)
+            lib.check(lib.L.dwx_buffer_copy(s.h, host.ctypes.data, ptr, nbytes, 0))
+            for k, c in enumerate([c for c, b in (("free", 1), ("evid", 2)) if mask & b]):
+                blk = host[k * block:(k + 1) * block]
+                if bits == 1:
+                    got = np.unpackbits(blk, bitorder="little")[:n]
+                elif bits == 8:
+                    got = blk[:n]
+                else:
+                    got = blk.view(np.uint32)[:n]
+                assert np.array_equal(got.astype(np.uint64), vals[c][ids.astype(np.int64)]), (bits, mask, c)
+            # scramble the variables, then unpack: the listed ones come back, nobody else moves
+            for c in vals:
+                s.set_assignments(c, (vals[c] + 1) % card.astype(np.uint64))
+            h.unpack(mask)
+            for c, b in (("free", 1), ("evid", 2)):
+                want = (vals[c] + 1) % card.astype(np.uint64)
+                if mask & b:
+                    want[ids.astype(np.int64)] = vals[c][ids.astype(np.int64)]
+                assert np.array_equal(s.assignments(c), want), (bits, mask, c)
+                s.set_assignments(c, vals[c])
+        s.close()
+
+    b = synthetic.cfg3b(700, n_weights=20, seed=2)
+    roundtrip(b, np.sort(rng.choice(700, 333, replace=False)).astype(np.uint64), 1)
+    roundtrip(b, np.array([699], np.uint64), 1)
+    c = synthetic.cfg4b(300, card=7)
+    roundtrip(c, np.sort(rng.choice(300, 77, replace=False)).astype(np.uint64), 8)
+    m = random_graph(12, V=300, F=900, W=10, p_cat=0.5, max_arity=2)
+    roundtrip(m, np.arange(0, 300, 3, dtype=np.uint64), 8)
+    big = synthetic.cfg4(40, card=300)
+    roundtrip(big, np.arange(5, 40, dtype=np.uint64), 32)
 
 
 def test_degree_bins_lane_wave_workgroup(lib):
