@@ -89,3 +89,5 @@ if __name__ == "__main__":
         run("cfg4", synthetic.cfg4(int(5_000_000 * sc), card=8, learn=False), 0, 20)
     if "cfg4learn" in todo:
         run("cfg4learn", synthetic.cfg4(int(5_000_000 * sc), card=8, learn=True), 10, 10, stepsize=0.001)
+    if "cfg4b" in todo:   # (not a BASELINE config: categorical chain, pairwise agreement factors)
+        run("cfg4b", synthetic.cfg4b(int(2_000_000 * sc), card=8, n_weights=int(200_000 * sc)), 5, 10, stepsize=0.001)
