@@ -86,6 +86,10 @@ typedef struct dwx_compile_opts {
   uint32_t wide_min_records;   /* degree binning: a variable with more edge records than this
                                   is walked by a whole wave instead of one lane (default 192;
                                   0xFFFFFFFF: never)                                   */
+  uint32_t no_record_vifs;     /* 1: factors of arity 2-3 keep their factor->variable entries once
+                                  per factor (default 0: once per edge record, in record order,
+                                  streamed by the staging pass -- 2-3x the entries; chosen
+                                  automatically when the copies would not fit 32-bit bases) */
 } dwx_compile_opts;
 
 typedef struct dwx_graph_info {

@@ -627,10 +627,22 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
         }
       });
       for (size_t i = 0; i < nt; ++i) tile_off[i + 1] += tile_off[i];
-      if (nvif + tile_off[nt] >= kUnset) throw LimitError("vif entries exceed 2^32-1");
-      g.NVif = nvif + tile_off[nt];
+      // (a graph whose per-record copies would not fit 32-bit bases keeps the small factors'
+      // entries once per factor, behind the large ones: slower gathers, same results)
+      const bool per_record = nvif + tile_off[nt] < kUnset && !o.no_record_vifs;
+      if (!per_record && nvif + nsmall >= kUnset) throw LimitError("vif entries exceed 2^32-1");
+      g.NVif = nvif + (per_record ? tile_off[nt] : nsmall);
       g.vifs.resize(g.NVif + 2);   // + 2 padding entries: branch-free pair loads of non-binary records
-      parallel_ranges(nt, nth, [&](uint64_t tb, uint64_t te) {
+      if (!per_record) {
+        parallel_ranges(nsmall, nth, [&](uint64_t b, uint64_t e) {
+          for (uint64_t i = b; i < e; ++i) g.vifs[nvif + i] = small_vifs[i];
+        });
+        parallel_ranges(g.NIdx, nth, [&](uint64_t b, uint64_t e) {
+          for (uint64_t i = b; i < e; ++i)
+            if (wants(g.edges[i])) g.edges[i].aux += (uint32_t)nvif;
+        });
+      }
+      if (per_record) parallel_ranges(nt, nth, [&](uint64_t tb, uint64_t te) {
         for (uint64_t i = tb; i < te; ++i) {
           const TileDesc &t = g.tiles[i];
           uint64_t at = nvif + tile_off[i];

@@ -214,6 +214,9 @@ def test_arity3_tiles_evaluated_edge_parallel(lib):
     assert s.graph.info.num_staged_tiles == s.graph.info.num_tiles
     run_parity(lib, synthetic.cfg3c(1500, n_weights=40, seed=4), n_learn=3, n_infer=2, stepsize=0.01,
                learn_non_evidence=True, sample_evidence=True)
+    # (factor->variable entries once per factor instead of per record: the layout huge graphs fall back to)
+    run_parity(lib, synthetic.cfg3c(1500, n_weights=40, seed=5), n_learn=2, n_infer=2, stepsize=0.01,
+               compile_opts=dict(no_record_vifs=1))
     for seed in (31, 32, 33):
         raw = random_graph(seed, V=800, F=4000, W=30, p_cat=0.0, max_arity=3, exact_fvals=True)
         run_parity(lib, raw, n_learn=3, n_infer=4, stepsize=0.05, learn_non_evidence=seed == 32,
