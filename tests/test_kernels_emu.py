@@ -214,6 +214,12 @@ def test_arity3_tiles_evaluated_edge_parallel(lib):
     assert s.graph.info.num_staged_tiles == s.graph.info.num_tiles
     run_parity(lib, synthetic.cfg3c(1500, n_weights=40, seed=4), n_learn=3, n_infer=2, stepsize=0.01,
                learn_non_evidence=True, sample_evidence=True)
+    # the 768-record and 3072-record kernel builds (K = 3: staged like K = 6; K = 12: generic walk)
+    for te in (700, 3000):
+        run_parity(lib, synthetic.cfg3c(900, n_weights=40, seed=8), n_learn=2, n_infer=2, stepsize=0.01,
+                   compile_opts=dict(tile_edges=te))
+        run_parity(lib, synthetic.cfg4b(300, card=4, seed=8), n_learn=2, n_infer=2, stepsize=0.01,
+                   compile_opts=dict(tile_edges=te))
     # (factor->variable entries once per factor instead of per record: the layout huge graphs fall back to)
     run_parity(lib, synthetic.cfg3c(1500, n_weights=40, seed=5), n_learn=2, n_infer=2, stepsize=0.01,
                compile_opts=dict(no_record_vifs=1))
