@@ -381,6 +381,24 @@ constexpr uint32_t COOP_U = 4;             // records per lane and step of a coo
 
 // sum over the 64 lanes of a wave, the same value (and the same association: the xor
 // butterfly) in every lane
+// Sums `acc` over the runs of equal `key` among the 64 lanes of a wave (equal keys sit in
+// neighbouring lanes); every lane gets the sum from itself to the end of its run, `head` says
+// whether it is the first lane of its run.  All 64 lanes call together.
+#ifndef DWX_WAVE_SEG_SUM_I64
+DWX_DEV long long wave_seg_sum_i64(uint32_t key, long long acc, bool &head) {
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (uint32_t off = 1; off < 64u; off <<= 1) {
+    const uint32_t ok = (uint32_t)__shfl_down((int)key, off, 64);
+    const long long oa = __shfl_down(acc, off, 64);
+    if (lane + off < 64u && ok == key) acc += oa;
+  }
+  const uint32_t pk = (uint32_t)__shfl_up((int)key, 1, 64);
+  head = lane == 0u || pk != key;
+  return acc;
+}
+#define DWX_WAVE_SEG_SUM_I64(key, acc, head) wave_seg_sum_i64(key, acc, head)
+#endif
 // the value of the neighbouring lane (lane ^ 1), both lanes of the pair calling together
 #ifndef DWX_PAIR_SWAP_U32
 #define DWX_PAIR_SWAP_U32(v) ((uint32_t)__shfl_xor((int)(v), 1, 64))
@@ -2080,8 +2098,11 @@ pull_grad_kernel(const uint32_t *inc_wid, const uint32_t *inc_slot, const float 
                  uint32_t n, const unsigned long long *delta, long long *grad) {
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t n_runs = (n + PULL_RUN - 1) / PULL_RUN;   // arrays are padded to a full run
-  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += stride) {
-    const uint32_t i0 = r * PULL_RUN;
+  const uint32_t lane = threadIdx.x & 63u;
+  // (whole waves stay in the loop: the lanes meet in a wave-wide sum at its end)
+  for (uint32_t r0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; r0 < n_runs; r0 += stride) {
+    const bool valid = r0 + lane < n_runs;
+    const uint32_t i0 = (valid ? r0 + lane : n_runs - 1) * PULL_RUN;
     uint32_t key[PULL_RUN], slot[PULL_RUN];
     float dd[PULL_RUN];
 #pragma unroll
@@ -2106,14 +2127,19 @@ pull_grad_kernel(const uint32_t *inc_wid, const uint32_t *inc_slot, const float 
         v = (dp[k].ng & bit) ? -q : q;
       }
       if (key[k] != cur) {
-        if (acc) atomicAdd((unsigned long long *)&grad[cur], (unsigned long long)acc);
+        if (acc && valid) atomicAdd((unsigned long long *)&grad[cur], (unsigned long long)acc);
         cur = key[k];
         acc = v;
       } else {
         acc += v;
       }
     }
-    if (acc) atomicAdd((unsigned long long *)&grad[cur], (unsigned long long)acc);
+    // The lane's last weight run usually continues in the next lanes (a heavily tied weight
+    // spans hundreds of lanes): one atomic per weight and WAVE instead of one per lane -- with
+    // 10^3-10^4 weights the per-lane atomics queued up on a few thousand addresses.
+    bool head;
+    const long long total = DWX_WAVE_SEG_SUM_I64(valid ? cur : 0xFFFFFFFFu, valid ? acc : 0ll, head);
+    if (head && total) atomicAdd((unsigned long long *)&grad[cur], (unsigned long long)total);
   }
 }
 

@@ -108,6 +108,29 @@ double wave_sum(double v) {
   return result[w];
 }
 
+long long wave_seg_sum(unsigned key, long long acc, bool &head) {
+  static unsigned keys[16][64], arrived[16], gen[16];
+  static long long accs[16][64], sums[2][16][64];
+  static bool heads[2][16][64];
+  const unsigned w = threadIdx_.x >> 6, l = threadIdx_.x & 63u;
+  const unsigned lanes = blockDim_.x - w * 64 < 64 ? blockDim_.x - w * 64 : 64;
+  keys[w][l] = key; accs[w][l] = acc;
+  const unsigned my_gen = gen[w];
+  if (++arrived[w] == lanes) {
+    for (unsigned i = 0; i < lanes; ++i) {
+      long long t = 0;
+      for (unsigned j = i; j < lanes && keys[w][j] == keys[w][i]; ++j) t += accs[w][j];
+      sums[my_gen & 1u][w][i] = t;
+      heads[my_gen & 1u][w][i] = i == 0 || keys[w][i - 1] != keys[w][i];
+    }
+    arrived[w] = 0;
+    ++gen[w];
+  }
+  while (gen[w] == my_gen) to_sched(false);
+  head = heads[my_gen & 1u][w][l];
+  return sums[my_gen & 1u][w][l];
+}
+
 // A pair exchange (the device's __shfl_xor(v, 1)): deposit, yield until the partner has arrived.
 // Two slots per lane, by generation: the partner may run ahead into its next exchange.
 unsigned pair_swap(unsigned v) {

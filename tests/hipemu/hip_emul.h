@@ -30,6 +30,9 @@ unsigned long long ballot(bool pred);
 // sum over the 64 lanes of the calling thread's wave in the xor-butterfly association of the
 // device code (wave_sum_f64); only the lanes of ONE wave have to reach it together
 double wave_sum(double v);
+// per-lane sum of `acc` from the lane to the end of its run of equal keys, and whether the lane
+// heads its run; the 64 lanes of a wave have to reach it together
+long long wave_seg_sum(unsigned key, long long acc, bool &head);
 // the value of lane ^ 1; the two lanes of a pair have to reach it together
 unsigned pair_swap(unsigned v);
 // run `body` once per (block, thread) of the grid, blocks sequentially
@@ -53,6 +56,7 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::functi
 #define DWX_BALLOT(pred) (::emu::ballot(pred))
 #define DWX_WAVE_SUM_F64(v) (::emu::wave_sum(v))
 #define DWX_PAIR_SWAP_U32(v) (::emu::pair_swap(v))
+#define DWX_WAVE_SEG_SUM_I64(key, acc, head) (::emu::wave_seg_sum(key, acc, head))
 #define DWX_UNIFORM(x) (x)
 #define DWX_NT_LOAD(p) (*(p))
 #define DWX_LOAD_ROW_NT 1

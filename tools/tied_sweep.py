@@ -19,6 +19,14 @@ def run(name, raw, W, stepsize, n=6):
             s.sample_sgd(stepsize) if kind == "learn" else s.sample()
         s.wait()
         out[kind + "_ms"] = round((time.perf_counter() - t0) / n * 1e3, 3)
+    # device time of the learning sweep kernels and of the pull-gradient kernels (events)
+    s.kernel_time_reset(True)
+    for _ in range(n):
+        s.sample_sgd(stepsize)
+    s.wait()
+    out["learn_kernel_ms"] = round(s.kernel_time("learn")[0] / n, 3)
+    out["pull_kernel_ms"] = round(s.kernel_time("pull")[0] / n, 3)
+    s.kernel_time_reset(False)
     b, c, eta = s.sgd_plan(stepsize)
     out.update(batches=b, chunks=c)
     print(json.dumps(out), flush=True)
