@@ -578,7 +578,7 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
     RawArray<Inc> kept;                    // the lists of all groups after the tables took their entries
     std::vector<uint64_t> kept_start;
     {
-      uint64_t min_w = 262144, bp_tiles = BP_TILES;
+      uint64_t min_w = 131072, bp_tiles = BP_TILES;   // (below: the list pull is as fast, tools/tied_sweep.py)
       if (const char *e = getenv("DWX_BLOCK_PULL_MIN_W")) min_w = (uint64_t)std::max(0L, atol(e));          // test hooks
       if (const char *e = getenv("DWX_BLOCK_PULL_TILES")) bp_tiles = (uint64_t)std::min<long>(BP_TILES, std::max(1L, atol(e)));
       const bool bp_timing = getenv("DWX_TIMING") != nullptr;

@@ -250,7 +250,7 @@ def test_block_pull_in_split_sweeps(lib, monkeypatch, block_tiles):
 
 
 def test_block_pull_at_size_equals_list_pull_and_oracle(lib, monkeypatch):
-    # 2 M variables, 300 k weights: the block pull engages on its own (>= 262 144 weights);
+    # 2 M variables, 300 k weights: the block pull engages on its own (>= 131 072 weights);
     # several variable blocks, two-row tables, entries left on the list.  Exact against the
     # oracle, and bit-identical to the same run with the block pull switched off.
     raw = synthetic.cfg3(2_000_000, n_weights=300_000, seed=21)
