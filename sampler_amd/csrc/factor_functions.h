@@ -1,0 +1,332 @@
+// factor_functions.h -- device-side arithmetic shared by every kernel: the Philox4x32-10 stream,
+// logadd / the draws' math, and the ten factor functions (src/factor.h:59-299) in their
+// one-evaluation and N-scenarios-in-one-walk forms.  Part of sweep_kernels.h (HIP source that
+// tests/hipemu also compiles for the host).
+#ifndef DWX_FACTOR_FUNCTIONS_H_
+#define DWX_FACTOR_FUNCTIONS_H_
+
+#include "device_types.h"
+
+#include "device_types.h"
+
+#ifndef DWX_DEV
+#define DWX_DEV __device__ __forceinline__
+#endif
+
+// Streamed-once loads / stores (per-variable words, row pointers, assignments of an all-unary
+// graph): non-temporal, so that they do not evict the re-used f32 weight table from L2.
+#ifndef DWX_NT_LOAD
+#ifdef DWX_NO_NT_META
+#define DWX_NT_LOAD(p) (*(p))
+#define DWX_NT_STORE(v, p) (*(p) = (v))
+#else
+#define DWX_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define DWX_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+#endif
+
+
+namespace dwx {
+
+
+constexpr uint32_t kNoVar = 0xFFFFFFFFu;
+
+// ---------------------------------------------------------------- RNG
+// Philox4x32-10 (Salmon et al., SC'11).  key = seed, counter = (variable id, sweep).
+DWX_DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t &c0, uint32_t &c1, uint32_t &c2,
+                           uint32_t &c3) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+}
+
+// two uniforms in [0,1) with 53 random bits each
+DWX_DEV void philox_uniforms(uint64_t seed, uint64_t vid, uint64_t sweep, double &A, double &B) {
+  uint32_t c0 = (uint32_t)vid, c1 = (uint32_t)(vid >> 32), c2 = (uint32_t)sweep,
+           c3 = (uint32_t)(sweep >> 32);
+  philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c0, c1, c2, c3);
+  uint64_t a = (uint64_t)c0 | ((uint64_t)c1 << 32);
+  uint64_t b = (uint64_t)c2 | ((uint64_t)c3 << 32);
+  A = (double)(a >> 11) * (1.0 / 9007199254740992.0);
+  B = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ---------------------------------------------------------------- math
+// src/common.h:118-132
+DWX_DEV double logadd(double a, double b) {
+  if (a < b) { double t = a; a = b; b = t; }
+  else if (a <= b && b <= a) return 0.693147180559945 + a;
+  double nd = b - a;
+  if (nd < -18.42) return a;
+  return a + log1p(exp(nd));
+}
+
+DWX_DEV bool is_linear_zero(double x) {
+  return x <= LINEAR_ZERO_THRESHOLD && x >= -LINEAR_ZERO_THRESHOLD;
+}
+
+// ---------------------------------------------------------------- factor functions
+// src/factor.h:94-100: the variable being sampled takes `proposal`, others their
+// current assignment on the chain.
+DWX_DEV bool vif_sat(const VifRec vf, uint32_t me, uint32_t proposal, const uint32_t *assign) {
+  uint32_t val = (vf.vid == me) ? proposal : assign[vf.vid];
+  return val == vf.equal_to;
+}
+
+// unary factor: the only predicate is on the sampled variable itself
+DWX_DEV double unary_sign(uint32_t func, bool s) {
+  switch (func) {
+    case FUNC_AND: case FUNC_ISTRUE: case FUNC_OR: case FUNC_IMPLY_NATURAL:
+      return s ? 1.0 : -1.0;
+    case FUNC_EQUAL:
+      return 1.0;
+    default:  // AND_CATEGORICAL, IMPLY_MLN, LINEAR, RATIO (log2(1+s)), LOGICAL
+      return s ? 1.0 : 0.0;
+  }
+}
+
+// The two FactorToVariable entries of an EDGE_INLINE2 record, decoded from the record
+// itself (TILE_INLINE2 tiles; no load).  `me` = device position of the record's owner.  A
+// pre-signed record of such a tile decodes to (me, me): harmless, its terms come from the
+// record's own fields.
+DWX_DEV void decode_inline2(const EdgeRec &r, uint32_t me, VifRec &a, VifRec &b) {
+  const bool pre = r.packed & EDGE_PRESIGNED;
+  a.vid = (pre || (r.packed & INLINE2_A_IS_OWNER)) ? me : r.aux;
+  b.vid = (pre || (r.packed & INLINE2_B_IS_OWNER)) ? me : r.aux;
+  a.equal_to = (r.packed >> INLINE2_PRED_A_SHIFT) & INLINE2_PRED_MASK;
+  b.equal_to = (r.packed >> INLINE2_PRED_B_SHIFT) & INLINE2_PRED_MASK;
+}
+
+// binary factor from its two satisfied bits (a = first predicate, b = second / head)
+DWX_DEV double binary_sign(uint32_t func, bool a, bool b) {
+  switch (func) {
+    case FUNC_AND: case FUNC_ISTRUE: return (a && b) ? 1.0 : -1.0;
+    case FUNC_AND_CATEGORICAL: return (a && b) ? 1.0 : 0.0;
+    case FUNC_OR: return (a || b) ? 1.0 : -1.0;
+    case FUNC_EQUAL: return (a == b) ? 1.0 : -1.0;
+    case FUNC_IMPLY_NATURAL: return !a ? 0.0 : (b ? 1.0 : -1.0);
+    case FUNC_IMPLY_MLN: return !a ? 1.0 : (b ? 1.0 : 0.0);
+    case FUNC_LINEAR: case FUNC_LOGICAL: return (!a || b) ? 1.0 : 0.0;
+    default: return (!a || b) ? 1.0 : 0.0;   // FUNC_RATIO: log2(1 + [!a || b])
+  }
+}
+
+// sign functions of src/factor.h:112-299 (returned as double, before * feature_value)
+DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const VifRec *vifs,
+                           const uint32_t *assign, uint32_t me, uint32_t proposal) {
+  if (arity == 1) return unary_sign(func, proposal == aux);
+  const VifRec *v = vifs + aux;
+  switch (func) {
+    case FUNC_AND: case FUNC_ISTRUE: {
+      for (uint32_t i = 0; i < arity; ++i) if (!vif_sat(v[i], me, proposal, assign)) return -1.0;
+      return 1.0;
+    }
+    case FUNC_AND_CATEGORICAL: {
+      for (uint32_t i = 0; i < arity; ++i) if (!vif_sat(v[i], me, proposal, assign)) return 0.0;
+      return 1.0;
+    }
+    case FUNC_OR: {
+      for (uint32_t i = 0; i < arity; ++i) if (vif_sat(v[i], me, proposal, assign)) return 1.0;
+      return -1.0;
+    }
+    case FUNC_EQUAL: {
+      const bool first = vif_sat(v[0], me, proposal, assign);
+      for (uint32_t i = 1; i < arity; ++i) if (vif_sat(v[i], me, proposal, assign) != first) return -1.0;
+      return 1.0;
+    }
+    case FUNC_IMPLY_MLN: case FUNC_IMPLY_NATURAL: {
+      bool body = true;
+      for (uint32_t i = 0; i + 1 < arity; ++i) body &= vif_sat(v[i], me, proposal, assign);
+      if (!body) return func == FUNC_IMPLY_MLN ? 1.0 : 0.0;
+      const bool head = vif_sat(v[arity - 1], me, proposal, assign);
+      return func == FUNC_IMPLY_MLN ? (head ? 1.0 : 0.0) : (head ? 1.0 : -1.0);
+    }
+    default: {  // LINEAR, RATIO, LOGICAL (src/factor.h:244-296)
+      const bool head = vif_sat(v[arity - 1], me, proposal, assign);
+      double res = (func == FUNC_RATIO) ? 1.0 : 0.0;
+      for (uint32_t i = 0; i + 1 < arity; ++i) {
+        const bool s = vif_sat(v[i], me, proposal, assign);
+        res += ((!s) || head) ? 1.0 : 0.0;
+      }
+      if (func == FUNC_LINEAR) return res;
+      if (func == FUNC_RATIO) return log2(res);
+      return res > 0.0 ? 1.0 : 0.0;
+    }
+  }
+}
+
+// NS evaluations of one factor in ONE walk over its variables.  Scenario j: the sampled
+// variable takes prop[j], every other variable its assignment on chain arr[j].  The generic
+// path needs several per record -- both proposals of a boolean owner; both chains when
+// learning; (evidence chain, evidence value) and (free chain, free sample) for the gradient --
+// and walking once per evaluation loads every vif entry and neighbour assignment again.
+// Same case analysis as factor_sign; s[j] = the sign in scenario j.
+//
+// Src says where position i's entry and a neighbour's value come from: memory (VifsInMemory:
+// any arity, a loop) or registers filled by an earlier, batched load phase (VifsPreloaded:
+// arity <= GEN_ARITY, loops unrolled so that every register index is static).
+constexpr uint32_t GEN_ARITY = 3;   // positions of a factor the batched generic walk preloads
+constexpr uint32_t PROP_OWN = 0xFFFFFFFFu, PROP_OTHER = 0xFFFFFFFEu;   // see factor_signs_from
+#ifndef DWX_GEN_BATCH
+#define DWX_GEN_BATCH 1
+#endif
+constexpr uint32_t GEN_BATCH = DWX_GEN_BATCH;   // records per step of the batched generic walk
+
+template <int NS>
+struct VifsInMemory {
+  static constexpr uint32_t MAXA = 0;
+  const VifRec *v;
+  const uint32_t *const (&arr)[NS];
+  DWX_DEV VifRec vif(uint32_t i) const { return v[i]; }
+  DWX_DEV uint32_t value(int j, uint32_t, uint32_t vid) const { return arr[j][vid]; }
+};
+// (one chain per scenario pair is enough for the preloaded form: chain[j] selects the value row)
+template <int NS, int NCHAIN>
+struct VifsPreloaded {
+  static constexpr uint32_t MAXA = GEN_ARITY;
+  const VifRec (&vf)[GEN_ARITY];
+  const uint32_t (&val)[NCHAIN][GEN_ARITY];
+  const int (&chain)[NS];
+  DWX_DEV VifRec vif(uint32_t i) const { return vf[i]; }
+  DWX_DEV uint32_t value(int j, uint32_t i, uint32_t) const { return val[chain[j]][i]; }
+};
+
+template <int NS, class Src>
+DWX_DEV void factor_signs_from(uint32_t func, uint32_t arity, const Src &src, uint32_t me,
+                               const uint32_t (&prop)[NS], double (&s)[NS]) {
+  constexpr uint32_t MAXA = Src::MAXA;
+  const uint32_t n = MAXA ? MAXA : arity;   // (MAXA: constant trip count, positions past the arity skipped)
+  // (PROP_OWN / PROP_OTHER: "the owner takes the value its own predicate names" / "any other
+  // value" -- what the edge-parallel staging of a categorical tile asks, where a record's
+  // proposal is its row's value)
+  auto sat = [&](uint32_t i, bool (&a)[NS]) {
+    const VifRec vf = src.vif(i);
+    const bool mine = vf.vid == me;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const bool own = prop[j] == PROP_OWN || (prop[j] != PROP_OTHER && prop[j] == vf.equal_to);
+      a[j] = mine ? own : src.value(j, i, vf.vid) == vf.equal_to;
+    }
+  };
+  bool a[NS];
+  switch (func) {
+    case FUNC_AND: case FUNC_ISTRUE: case FUNC_AND_CATEGORICAL: {
+      bool all[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) all[j] = true;
+#pragma unroll
+      for (uint32_t i = 0; i < n; ++i) {
+        if (MAXA && i >= arity) continue;
+        sat(i, a);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) all[j] &= a[j];
+      }
+      const double no = func == FUNC_AND_CATEGORICAL ? 0.0 : -1.0;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) s[j] = all[j] ? 1.0 : no;
+      return;
+    }
+    case FUNC_OR: {
+      bool any[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) any[j] = false;
+#pragma unroll
+      for (uint32_t i = 0; i < n; ++i) {
+        if (MAXA && i >= arity) continue;
+        sat(i, a);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) any[j] |= a[j];
+      }
+#pragma unroll
+      for (int j = 0; j < NS; ++j) s[j] = any[j] ? 1.0 : -1.0;
+      return;
+    }
+    case FUNC_EQUAL: {
+      bool first[NS], eq[NS];
+      sat(0, first);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) eq[j] = true;
+#pragma unroll
+      for (uint32_t i = 1; i < (MAXA ? MAXA : arity); ++i) {
+        if (MAXA && i >= arity) continue;
+        sat(i, a);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) eq[j] &= a[j] == first[j];
+      }
+#pragma unroll
+      for (int j = 0; j < NS; ++j) s[j] = eq[j] ? 1.0 : -1.0;
+      return;
+    }
+    case FUNC_IMPLY_MLN: case FUNC_IMPLY_NATURAL: {
+      bool body[NS], head[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) { body[j] = true; head[j] = false; }
+#pragma unroll
+      for (uint32_t i = 0; i < n; ++i) {
+        if (MAXA && i >= arity) continue;
+        sat(i, a);
+        const bool is_head = i + 1 == arity;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { if (is_head) head[j] = a[j]; else body[j] &= a[j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < NS; ++j)
+        s[j] = func == FUNC_IMPLY_MLN ? (!body[j] ? 1.0 : (head[j] ? 1.0 : 0.0))
+                                      : (!body[j] ? 0.0 : (head[j] ? 1.0 : -1.0));
+      return;
+    }
+    default: {  // LINEAR, RATIO, LOGICAL (src/factor.h:244-296)
+      bool head[NS];
+      if (MAXA) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) head[j] = false;
+#pragma unroll
+        for (uint32_t i = 0; i < MAXA; ++i) {
+          if (i + 1 != arity) continue;
+          sat(i, a);
+#pragma unroll
+          for (int j = 0; j < NS; ++j) head[j] = a[j];
+        }
+      } else {
+        sat(arity - 1, head);
+      }
+      double r[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) r[j] = (func == FUNC_RATIO) ? 1.0 : 0.0;
+#pragma unroll
+      for (uint32_t i = 0; i < n; ++i) {
+        if (i + 1 >= arity) continue;
+        sat(i, a);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) r[j] += ((!a[j]) || head[j]) ? 1.0 : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < NS; ++j)
+        s[j] = func == FUNC_LINEAR ? r[j] : (func == FUNC_RATIO ? log2(r[j]) : (r[j] > 0.0 ? 1.0 : 0.0));
+      return;
+    }
+  }
+}
+
+template <int NS>
+DWX_DEV void factor_signs(uint32_t func, uint32_t arity, uint32_t aux, const VifRec *vifs, uint32_t me,
+                          const uint32_t *const (&arr)[NS], const uint32_t (&prop)[NS], double (&s)[NS]) {
+  if (arity == 1) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) s[j] = unary_sign(func, prop[j] == aux);
+    return;
+  }
+  const VifsInMemory<NS> src{vifs + aux, arr};
+  factor_signs_from<NS>(func, arity, src, me, prop, s);
+}
+
+}  // namespace dwx
+#endif  // DWX_FACTOR_FUNCTIONS_H_
