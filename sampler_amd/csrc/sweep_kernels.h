@@ -210,8 +210,9 @@ DWX_DEV void stage_generic_records(const KernelParams &P, const TileDesc &d, con
 // of a tile is computed under the latency of its weight gathers.  K = records staged
 // per lane (LDS holds K * 256 records).  Oversized variables are skipped here and
 // handled by giant_kernel.
-// WIDE (learning only): the graph has TILE_TERMS2 tiles; their records are staged as
-// 32-byte LearnRec (LDS doubles, one workgroup per CU, so registers are plentiful).
+// WIDE (learning only): the graph has TILE_TERMS2 / TILE_TERMS3 tiles; their records are staged as
+// 32-byte LearnRec (the LDS region doubles: 48 KiB per workgroup at K = 6, three workgroups per CU
+// -- measured against two and four: 2.33 / 2.75 / 4.8 ms on config 3b).
 template <bool LEARN, int K, bool WIDE = false>
 // (the learning kernel's LDS footprint admits 2 workgroups per CU at K = 12: give the
 // register allocator the matching budget instead of spilling at the 3-per-CU limit)
