@@ -90,6 +90,9 @@ typedef struct dwx_compile_opts {
                                   per factor (default 0: once per edge record, in record order,
                                   streamed by the staging pass -- 2-3x the entries; chosen
                                   automatically when the copies would not fit 32-bit bases) */
+  uint32_t no_pull_unary;      /* 1: tiles with non-unary factors scatter the gradient of all their
+                                  records (default 0: their unary records take the pull gradient
+                                  of all-unary tiles when the graph has more than 1024 weights) */
 } dwx_compile_opts;
 
 typedef struct dwx_graph_info {

@@ -114,6 +114,10 @@ constexpr uint32_t TILE_INLINE2 = 1u << 4;
 constexpr uint32_t TILE_TERMS3 = 1u << 7;
 constexpr uint32_t TILE_GIANT = 1u << 5;
 constexpr uint32_t TILE_WIDE = 1u << 6;
+// boolean TILE_TERMS2 / TILE_TERMS3 tile of a graph with many weights: its PRE-SIGNED (unary) records
+// take the pull gradient of TILE_PULL tiles -- the sweep publishes the variables' ballots, the
+// incidence lists hold those records -- and only the non-unary records scatter atomics
+constexpr uint32_t TILE_PULL_UNARY = 1u << 8;
 constexpr uint32_t TILE_OUTSIDE = TILE_GIANT | TILE_WIDE;
 constexpr uint32_t WIDE_MIN_RECORDS_DEFAULT = 192;
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");

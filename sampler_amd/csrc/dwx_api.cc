@@ -540,7 +540,10 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
         [&](uint64_t tb, uint64_t te, auto &&emit) {
           for (uint64_t ti = tb; ti < te; ++ti) {
             const TileDesc &td = c.tiles[ti];
-            if (!(td.flags & TILE_PULL)) continue;
+            // (TILE_PULL_UNARY: only the tile's pre-signed records; not in a K = 12 build, whose
+            // kernels walk such tiles generically)
+            const bool unary_only = !(td.flags & TILE_PULL) && (td.flags & TILE_PULL_UNARY) && c.ecap <= 6 * BLOCK_THREADS;
+            if (!(td.flags & TILE_PULL) && !unary_only) continue;
             if (td.flags & TILE_OUTSIDE) continue;   // giant_kernel / wide_kernel: atomics
             for (uint32_t l = 0; l < td.nv; ++l) {
               const uint32_t p = td.v0 + l, m = c.v_meta[p];
@@ -548,6 +551,7 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
               for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p] + 1]; ++e) {
                 const EdgeRec &r = c.edges[e];
                 if (r.packed & EDGE_FIXED_FLAG) continue;
+                if (unary_only && !(r.packed & EDGE_PRESIGNED)) continue;
                 float miss;
                 std::memcpy(&miss, &r.aux, 4);
                 const float dd = r.fval - miss;    // exact: |hit| == |miss| or one of them is 0
@@ -1170,7 +1174,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       // edge-parallel evaluation of binary factors is compiled for K <= 6 only (register
       // budget): with 3072-record tiles such tiles take the generic path
       std::vector<TileDesc> tiles = c.tiles;
-      if (c.ecap > 6 * BLOCK_THREADS) for (auto &t : tiles) t.flags &= ~(TILE_TERMS2 | TILE_TERMS3);
+      if (c.ecap > 6 * BLOCK_THREADS) for (auto &t : tiles) t.flags &= ~(TILE_TERMS2 | TILE_TERMS3 | TILE_PULL_UNARY);
       s->d_tiles = upload(tiles, st);
     }
     for (uint32_t ti : c.giant_tiles) ((c.tiles[ti].flags & TILE_CATEGORICAL) ? s->cgiant_tiles : s->bgiant_tiles).push_back(ti);

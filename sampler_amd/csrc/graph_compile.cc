@@ -572,6 +572,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
                 ((simple && !cat && W > LDS_AGG_MAX_W && !outside) ? TILE_PULL : 0u) |
                 ((terms2 && !simple && !cat && t.nv <= 256 && !outside) ? TILE_TERMS2 : 0u) |
                 ((terms3 && !simple && (cat ? cat_terms3 : !terms2) && t.nv <= 256 && !outside) ? TILE_TERMS3 : 0u);
+      if ((t.flags & (TILE_TERMS2 | TILE_TERMS3)) && !cat && W > LDS_AGG_MAX_W && !o.no_pull_unary) t.flags |= TILE_PULL_UNARY;
       if (t.flags & (TILE_TERMS2 | TILE_TERMS3)) ++n_terms2;
       // arity-2 records carry their two vif entries themselves where the kernels that will
       // see the tile implement it (the K <= 6 builds; not the oversized-variable kernel) and

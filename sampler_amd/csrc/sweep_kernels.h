@@ -246,6 +246,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
     // learning, pull-gradient tile (all-unary boolean, no gradient scatter): the compute
     // phase needs only the records' potential terms, exactly as an inference sweep does
     const bool pull = LEARN && tile_fits(P, d) && (d.flags & TILE_PULL) && !(P.flags & OPT_NO_PULL);   // uniform
+    // ... and a TERMS tile whose unary records are pulled the same way (the others scatter)
+    const bool pull_unary = K <= 6 && LEARN && WIDE && fits && (d.flags & TILE_PULL_UNARY) && !(P.flags & OPT_NO_PULL);
     if (fits) {
       // gather the f32 sampling weight of every record this lane staged ...
       const EdgeRec (&rec)[K] = f.rec;
@@ -471,13 +473,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
     int delta = 0;
     if (fits && chain_pair_tile<LEARN, K, WIDE>(d)) {
       if (t < 2u * d.nv)
-        learn_variable_terms2_pair(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + (t >> 1), pre, A, B, t & 1u);
+        delta = learn_variable_terms2_pair(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + (t >> 1), pre, A, B,
+                                           t & 1u, pull_unary);
     } else if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
       if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS3) && (d.flags & TILE_CATEGORICAL))
         process_variable<LEARN, W_LREC, false>(P, T, d.v0 + t, pre, A, B);
       else if (K <= 6 && LEARN && WIDE && (d.flags & (TILE_TERMS2 | TILE_TERMS3)))
-        learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B);
+        delta = learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B, pull_unary);
       else if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
         delta = process_variable<LEARN, W_TERMS, true>(P, T, d.v0 + t, pre, A, B, true);
       else if ((d.flags & TILE_SIMPLE) || (K <= 6 && !LEARN && (d.flags & (TILE_TERMS2 | TILE_TERMS3))))
@@ -485,11 +488,19 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
       else
         process_variable<LEARN, WMODE, false>(P, T, d.v0 + t, pre, A, B);
     }
-    if (pull) {
+    if (pull || pull_unary) {
       // every wave of the tile publishes its two ballots (also when all zero: the words
       // are rewritten each learning sweep, so nothing needs clearing)
       const unsigned long long nz = DWX_BALLOT(delta != 0), ng = DWX_BALLOT(delta < 0);
-      if ((t & 63u) == 0) {
+      if (pull_unary && chain_pair_tile<LEARN, K, WIDE>(d)) {
+        // two lanes per variable: a wave holds 32 variables, half a ballot word
+        const uint32_t nz32 = compress_even_bits(nz), ng32 = compress_even_bits(ng);
+        if ((t & 63u) == 0) {
+          uint32_t *w = (uint32_t *)(P.delta + ((size_t)tile * 4 + (t >> 7)) * 2);
+          const uint32_t half = (t >> 6) & 1u;
+          DWX_NT_STORE(nz32, &w[half]); DWX_NT_STORE(ng32, &w[2 + half]);
+        }
+      } else if ((t & 63u) == 0) {
         unsigned long long *w = P.delta + ((size_t)tile * 4 + (t >> 6)) * 2;
         DWX_NT_STORE(nz, &w[0]); DWX_NT_STORE(ng, &w[1]);
       }

@@ -878,11 +878,25 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
 
 // ---------------------------------------------------------------- learning, TILE_TERMS2
 
+// the even bits of x, packed (lanes 2j and 2j + 1 of a chain-pair tile vote alike: 32 variables per wave)
+DWX_DEV uint32_t compress_even_bits(unsigned long long x) {
+  x &= 0x5555555555555555ull;
+  x = (x | (x >> 1)) & 0x3333333333333333ull;
+  x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+  return (uint32_t)x;
+}
+
 // sample_sgd_single_variable (src/gibbs_sampler.h:127-149) + sgd_on_variable
 // (src/factor_graph.cc:262-275) for a boolean variable, everything out of LDS.
-DWX_DEV void learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr, uint32_t row_bias,
-                                   const LearnRec *recs, uint32_t edge_bias, long long *agg,
-                                   uint32_t p, const VarPre pre, double A, double B) {
+// pull_unary (TILE_PULL_UNARY): the pre-signed records' gradient is pulled (aux_kernels.h) from the
+// returned hit(free) - hit(evid) in {-1, 0, +1} (0 for a variable that triggers no SGD); only the
+// other records scatter.
+DWX_DEV int learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr, uint32_t row_bias,
+                                  const LearnRec *recs, uint32_t edge_bias, long long *agg,
+                                  uint32_t p, const VarPre pre, double A, double B, const bool pull_unary) {
   const bool is_evid = pre.meta & VM_EVIDENCE;
   const bool noise_aware = P.flags & OPT_NOISE_AWARE;
   const uint32_t es = rowptr[pre.row0 - row_bias], ee = rowptr[pre.row0 + 1 - row_bias];
@@ -907,10 +921,11 @@ DWX_DEV void learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr
   // boolean variables carry no truthiness: sample_evid is "evidence value" or a Gibbs draw
   const uint32_t p_evid = (!noise_aware && is_evid) ? evid_value : bool_draw(B, ppe, pne);
   P.assign_evid[p] = p_evid;
-  if (!(P.flags & OPT_LEARN_NON_EVIDENCE) && (noise_aware || !is_evid)) return;
+  if (!(P.flags & OPT_LEARN_NON_EVIDENCE) && (noise_aware || !is_evid)) return 0;
   for (uint32_t e = es; e < ee; ++e) {
     const LearnRec r = recs[e - edge_bias];
     if (r.packed & EDGE_FIXED_FLAG) continue;
+    if (pull_unary && (r.packed & EDGE_PRESIGNED)) continue;
     const double pot_free = (double)(p_free ? r.sf1 : r.sf0);
     const double pot_evid = (double)(evid_value ? r.se1 : r.se0);
     const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
@@ -919,15 +934,17 @@ DWX_DEV void learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr
     if (P.flags & OPT_DYNAMIC_T)
       atomicAdd((unsigned long long *)&dst[P.num_weights + r.wid], (unsigned long long)(long long)FIX_SCALE);
   }
+  return (int)p_free - (int)evid_value;
 }
 
 // The same with TWO lanes per variable (tiles of at most 128 variables -- twelve and more records
 // each -- would leave half of the workgroup idle in this phase): lane 2j sums and draws the free
 // chain of variable j, lane 2j + 1 its evidence chain -- each sum in row order as before -- they
 // swap the free sample, and each takes every other record of the gradient walk.
-DWX_DEV void learn_variable_terms2_pair(const KernelParams &P, const uint32_t *rowptr, uint32_t row_bias,
-                                        const LearnRec *recs, uint32_t edge_bias, long long *agg,
-                                        uint32_t p, const VarPre pre, double A, double B, const uint32_t chain) {
+DWX_DEV int learn_variable_terms2_pair(const KernelParams &P, const uint32_t *rowptr, uint32_t row_bias,
+                                       const LearnRec *recs, uint32_t edge_bias, long long *agg,
+                                       uint32_t p, const VarPre pre, double A, double B, const uint32_t chain,
+                                       const bool pull_unary) {
   const bool is_evid = pre.meta & VM_EVIDENCE;
   const bool noise_aware = P.flags & OPT_NOISE_AWARE;
   const uint32_t es = rowptr[pre.row0 - row_bias], ee = rowptr[pre.row0 + 1 - row_bias];
@@ -955,10 +972,11 @@ DWX_DEV void learn_variable_terms2_pair(const KernelParams &P, const uint32_t *r
   }
   const uint32_t theirs = DWX_PAIR_SWAP_U32(mine);
   const uint32_t p_free = chain == 0u ? mine : theirs;
-  if (!(P.flags & OPT_LEARN_NON_EVIDENCE) && (noise_aware || !is_evid)) return;
+  if (!(P.flags & OPT_LEARN_NON_EVIDENCE) && (noise_aware || !is_evid)) return 0;
   for (uint32_t e = es + chain; e < ee; e += 2u) {
     const LearnRec r = recs[e - edge_bias];
     if (r.packed & EDGE_FIXED_FLAG) continue;
+    if (pull_unary && (r.packed & EDGE_PRESIGNED)) continue;
     const double pot_free = (double)(p_free ? r.sf1 : r.sf0);
     const double pot_evid = (double)(evid_value ? r.se1 : r.se0);
     const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
@@ -967,6 +985,7 @@ DWX_DEV void learn_variable_terms2_pair(const KernelParams &P, const uint32_t *r
     if (P.flags & OPT_DYNAMIC_T)
       atomicAdd((unsigned long long *)&dst[P.num_weights + r.wid], (unsigned long long)(long long)FIX_SCALE);
   }
+  return (int)p_free - (int)evid_value;   // (both lanes of the pair hold it)
 }
 
 // learning sweep over a boolean TILE_TERMS2 / TILE_TERMS3 tile of at most 128 variables: two

@@ -46,7 +46,8 @@ class CompileOpts(C.Structure):
     _fields_ = [("tile_vars", C.c_uint32), ("tile_edges", C.c_uint32), ("tile_rows", C.c_uint32),
                 ("conflict_arity_cap", C.c_uint32), ("n_threads", C.c_uint32),
                 ("no_compact_records", C.c_uint32), ("no_weight_order", C.c_uint32),
-                ("wide_min_records", C.c_uint32), ("no_record_vifs", C.c_uint32)]
+                ("wide_min_records", C.c_uint32), ("no_record_vifs", C.c_uint32),
+                ("no_pull_unary", C.c_uint32)]
 
 
 class GraphInfo(C.Structure):

@@ -300,6 +300,14 @@ def test_halo_lists_travel_as_bits_bytes_or_words(lib):
     E.test_halo_lists_travel_as_bits_bytes_or_words(lib)
 
 
+def test_unary_records_of_mixed_tiles_take_the_pull_gradient(lib):
+    import test_kernels_emu as E
+    E.test_unary_records_of_mixed_tiles_take_the_pull_gradient(lib)
+    # at size, block pull engaged (300 k weights) and list pull (20 k)
+    run_parity(lib, synthetic.cfg3b(2_000_000, n_weights=300_000, seed=8), n_learn=2, n_infer=1, stepsize=0.001, check_index=False)
+    run_parity(lib, synthetic.cfg3c(1_000_000, n_weights=20_000, seed=9), n_learn=2, n_infer=1, stepsize=0.001, check_index=False)
+
+
 def test_categorical_tiles_evaluated_edge_parallel(lib):
     import test_kernels_emu as E
     E.test_categorical_tiles_evaluated_edge_parallel(lib)

@@ -229,6 +229,30 @@ def test_arity3_tiles_evaluated_edge_parallel(lib):
                    sample_evidence=seed == 33, compile_opts=dict(tile_vars=64))
 
 
+def test_unary_records_of_mixed_tiles_take_the_pull_gradient(lib):
+    """TILE_PULL_UNARY: in a graph with more than 1024 weights the pre-signed records of boolean
+    TERMS tiles are pulled through the ballots like all-unary tiles (two lanes per variable: half
+    a ballot word per wave), the others scatter; split sweeps, the block pull, every option, and
+    the compile option that turns it off."""
+    from randgraph import random_graph
+    for kw in (dict(), dict(learn_non_evidence=True, sample_evidence=True), dict(noise_aware=True)):
+        run_parity(lib, synthetic.cfg3b(2500, n_weights=2000, seed=3), n_learn=3, n_infer=2, stepsize=0.01, **kw)
+    run_parity(lib, synthetic.cfg3c(2000, n_weights=1500, seed=4), n_learn=3, n_infer=2, stepsize=0.01)
+    run_parity(lib, synthetic.cfg3b(2000, n_weights=1200, seed=5), n_learn=2, n_infer=1, stepsize=0.01,
+               compile_opts=dict(no_pull_unary=1))
+    for seed in (51, 52, 53):   # (about ten records per variable: tiles of more than 128 variables, one lane each)
+        raw = random_graph(seed, V=900, F=4000, W=1300, p_cat=0.3 if seed == 53 else 0.0, max_arity=3, exact_fvals=True)
+        run_parity(lib, raw, n_learn=3, n_infer=2, stepsize=0.05, learn_non_evidence=seed == 52)
+        run_parity(lib, raw, n_learn=2, n_infer=1, stepsize=0.05, compile_opts=dict(tile_vars=64))
+    # heavily tied weights cut the sweep into mini-batches: per-chunk lists; and the block pull
+    run_parity(lib, synthetic.cfg3b(3000, n_weights=1100, seed=6), n_learn=3, n_infer=1, stepsize=0.5, step_cap=0.05)
+    os.environ["DWX_BLOCK_PULL_MIN_W"] = "1000"
+    try:
+        run_parity(lib, synthetic.cfg3b(3000, n_weights=1100, seed=7), n_learn=3, n_infer=1, stepsize=0.01)
+    finally:
+        del os.environ["DWX_BLOCK_PULL_MIN_W"]
+
+
 def test_categorical_tiles_evaluated_edge_parallel(lib):
     """Categorical tiles whose factors have arity <= 3 take TILE_TERMS3 too: a record's proposal
     is its row's value ("the owner's own predicate holds"), learning stages LearnRecs (hit / miss
