@@ -105,6 +105,11 @@ struct dwx_sampler {
   dwx_options opts;
   int device = 0;
   rt::stream_t stream = nullptr;
+  // The three degree bins of a launch are independent sets of one colour: the wave-per-variable and
+  // workgroup-per-variable kernels run beside the tiles' sweep kernel on two side streams, forked
+  // from and joined into `stream` with events (a hub graph's chunk: 180 -> 85 us).
+  rt::stream_t side[2] = {nullptr, nullptr};
+  rt::event_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   // device buffers
   uint32_t *d_v_meta = nullptr, *d_v_orig = nullptr, *d_v_row = nullptr, *d_v_init = nullptr;
   uint32_t *d_row_ptr = nullptr;
@@ -207,6 +212,8 @@ struct dwx_sampler {
     rt::dfree(d_edges); rt::dfree(d_edges8); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
     rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_terms); rt::dfree(d_delta);
     rt::dfree(d_w_fixed); rt::dfree(d_grad);
+    for (int i = 0; i < 2; ++i) { if (side[i]) rt::stream_destroy(side[i]); if (ev_join[i]) rt::event_destroy(ev_join[i]); }
+    if (ev_fork) rt::event_destroy(ev_fork);
     if (stream) rt::stream_destroy(stream);
   }
 };
@@ -232,6 +239,26 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   uint32_t launches = 0;
   P.tile_begin = t0;
   P.tile_end = t1;
+  // the oversized and mid-degree variables among these tiles (the lists are sorted by tile index)
+  const auto &cgt = s->cgiant_tiles;
+  const uint32_t cg0 = (uint32_t)(std::lower_bound(cgt.begin(), cgt.end(), t0) - cgt.begin());
+  const uint32_t cg1 = (uint32_t)(std::lower_bound(cgt.begin(), cgt.end(), t1) - cgt.begin());
+  const auto &bgt = s->bgiant_tiles;
+  const uint32_t bg0 = (uint32_t)(std::lower_bound(bgt.begin(), bgt.end(), t0) - bgt.begin());
+  const uint32_t bg1 = (uint32_t)(std::lower_bound(bgt.begin(), bgt.end(), t1) - bgt.begin());
+  const uint32_t *wb = c.wide_tiles.data() + c.launch_wide[l], *we = c.wide_tiles.data() + c.launch_wide[l + 1];
+  const uint32_t w0 = (uint32_t)(std::lower_bound(wb, we, t0) - c.wide_tiles.data());
+  const uint32_t w1 = (uint32_t)(std::lower_bound(wb, we, t1) - c.wide_tiles.data());
+  const bool any_giant = cg1 > cg0 || bg1 > bg0, any_wide = w1 > w0;
+  // fork: the side streams start where `stream` stands now, beside the tiles' kernel
+  // (learning launches only: an inference launch is too short -- the joins cost more than they hide)
+  const bool fork = LEARN && s->ev_fork && (any_giant || any_wide);
+  rt::stream_t st_giant = fork ? s->side[0] : s->stream, st_wide = fork ? s->side[1] : s->stream;
+  if (fork) {
+    rt::event_record(s->ev_fork, s->stream);
+    if (any_giant) rt::stream_wait_event(st_giant, s->ev_fork);
+    if (any_wide) rt::stream_wait_event(st_wide, s->ev_fork);
+  }
   // persistent grid: as many workgroups as stay resident, each striding over tiles
   // all-unary graph: 8-byte record stream (a run on the terms table streams those instead)
   const bool rec8 = s->rec8;
@@ -271,47 +298,38 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
     }
   }
   ++launches;
-  // oversized variables among these tiles (the lists are sorted by tile index); categorical: a
-  // workgroup each
-  {
-    const auto &gt = s->cgiant_tiles;
-    const uint32_t g0 = (uint32_t)(std::lower_bound(gt.begin(), gt.end(), t0) - gt.begin());
-    const uint32_t g1 = (uint32_t)(std::lower_bound(gt.begin(), gt.end(), t1) - gt.begin());
-    if (g1 > g0) {
-      rt::launch(giant_kernel<LEARN>, g1 - g0, GIANT_THREADS, 0, s->stream, P,
-                 (const uint32_t *)(s->d_giant + g0), g1 - g0);
+  // categorical oversized variables: a workgroup each
+  if (cg1 > cg0) {
+    rt::launch(giant_kernel<LEARN>, cg1 - cg0, GIANT_THREADS, 0, st_giant, P,
+               (const uint32_t *)(s->d_giant + cg0), cg1 - cg0);
+    ++launches;
+  }
+  // boolean: the pieces' partial potentials, the decisions, (learning) the pieces' gradients
+  if (bg1 > bg0) {
+    const uint32_t p0 = s->bgiant_piece_off[bg0], np = s->bgiant_piece_off[bg1] - p0;
+    rt::launch(giant_pot_kernel<LEARN>, np, GIANT_THREADS, 0, st_giant, P, (const uint32_t *)s->d_bgiant,
+               (const GiantPiece *)s->d_bgiant_pieces, p0, np, s->d_bgiant_partial);
+    rt::launch(giant_decide_kernel<LEARN>, (bg1 - bg0 + BLOCK_THREADS - 1) / BLOCK_THREADS, BLOCK_THREADS, 0, st_giant, P,
+               (const uint32_t *)s->d_bgiant, (const uint32_t *)s->d_bgiant_piece_off, bg0, bg1 - bg0,
+               (const double *)s->d_bgiant_partial, s->d_bgiant_decision);
+    launches += 2;
+    if (LEARN) {
+      rt::launch(giant_grad_kernel, np, GIANT_THREADS, 0, st_giant, P, (const uint32_t *)s->d_bgiant,
+                 (const GiantPiece *)s->d_bgiant_pieces, p0, np, (const uint32_t *)s->d_bgiant_decision);
       ++launches;
     }
   }
-  // boolean: the pieces' partial potentials, the decisions, (learning) the pieces' gradients
-  {
-    const auto &gt = s->bgiant_tiles;
-    const uint32_t g0 = (uint32_t)(std::lower_bound(gt.begin(), gt.end(), t0) - gt.begin());
-    const uint32_t g1 = (uint32_t)(std::lower_bound(gt.begin(), gt.end(), t1) - gt.begin());
-    if (g1 > g0) {
-      const uint32_t p0 = s->bgiant_piece_off[g0], np = s->bgiant_piece_off[g1] - p0;
-      rt::launch(giant_pot_kernel<LEARN>, np, GIANT_THREADS, 0, s->stream, P, (const uint32_t *)s->d_bgiant,
-                 (const GiantPiece *)s->d_bgiant_pieces, p0, np, s->d_bgiant_partial);
-      rt::launch(giant_decide_kernel<LEARN>, (g1 - g0 + BLOCK_THREADS - 1) / BLOCK_THREADS, BLOCK_THREADS, 0, s->stream, P,
-                 (const uint32_t *)s->d_bgiant, (const uint32_t *)s->d_bgiant_piece_off, g0, g1 - g0,
-                 (const double *)s->d_bgiant_partial, s->d_bgiant_decision);
-      launches += 2;
-      if (LEARN) {
-        rt::launch(giant_grad_kernel, np, GIANT_THREADS, 0, s->stream, P, (const uint32_t *)s->d_bgiant,
-                   (const GiantPiece *)s->d_bgiant_pieces, p0, np, (const uint32_t *)s->d_bgiant_decision);
-        ++launches;
-      }
-    }
-  }
   // mid-degree variables among these tiles: a wave each
-  const uint32_t *wb = c.wide_tiles.data() + c.launch_wide[l], *we = c.wide_tiles.data() + c.launch_wide[l + 1];
-  const uint32_t w0 = (uint32_t)(std::lower_bound(wb, we, t0) - c.wide_tiles.data());
-  const uint32_t w1 = (uint32_t)(std::lower_bound(wb, we, t1) - c.wide_tiles.data());
   if (w1 > w0) {
     const uint32_t per_block = BLOCK_THREADS / 64u;
-    rt::launch(wide_kernel<LEARN>, (w1 - w0 + per_block - 1) / per_block, BLOCK_THREADS, 0, s->stream, P,
+    rt::launch(wide_kernel<LEARN>, (w1 - w0 + per_block - 1) / per_block, BLOCK_THREADS, 0, st_wide, P,
                (const uint32_t *)(s->d_wide + w0), w1 - w0);
     ++launches;
+  }
+  // join: whatever follows on `stream` (the next colour, the pull gradient, an update) waits for all three
+  if (fork) {
+    if (any_giant) { rt::event_record(s->ev_join[0], st_giant); rt::stream_wait_event(s->stream, s->ev_join[0]); }
+    if (any_wide) { rt::event_record(s->ev_join[1], st_wide); rt::stream_wait_event(s->stream, s->ev_join[1]); }
   }
   return launches;
 }
@@ -1156,6 +1174,10 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     const CompiledGraph &c = *s->cg;
     s->stream = rt::stream_create();
     rt::stream_t st = s->stream;
+    if (!getenv("DWX_NO_SIDE_STREAMS")) {   // (A/B knob)
+      for (int i = 0; i < 2; ++i) { s->side[i] = rt::stream_create(); s->ev_join[i] = rt::event_create_ordering(); }
+      s->ev_fork = rt::event_create_ordering();
+    }
     const bool timing = getenv("DWX_TIMING") != nullptr;   // wall time of every phase on stderr
     auto t_phase = std::chrono::steady_clock::now();
     auto phase = [&](const char *what) {

@@ -68,6 +68,13 @@ inline event_t event_create() {
   DWX_HIP(hipEventCreate(&e));
   return e;
 }
+// (ordering only: no timestamps taken)
+inline event_t event_create_ordering() {
+  event_t e;
+  DWX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return e;
+}
+inline void stream_wait_event(stream_t s, event_t e) { DWX_HIP(hipStreamWaitEvent(s, e, 0)); }
 inline void event_destroy(event_t e) { (void)hipEventDestroy(e); }
 inline void event_record(event_t e, stream_t s) { DWX_HIP(hipEventRecord(e, s)); }
 inline double event_elapsed_ms(event_t a, event_t b) {

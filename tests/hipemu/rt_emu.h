@@ -32,6 +32,8 @@ inline stream_t stream_create() { return (stream_t)1; }
 inline void stream_destroy(stream_t) {}
 inline void stream_sync(stream_t) {}
 inline event_t event_create() { return new std::chrono::steady_clock::time_point(); }
+inline event_t event_create_ordering() { return event_create(); }
+inline void stream_wait_event(stream_t, event_t) {}   // (launches run to completion in order)
 inline void event_destroy(event_t e) { delete e; }
 inline void event_record(event_t e, stream_t) { *e = std::chrono::steady_clock::now(); }
 inline double event_elapsed_ms(event_t a, event_t b) {
