@@ -33,7 +33,10 @@ namespace dwx {
 //   W_LREC     (learning, categorical TILE_TERMS3 tiles) the staged records are LearnRecs: weight and
 //              the four products per record come out of LDS, for the draws and the gradient alike
 enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4, W_COOP = 5, W_COOPB = 6, W_PRESUM = 7, W_LREC = 8 };
-constexpr uint32_t GIANT_PIECE = 8192;     // records per workgroup of a boolean oversized variable
+#ifndef DWX_GIANT_PIECE
+#define DWX_GIANT_PIECE 4096   // (one batched step of 4 records per lane: half the latency of 8192, hub graph learning 16.8 -> 13.5 ms)
+#endif
+constexpr uint32_t GIANT_PIECE = DWX_GIANT_PIECE;     // records per workgroup of a boolean oversized variable
 #ifndef DWX_GIANT_THREADS
 #define DWX_GIANT_THREADS 1024
 #endif
