@@ -51,6 +51,9 @@ constexpr uint32_t COOP_U = 4;             // records per lane and step of a coo
 #ifndef DWX_WAVE_SEG_SUM_I64
 DWX_DEV long long wave_seg_sum_i64(uint32_t key, long long acc, bool &head) {
   const uint32_t lane = threadIdx.x & 63u;
+  // (no two neighbouring lanes share a key -- lightly tied weights: every lane heads its own run)
+  const uint32_t nk = (uint32_t)__shfl_down((int)key, 1, 64);
+  if (__ballot(lane < 63u && nk == key) == 0ull) { head = true; return acc; }
 #pragma unroll
   for (uint32_t off = 1; off < 64u; off <<= 1) {
     const uint32_t ok = (uint32_t)__shfl_down((int)key, off, 64);
