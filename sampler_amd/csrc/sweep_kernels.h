@@ -165,41 +165,53 @@ DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t
 // (TILE_TERMS3): the lane's K records in three batched phases -- all their first three
 // factor->variable entries, then those variables' assignments on every chain, then the sign
 // functions on registers -- in NS scenarios at once (as coop_for_records).  out(k, term[NS]).
-template <int K, int NS, int NCHAIN, class Out>
+// SBATCH records per batch: their loads are all in flight together (registers against
+// memory-level parallelism; 0: all K).  Measured (config 3c / categorical 4b, K = 6): inference
+// 0.934 / 0.391 ms in one batch, 0.916 / 0.349 in two (155 VGPRs and no spills instead of 167 + 16
+// spilled: config 3b's inference gains 5 % too); learning 2.92 / 1.93 against 3.04 / 1.74, and both
+// forms in one kernel cost more than either -- inference takes two batches, learning one.
+template <int K, int NS, int NCHAIN, int SBATCH, class Out>
 DWX_DEV void stage_generic_records(const KernelParams &P, const TileDesc &d, const EdgeRec (&rec)[K],
                                    const uint32_t *const (&chains)[NCHAIN], const int (&chain)[NS],
                                    const uint32_t (&prop)[NS], const bool (&hit)[NS], Out &&out) {
-  VifRec vf[K][GEN_ARITY];
-  uint32_t val[K][NCHAIN][GEN_ARITY];
+  constexpr int SB = (SBATCH > 0 && SBATCH < K) ? SBATCH : K;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const bool generic = !(rec[k].packed & EDGE_PRESIGNED);
-    const uint32_t ar = generic ? edge_arity(rec[k]) : 1u, base = (generic && ar >= 2u) ? rec[k].aux : 0u;
+  for (int k0 = 0; k0 < K; k0 += SB) {
+    VifRec vf[SB][GEN_ARITY];
+    uint32_t val[SB][NCHAIN][GEN_ARITY];
 #pragma unroll
-    for (uint32_t i = 0; i < GEN_ARITY; ++i) vf[k][i] = P.vifs[base + umin(i, ar - 1u)];
-  }
+    for (int b = 0; b < SB; ++b) {
+      const int k = k0 + b < K ? k0 + b : K - 1;
+      const bool generic = !(rec[k].packed & EDGE_PRESIGNED);
+      const uint32_t ar = generic ? edge_arity(rec[k]) : 1u, base = (generic && ar >= 2u) ? rec[k].aux : 0u;
 #pragma unroll
-  for (int k = 0; k < K; ++k)
-#pragma unroll
-    for (int c = 0; c < NCHAIN; ++c)
-#pragma unroll
-      for (uint32_t i = 0; i < GEN_ARITY; ++i) val[k][c][i] = chains[c][vf[k][i].vid];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const EdgeRec r = rec[k];
-    double term[NS];
-    if (r.packed & EDGE_PRESIGNED) {
-#pragma unroll
-      for (int j = 0; j < NS; ++j) term[j] = (double)(hit[j] ? r.fval : bits_to_float(r.aux));
-    } else {
-      const uint32_t me = d.v0 + edge_owner_lane(r);
-      double sg[NS];
-      const VifsPreloaded<NS, NCHAIN> src{vf[k], val[k], chain};
-      factor_signs_from<NS>(edge_func(r), edge_arity(r), src, me, prop, sg);
-#pragma unroll
-      for (int j = 0; j < NS; ++j) term[j] = sg[j] * (double)r.fval;
+      for (uint32_t i = 0; i < GEN_ARITY; ++i) vf[b][i] = P.vifs[base + umin(i, ar - 1u)];
     }
-    out(k, term);
+#pragma unroll
+    for (int b = 0; b < SB; ++b)
+#pragma unroll
+      for (int c = 0; c < NCHAIN; ++c)
+#pragma unroll
+        for (uint32_t i = 0; i < GEN_ARITY; ++i) val[b][c][i] = chains[c][vf[b][i].vid];
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+      const int k = k0 + b;
+      if (k >= K) break;
+      const EdgeRec r = rec[k];
+      double term[NS];
+      if (r.packed & EDGE_PRESIGNED) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) term[j] = (double)(hit[j] ? r.fval : bits_to_float(r.aux));
+      } else {
+        const uint32_t me = d.v0 + edge_owner_lane(r);
+        double sg[NS];
+        const VifsPreloaded<NS, NCHAIN> src{vf[b], val[b], chain};
+        factor_signs_from<NS>(edge_func(r), edge_arity(r), src, me, prop, sg);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) term[j] = sg[j] * (double)r.fval;
+      }
+      out(k, term);
+    }
   }
 }
 
@@ -275,12 +287,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
         const uint32_t p1 = cat ? PROP_OWN : 1u, p0 = cat ? PROP_OTHER : 0u;
         const uint32_t prop[4] = {p1, p0, p1, p0};
         const bool hit[4] = {true, false, true, false};
-        stage_generic_records<K, 4, 2>(P, d, rec, chains, chain, prop, hit, [&](int k, const double (&term)[4]) {
+        auto put = [&](int k, const double (&term)[4]) {
           LearnRec lr;
           lr.wid = rec[k].wid; lr.packed = rec[k].packed; lr.w = w[k]; lr.pad = 0;
           lr.sf1 = (float)term[0]; lr.sf0 = (float)term[1]; lr.se1 = (float)term[2]; lr.se0 = (float)term[3];
           s_lrec[t + k * BLOCK_THREADS] = lr;
-        });
+        };
+        stage_generic_records<K, 4, 2, 0>(P, d, rec, chains, chain, prop, hit, put);
       } else if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
         LearnRec *s_lrec = (LearnRec *)s_edges;
         VifRec va[K], vb[K];
@@ -335,7 +348,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
         const bool cat = d.flags & TILE_CATEGORICAL;   // (a record's proposal is its row's value; t0 unused)
         const uint32_t prop[2] = {cat ? PROP_OWN : 1u, cat ? PROP_OTHER : 0u};
         const bool hit[2] = {true, false};
-        stage_generic_records<K, 2, 1>(P, d, rec, chains, chain, prop, hit, [&](int k, const double (&term)[2]) {
+        stage_generic_records<K, 2, 1, (K + 1) / 2>(P, d, rec, chains, chain, prop, hit, [&](int k, const double (&term)[2]) {
           const double wv = (double)w[k];
           EdgeTerms tt;
           tt.t1 = wv * term[0];
