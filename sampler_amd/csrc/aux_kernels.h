@@ -27,6 +27,9 @@ struct alignas(16) F32x4 { float v[4]; };
 // fully across the lane's loads), gathers their owners' bits (one 16-byte L2 hit each,
 // all in flight), sums per weight run in registers and flushes one atomic per run.
 // No LDS, no barrier.
+// SEG: weights own long stretches of the list (host: entries per weight >= 8) -- the lanes' last
+// runs are summed per weight across the wave before the atomic; else every lane flushes its own.
+template <bool SEG>
 __global__ void __launch_bounds__(BLOCK_THREADS)
 pull_grad_kernel(const uint32_t *inc_wid, const uint32_t *inc_slot, const float *inc_d,
                  uint32_t n, const unsigned long long *delta, long long *grad) {
@@ -71,9 +74,13 @@ pull_grad_kernel(const uint32_t *inc_wid, const uint32_t *inc_slot, const float 
     // The lane's last weight run usually continues in the next lanes (a heavily tied weight
     // spans hundreds of lanes): one atomic per weight and WAVE instead of one per lane -- with
     // 10^3-10^4 weights the per-lane atomics queued up on a few thousand addresses.
-    bool head;
-    const long long total = DWX_WAVE_SEG_SUM_I64(valid ? cur : 0xFFFFFFFFu, valid ? acc : 0ll, head);
-    if (head && total) atomicAdd((unsigned long long *)&grad[cur], (unsigned long long)total);
+    if (SEG) {
+      bool head;
+      const long long total = DWX_WAVE_SEG_SUM_I64(valid ? cur : 0xFFFFFFFFu, valid ? acc : 0ll, head);
+      if (head && total) atomicAdd((unsigned long long *)&grad[cur], (unsigned long long)total);
+    } else if (acc && valid) {
+      atomicAdd((unsigned long long *)&grad[cur], (unsigned long long)acc);
+    }
   }
 }
 

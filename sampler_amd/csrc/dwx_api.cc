@@ -1018,9 +1018,14 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
     const uint32_t n = pe - pb;
     const unsigned chunk_sz = BLOCK_THREADS * PULL_RUN;
     const unsigned grid = std::min<unsigned>((n + chunk_sz - 1) / chunk_sz, 256u * DWX_PULL_GRID);
-    rt::launch(pull_grad_kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)(L.d_inc_wid + pb),
-               (const uint32_t *)(L.d_inc_slot + pb), (const float *)(L.d_inc_d + pb), n,
-               (const unsigned long long *)s->d_delta, s->d_grad);
+    auto go = [&](auto kernel) {
+      rt::launch(kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)(L.d_inc_wid + pb),
+                 (const uint32_t *)(L.d_inc_slot + pb), (const float *)(L.d_inc_d + pb), n,
+                 (const unsigned long long *)s->d_delta, s->d_grad);
+    };
+    // (a weight's entries span lanes only when it has many: what the block tables left over of a
+    // million weights does not)
+    if ((uint64_t)n >= 8 * s->cg->W) go(pull_grad_kernel<true>); else go(pull_grad_kernel<false>);
     pulled = true;
   }
   if (timing) {
