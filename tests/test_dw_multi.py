@@ -104,6 +104,43 @@ def test_cross_shard_factors_equal_the_lockstep_emulation_of_the_python_driver(d
     assert m == "".join(want) and len(want) > 100
 
 
+def test_categorical_chain_across_shards_equals_the_lockstep_emulation(dw_emu):
+    """The same comparison for categorical variables whose pairwise factors cross the block
+    boundaries (synthetic.cfg4b: a chain, every block edge is crossed): ghost values travel as
+    bytes (dwx_halo_message_bytes), update counts are dynamic ([G|T] all-reduced), the tiles are
+    staged edge-parallel -- three ranks."""
+    import halo_worker as hw
+    from test_halo_gloo import _lockstep
+    from sampler_amd import synthetic
+    from sampler_amd.dwx import fmt_g
+    total, world, card = 330, 3, 5
+
+    def build(n):
+        return synthetic.cfg4b(n, card=card, seed=21)
+
+    engines = _lockstep(total, world, build=build)
+    raw = build(total)
+    with tempfile.TemporaryDirectory() as d, tempfile.TemporaryDirectory() as out:
+        files = _write(raw, d)
+        r = subprocess.run([dw_emu, "gibbs"] + files + ["-o", out, "-l", str(hw.N_LEARN), "-i", str(hw.N_INFER),
+                                                        "--alpha", str(hw.STEP), "--diminish", str(hw.DECAY),
+                                                        "--reg_param", str(hw.REG), "--seed", str(hw.SEED),
+                                                        "--step_cap", "0", "-q", "--gpus", str(world), "--comm", "host"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        w, m = outputs(out)
+    assert w == "".join("%d %s\n" % (j, fmt_g(x)) for j, x in enumerate(engines[0].o.weights))
+    want = []
+    for e in engines:
+        t = e.o.tallies
+        for i in range(e.n_owned):
+            v = e.begin + i
+            if raw.var_role[v] == 0:
+                for k in range(card):
+                    want.append("%d %d %s\n" % (v, k, fmt_g(float(t[i * card + k]) / hw.N_INFER)))
+    assert m == "".join(want) and len(want) > 100
+
+
 def test_replicas_follow_the_reference_epoch_arithmetic(dw_emu):
     with tempfile.TemporaryDirectory() as out:
         r = run_dw(dw_emu, "biased_coin", out, args=["-l", "7", "-i", "5", "-a", "0.1", "-c", "2", "--comm", "host"])

@@ -43,10 +43,10 @@ def test_make_shard_structure():
     assert g.info.num_owned_variables == n_owned and g.info.num_values == n_owned
 
 
-def _lockstep(total, world):
+def _lockstep(total, world, build=None):
     """Two shard oracles in ONE process, stepped together; ghosts copied between sweeps."""
     import halo_worker as hw
-    raw = hw.build(total)
+    raw = (build or hw.build)(total)
     bounds = [shard_range(total, k, world) for k in range(world)]
     engines, ghosts = [], []
     for k in range(world):
