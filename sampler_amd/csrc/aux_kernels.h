@@ -131,6 +131,9 @@ pull_ell_kernel(const U32x4 *__restrict__ ell, const uint32_t *block_tile0, uint
   const uint32_t g0 = part * per, g1 = g0 + per < groups ? g0 + per : groups;
   const U32x4 *__restrict__ rows = ell + (size_t)b * DEPTH * Wp;
   long long *__restrict__ out = partial + (size_t)b * Wp;
+  // UNIFORM: one BYTE per (block, weight) -- the count of +1 / -1 steps; fold_partials_kernel multiplies
+  // (an eighth of the partial sums' traffic: 160 MB written and read again per sweep on config 3)
+  signed char *__restrict__ out8 = (signed char *)partial + (size_t)b * Wp;
   // BP_UNROLL groups per step: all their row loads are issued before the first is used (the
   // compiler does not hoist them over the stores on its own); past the end the last group is
   // loaded again and not stored
@@ -145,6 +148,7 @@ pull_ell_kernel(const U32x4 *__restrict__ ell, const uint32_t *block_tile0, uint
 #pragma unroll
     for (uint32_t u = 0; u < BP_UNROLL; ++u) {
       long long acc = 0;
+      int cnt = 0;   // UNIFORM: the sum in units of the one step (at most BP_ROW * DEPTH entries: a byte)
 #pragma unroll
       for (int dd = 0; dd < DEPTH; ++dd) {
 #pragma unroll
@@ -158,22 +162,38 @@ pull_ell_kernel(const U32x4 *__restrict__ ell, const uint32_t *block_tile0, uint
           const uint32_t nzw = s_words[word], ngw = s_words[word + 2u];
           const long long q = UNIFORM ? q0 : s_q[(e >> BP_SLOT_BITS) & (BP_DELTA_SLOTS - 1)];
           const uint32_t nz = (nzw >> (slot & 31u)) & (e != BP_EMPTY ? 1u : 0u), ng = (ngw >> (slot & 31u)) & 1u;
-          const long long t = ng ? -q : q;
-          acc += nz ? t : 0;
+          if (UNIFORM) {
+            cnt += nz ? (ng ? -1 : 1) : 0;
+          } else {
+            const long long t = ng ? -q : q;
+            acc += nz ? t : 0;
+          }
         }
       }
-      if (g + u < g1) DWX_NT_STORE(acc, &out[(g + u) * BP_THREADS + tid]);
+      if (g + u < g1) {
+        if (UNIFORM) DWX_NT_STORE((signed char)cnt, &out8[(g + u) * BP_THREADS + tid]);
+        else DWX_NT_STORE(acc, &out[(g + u) * BP_THREADS + tid]);
+      }
     }
   }
 }
 
-// grad[w] += sum over blocks of partial[block][w]
+// grad[w] += sum over blocks of partial[block][w]  (UNIFORM: byte counts of the one step q0)
+template <bool UNIFORM>
 __global__ void __launch_bounds__(BLOCK_THREADS)
-fold_partials_kernel(const long long *partial, uint32_t n_blocks, uint32_t Wp, uint32_t W, long long *grad) {
+fold_partials_kernel(const long long *partial, uint32_t n_blocks, uint32_t Wp, uint32_t W, long long *grad,
+                     const long long *qtab) {
   const uint32_t stride = gridDim.x * blockDim.x;
+  const long long q0 = qtab[0];
   for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < W; w += stride) {
     long long acc = 0;
-    for (uint32_t b = 0; b < n_blocks; ++b) acc += partial[(size_t)b * Wp + w];
+    if (UNIFORM) {
+      int cnt = 0;
+      for (uint32_t b = 0; b < n_blocks; ++b) cnt += ((const signed char *)partial)[(size_t)b * Wp + w];
+      acc = (long long)cnt * q0;
+    } else {
+      for (uint32_t b = 0; b < n_blocks; ++b) acc += partial[(size_t)b * Wp + w];
+    }
     if (acc) grad[w] += acc;
   }
 }

@@ -1009,8 +1009,13 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
       if (bt.depth == 2) { if (uni) go(pull_ell_kernel<2, true>); else go(pull_ell_kernel<2, false>); }
       else { if (uni) go(pull_ell_kernel<1, true>); else go(pull_ell_kernel<1, false>); }
       const uint32_t W = (uint32_t)s->cg->W;
-      rt::launch(fold_partials_kernel, std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 4096u), BLOCK_THREADS, 0,
-                 s->stream, (const long long *)L.d_bp_partial, bt.blocks, L.bp_wp, W, s->d_grad);
+      const unsigned fgrid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 4096u);
+      if (uni)
+        rt::launch(fold_partials_kernel<true>, fgrid, BLOCK_THREADS, 0, s->stream, (const long long *)L.d_bp_partial,
+                   bt.blocks, L.bp_wp, W, s->d_grad, (const long long *)L.d_bp_qtab);
+      else
+        rt::launch(fold_partials_kernel<false>, fgrid, BLOCK_THREADS, 0, s->stream, (const long long *)L.d_bp_partial,
+                   bt.blocks, L.bp_wp, W, s->d_grad, (const long long *)L.d_bp_qtab);
       pulled = true;
     }
   }
