@@ -122,6 +122,39 @@ def convert_fixture(name):
             f.write(" ".join(a + ["-t", "1", "-c", "1"]) + "\n")
 
 
+FLAG_GOLDENS = {
+    # tag: flags appended to the fixture's "short" arguments (TCLAP keeps the last value of a
+    # repeated flag, /root/reference/src/cmd_parser.cc getLastValueOrDefault)
+    "l1": ["--regularization", "l1", "--reg_param", "0.01"],
+    "lne": ["--learn_non_evidence"],
+    "l1_lne": ["--regularization", "l1", "--reg_param", "0.02", "--learn_non_evidence"],
+}
+
+
+def flag_goldens():
+    """`-t 1 -c 1` byte goldens of all seven fixtures with the learning flags none of the
+    reference's own dw-args exercise: --regularization l1 (src/inference_result.h:76-78) and
+    --learn_non_evidence (src/gibbs_sampler.h:144-146).  Pins the oracle's reference mode on
+    those branches (tests/test_oracle_golden.py).  sparse_multinomial2 ships with -l 0; it
+    gets 50 learning epochs here so that the flags do something."""
+    for name in FIXTURES:
+        dst = os.path.join(HERE, name)
+        base = open(os.path.join(dst, "ref_short.args")).read().split()
+        if name == "sparse_multinomial2":
+            base[base.index("-l") + 1] = "50"
+        for tag, extra in FLAG_GOLDENS.items():
+            a = base + extra
+            with tempfile.TemporaryDirectory() as out:
+                run_ref(dst, a, out)
+                shutil.copy(os.path.join(out, "inference_result.out.weights.text"),
+                            os.path.join(dst, "ref_%s.weights.text" % tag))
+                shutil.copy(os.path.join(out, "inference_result.out.text"),
+                            os.path.join(dst, "ref_%s.text" % tag))
+            with open(os.path.join(dst, "ref_%s.args" % tag), "w") as f:
+                f.write(" ".join(a) + "\n")
+        print("golden:", name, "l1 / learn_non_evidence")
+
+
 def synth_goldens():
     """Reference marginals / weights on small synthetic graphs (1/500 scale of
     BASELINE.json configs 2-4).  The reference runs multi-threaded here, so these
@@ -257,6 +290,8 @@ if __name__ == "__main__":
     if "fixtures" in which:
         codec_goldens()
         print("golden: text2bin codec fixtures")
+    if "flags" in which:
+        flag_goldens()
     if "synth" in which:
         synth_goldens()
         print("golden: synthetic")
