@@ -228,9 +228,11 @@ int dwx_sgd_plan_rows(dwx_sampler *s, uint32_t n_rows);
  * must put the same vector through the collective.  No effect on an un-split plan; reset by
  * the next dwx_sgd_plan. */
 int dwx_sgd_plan_force_dynamic(dwx_sampler *s, int on);
-/* chunk_off[n_chunks+1]: chunk c covers positions [chunk_off[c], chunk_off[c+1]) of the
- * schedule order (dwx_graph_get_schedule). */
-int dwx_sgd_get_chunks(dwx_sampler *s, uint64_t *chunk_off);
+/* chunk_range[2 * n_chunks]: chunk c covers positions [chunk_range[2c], chunk_range[2c+1]) of
+ * the schedule order (dwx_graph_get_schedule).  The chunks of a split plan go round-robin over
+ * the colour launches (the reference's id-order scan meets the colours interleaved), so their
+ * ranges are not ascending. */
+int dwx_sgd_get_chunks(dwx_sampler *s, uint64_t *chunk_range);
 int dwx_sgd_accumulate_async(dwx_sampler *s, uint32_t chunk);
 int dwx_sgd_apply_async(dwx_sampler *s);
 int dwx_sgd_finish(dwx_sampler *s);

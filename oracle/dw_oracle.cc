@@ -720,7 +720,9 @@ extern "C" void orc_sched_accumulate(orc_sampler *s, const orc_schedule *sch, ui
 // of the gradient flow the reference's T sequential updates of a weight follow over the batch,
 // with the gradient linearised with slope h:  w -= s (G + reg T w),
 // s = (1 - exp(-c stepsize)) / c, c = h + reg T  (-> the reference's own step for c stepsize
-// << 1).  L1 keeps the reference's form, only the gradient step saturates.
+// << 1).  L1 (the reference adds reg_param per visit while the weight is
+// negative, src/inference_result.h:76-78): the same flow with the push as a second field below
+// zero, integrated piece by piece (l1_flow below restates apply_kernel's).
 // hess != null: use these bounds instead of the accumulated ones (the device's fallback for
 // plans without per-chunk tables applies every chunk with the WHOLE sweep's bounds)
 extern "C" void orc_sched_apply_h(orc_sampler *s, double stepsize, const int64_t *hess);
@@ -734,9 +736,41 @@ extern "C" void orc_sched_curvature(orc_sampler *s, const orc_schedule *sch, int
     s->curvature_bounds(vid, [out](uint64_t wid, double bound) { out[wid] += llrint(kHessScale * bound); });
   }
 }
+namespace {
+constexpr double kCurvMid = 0.5;   // DWX_CURV_MID of aux_kernels.h
+// w < 0: dw/dtau = P - G - h (w - w0), P = reg T / stepsize;  w >= 0: dw/dtau = -G - h (w - w0);
+// tau in [0, stepsize].  Fields pointing at each other across zero: the reference's weight
+// rides the sawtooth w <- w - d + reg [w < 0] (values fill [-d, reg - d) evenly): end at its mean.
+double l1_flow(double w0, double G, double h, double T, double stepsize, double reg) {
+  if (!(stepsize > 0.0)) return w0;
+  const double P = reg * T / stepsize, hm = kCurvMid * h;
+  double w = w0, left = stepsize;
+  for (int piece = 0; piece < 3; ++piece) {
+    const double aP = -G - hm * (w - w0), aN = aP + P;
+    double a;
+    if (w < 0.0 || (w == 0.0 && aN <= 0.0)) a = aN;
+    else if (w > 0.0 || aP > 0.0) a = aP;
+    else return 0.5 * reg + aP * stepsize / T;
+    double phi = hm > 0.0 ? -expm1(-hm * left) / hm : left;
+    if (phi * h > 1.0) phi = 1.0 / h;
+    const double end = w + a * phi;
+    if (w == 0.0 || (w < 0.0) == (end <= 0.0)) return end;
+    const double q = -w / a;
+    left -= hm > 0.0 ? -log1p(-hm * q) / hm : q;
+    w = 0.0;
+    if (!(left > 0.0)) return 0.0;
+  }
+  return w;
+}
+}  // namespace
 extern "C" void orc_sched_apply_h(orc_sampler *s, double stepsize, const int64_t *hess) {
   int64_t *G = s->GT.data(), *T = s->GT.data() + s->W, *H = s->GT.data() + 2 * s->W;
-  auto step = [stepsize](double c) { return c > 0.0 ? -expm1(-c * stepsize) / c : stepsize; };
+  // batch_step of aux_kernels.h: the flow with the middle of [0, h] as curvature, capped at 1 / (h + r)
+  auto step = [stepsize](double h, double r) {
+    const double c = kCurvMid * h + r, cb = h + r;
+    const double st = c > 0.0 ? -expm1(-c * stepsize) / c : stepsize;
+    return st * cb > 1.0 ? 1.0 / cb : st;
+  };
   for (uint64_t w = 0; w < s->W; ++w) {
     const int64_t g = G[w], t = T[w], h = hess ? hess[w] : H[w];
     G[w] = 0; T[w] = 0; H[w] = 0;
@@ -744,10 +778,9 @@ extern "C" void orc_sched_apply_h(orc_sampler *s, double stepsize, const int64_t
     const double Tt = (double)t / kFixScale, Gg = (double)g / kFixScale, hh = (double)h / kHessScale;
     double x = s->weight_values[w];
     if (s->opts.regularization == 1) {
-      x -= step(hh + s->opts.reg_param * Tt) * (Gg + s->opts.reg_param * Tt * x);
+      x -= step(hh, s->opts.reg_param * Tt) * (Gg + s->opts.reg_param * Tt * x);
     } else {
-      x += s->opts.reg_param * Tt * (x < 0);
-      x -= step(hh) * Gg;
+      x = l1_flow(x, Gg, hh, Tt, stepsize, s->opts.reg_param);
     }
     s->weight_values[w] = x;
   }

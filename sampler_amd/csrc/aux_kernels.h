@@ -214,11 +214,53 @@ fold_partials_kernel(const long long *partial, uint32_t n_blocks, uint32_t Wp, u
 //   w - s * (G + reg T w),   s = (1 - exp(-c stepsize)) / c,   c = h[w] + reg T.
 // s -> stepsize for c stepsize << 1 (weights with few factors: the reference's own step, to
 // first order w / (1 + reg stepsize)^T - stepsize G), s -> 1 / c for heavily tied weights
-// (the flow has converged within the batch).  L1 (the reference adds reg * (w < 0) per
-// update, not scaled by the step) keeps its form; only the gradient step saturates.
+// (the flow has converged within the batch).
 // Also refreshes the f32 sampling copy of each weight it changes.
 DWX_DEV double saturating_step(double c, double stepsize) {
   return c > 0.0 ? -expm1(-c * stepsize) / c : stepsize;
+}
+// h is an upper BOUND of the batch's curvature; the reference's visits feel the true one,
+// somewhere in [0, h].  While no step can overshoot anyway (s (h + r) <= 1: monotone approach
+// whatever the truth) the flow is integrated with the middle of that interval, CURV_MID h --
+// half the worst-case lag behind the reference in a transient -- and the step is capped at
+// 1 / (h + r), the converged flow under the bound.  r = the exact part (L2 pull, reg T).
+#ifndef DWX_CURV_MID
+#define DWX_CURV_MID 0.5
+#endif
+DWX_DEV double batch_step(double h, double r, double stepsize) {
+  const double s = saturating_step(DWX_CURV_MID * h + r, stepsize), cb = h + r;
+  return s * cb > 1.0 ? 1.0 / cb : s;
+}
+// L1 (src/inference_result.h:76-78): every visit adds reg_param -- NOT scaled by the step --
+// while the weight is negative, then takes the gradient step.  Over a batch of T visits that is
+// the flow of a piecewise-linear field,
+//   w < 0:   dw/dtau = P - G - h (w - w0),   P = reg_param T / stepsize
+//   w >= 0:  dw/dtau =     - G - h (w - w0),                     tau in [0, stepsize]
+// integrated piece by piece: the push STOPS at the zero crossing.  Where the two fields point
+// at each other across zero (the gradient wants the weight negative, the push is stronger) the
+// reference's weight rides a sawtooth around zero -- w <- w - d + reg_param [w < 0] with
+// d = stepsize G(0) / T per visit, a rotation whose values fill [-d, reg_param - d) evenly; a
+// batch that ends there ends at that sawtooth's mean, reg_param / 2 - d.
+DWX_DEV double l1_flow(double w0, double G, double h, double T, double stepsize, double reg_param) {
+  if (!(stepsize > 0.0)) return w0;
+  const double P = reg_param * T / stepsize, hm = DWX_CURV_MID * h;
+  double w = w0, left = stepsize;
+  for (int piece = 0; piece < 3; ++piece) {
+    const double aP = -G - hm * (w - w0), aN = aP + P;  // the two fields at w
+    double a;
+    if (w < 0.0 || (w == 0.0 && aN <= 0.0)) a = aN;
+    else if (w > 0.0 || aP > 0.0) a = aP;
+    else return 0.5 * reg_param + aP * stepsize / T;    // sliding: aN > 0 >= aP, d = -aP stepsize / T
+    double phi = hm > 0.0 ? -expm1(-hm * left) / hm : left;
+    if (phi * h > 1.0) phi = 1.0 / h;                   // as batch_step: never past the bound's fixed point
+    const double end = w + a * phi;                     // dw/dtau = a - hm (w(tau) - w)
+    if (w == 0.0 || (w < 0.0) == (end <= 0.0)) return end;   // no crossing: monotone towards its fixed point
+    const double q = -w / a;                            // phi(tau_c): the flow reaches zero
+    left -= hm > 0.0 ? -log1p(-hm * q) / hm : q;
+    w = 0.0;
+    if (!(left > 0.0)) return 0.0;
+  }
+  return w;
 }
 __global__ void __launch_bounds__(BLOCK_THREADS)
 apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *grad,
@@ -234,10 +276,9 @@ apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *gra
     const double h = t_hess ? (double)t_hess[i] / H_SCALE : 0.0;
     double x = weights[i];
     if (l2) {
-      x -= saturating_step(h + reg_param * Tt, stepsize) * (Gg + reg_param * Tt * x);
+      x -= batch_step(h, reg_param * Tt, stepsize) * (Gg + reg_param * Tt * x);
     } else {
-      x += reg_param * Tt * (x < 0 ? 1.0 : 0.0);
-      x -= saturating_step(h, stepsize) * Gg;
+      x = l1_flow(x, Gg, h, Tt, stepsize, reg_param);
     }
     weights[i] = x;
     w32[i] = (float)x;

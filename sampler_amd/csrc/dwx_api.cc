@@ -489,9 +489,24 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
   const dwx_options &o = s->opts;
   const uint32_t nth = host_threads();
   std::unique_ptr<dwx_sampler::Level> L(new dwx_sampler::Level());
-  for (size_t l = 0; l + 1 < c.launch_off.size(); ++l) {
-    const std::vector<uint32_t> cut = cut_launch(s, l, batches);
-    for (size_t b = 0; b + 1 < cut.size(); ++b) L->chunks.push_back({(uint32_t)l, cut[b], cut[b + 1]});
+  // The pieces of a split sweep are visited ROUND-ROBIN over the colour launches, piece b of n
+  // at position (b + 1/2) / n of the sweep: any order of independent sets is a Gibbs scan, and
+  // the reference's scan in id order meets the colours interleaved, not one after the other --
+  // with heavily tied weights the weights at the end of a sweep are those the LAST visits want,
+  // and a colour can be a biased sample of the model (the observed middle variables of a chain
+  // a - b - c: tests/golden tied_chain; the reference itself run on the colour-major relabelling
+  // of that graph learns 0.87 .. 1.0 in its first epoch against 0.34 .. 0.52 in id order).
+  {
+    struct Piece { double at; dwx_sampler::Chunk ch; };
+    std::vector<Piece> pieces;
+    for (size_t l = 0; l + 1 < c.launch_off.size(); ++l) {
+      const std::vector<uint32_t> cut = cut_launch(s, l, batches);
+      const size_t n = cut.size() - 1;
+      for (size_t b = 0; b < n; ++b)
+        pieces.push_back({((double)b + 0.5) / (double)n, {(uint32_t)l, cut[b], cut[b + 1]}});
+    }
+    std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &a, const Piece &b) { return a.at < b.at; });
+    for (const Piece &pc : pieces) L->chunks.push_back(pc.ch);
   }
   const uint32_t nc = (uint32_t)L->chunks.size();
   // beyond this the per-chunk tables cost more than they save: such plans keep the
@@ -962,8 +977,9 @@ void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
 double plan_min_step(dwx_sampler *s) {
   const dwx_sampler::Level *L = s->plan_level;
   if (!L || L->c_max <= 0.0 || s->plan_eta <= 0.0) return s->plan_eta;
-  const double c = L->c_max + (s->opts.regularization == 1 ? s->opts.reg_param * L->t_max : 0.0);
-  return -std::expm1(-c * s->plan_eta) / c;
+  const double r = s->opts.regularization == 1 ? s->opts.reg_param * L->t_max : 0.0;
+  const double c = DWX_CURV_MID * L->c_max + r, st = -std::expm1(-c * s->plan_eta) / c;
+  return st * (L->c_max + r) > 1.0 ? 1.0 / (L->c_max + r) : st;   // batch_step (aux_kernels.h)
 }
 
 // accumulate the gradient of one chunk of the plan (sampling both chains on the way)
@@ -1471,13 +1487,12 @@ int dwx_sgd_plan_force_dynamic(dwx_sampler *s, int on) {
   return DWX_OK;
 }
 
-int dwx_sgd_get_chunks(dwx_sampler *s, uint64_t *chunk_off) {
-  if (!s || !chunk_off) return fail(DWX_E_INVALID, "null argument");
+int dwx_sgd_get_chunks(dwx_sampler *s, uint64_t *chunk_range) {
+  if (!s || !chunk_range) return fail(DWX_E_INVALID, "null argument");
   if (!s->plan_valid) return fail(DWX_E_INVALID, "no plan: call dwx_sgd_plan first");
   const CompiledGraph &c = *s->cg;
   size_t i = 0;
-  for (const auto &ch : s->plan_chunks) chunk_off[i++] = c.tile_v[ch.t0];
-  chunk_off[i] = s->plan_chunks.empty() ? 0 : c.tile_v[s->plan_chunks.back().t1];
+  for (const auto &ch : s->plan_chunks) { chunk_range[i++] = c.tile_v[ch.t0]; chunk_range[i++] = c.tile_v[ch.t1]; }
   return DWX_OK;
 }
 

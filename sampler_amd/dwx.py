@@ -266,9 +266,10 @@ class GibbsSampler:
         self.lib.check(self.lib.L.dwx_sgd_plan_force_dynamic(self.h, int(bool(on))))
 
     def sgd_chunks(self, n_chunks):
-        off = np.zeros(n_chunks + 1, np.uint64)
-        self.lib.check(self.lib.L.dwx_sgd_get_chunks(self.h, off.ctypes.data))
-        return off
+        """[n_chunks, 2]: chunk c covers positions [r[c, 0], r[c, 1]) of the schedule order."""
+        r = np.zeros((n_chunks, 2), np.uint64)
+        self.lib.check(self.lib.L.dwx_sgd_get_chunks(self.h, r.ctypes.data))
+        return r
 
     def sgd_accumulate(self, chunk):
         self.lib.check(self.lib.L.dwx_sgd_accumulate_async(self.h, chunk))

@@ -159,6 +159,37 @@ def tied(n_evid=100_000, n_query=1_000, n_weights=1, seed=7, p_one=(0.7, 0.3, 0.
         w_initial_value=np.zeros(n_weights), w_is_fixed=np.zeros(n_weights, np.uint8))
 
 
+def chain(n_chains=100_000, p_observed=0.5, seed=9, agree=(0.8, 0.65)):
+    """Heavily tied weights on PAIRWISE factors (the test/partial_observation shape at scale):
+    n_chains chains a - b - c of boolean variables, EQUAL(a, b) on weight 0 and EQUAL(b, c) on
+    weight 1 (func 3, predicates 1, 1): two weights x n_chains factors.  a and c are evidence,
+    b is observed with probability p_observed (else a query variable both chains sample);
+    the hidden truth has b = a with probability agree[0] and c = b with probability agree[1]."""
+    rng = _rng(seed, 0)
+    n = n_chains
+    V = 3 * n
+    a = rng.random(n) < 0.5
+    b = np.where(rng.random(n) < agree[0], a, ~a)
+    c = np.where(rng.random(n) < agree[1], b, ~b)
+    obs = rng.random(n) < p_observed
+    role = np.ones(V, np.uint8)
+    role[1::3] = obs
+    val = np.zeros(V, np.uint64)
+    val[0::3] = a; val[1::3] = b & obs; val[2::3] = c
+    F = 2 * n
+    i = np.arange(n, dtype=np.uint64)
+    edge_vid = np.empty(2 * F, np.uint64)
+    ev = edge_vid.reshape(n, 4)
+    ev[:, 0] = 3 * i; ev[:, 1] = 3 * i + 1; ev[:, 2] = 3 * i + 1; ev[:, 3] = 3 * i + 2
+    return RawGraph(
+        var_role=role, var_init_value=val,
+        var_dtype=np.full(V, DTYPE_BOOLEAN, np.uint16), var_cardinality=np.full(V, 2, np.uint64),
+        fac_func=np.full(F, FUNC_EQUAL, np.uint16), fac_edge_offset=2 * np.arange(F + 1, dtype=np.uint64),
+        fac_weight_id=np.tile(np.array([0, 1], np.uint64), n), fac_feature_value=np.ones(F),
+        edge_vid=edge_vid, edge_equal_to=np.ones(2 * F, np.uint64),
+        w_initial_value=np.zeros(2), w_is_fixed=np.zeros(2, np.uint8))
+
+
 def cfg4(V=5_000_000, card=8, seed=1234, learn=False, shard=0):
     """Config 4: V categorical variables of cardinality `card` (implicit dense domain),
     one unary AND_CATEGORICAL factor per (v, d) with weight id d (the

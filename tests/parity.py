@@ -51,7 +51,7 @@ def learn_sweep_both(s, o, order, seed, sweep, stepsize):
         hess = o.sched_curvature(order)
     s.sample_sgd(stepsize); s.wait()
     for c in range(n_chunks):
-        sl = order[int(chunk_off[c]):int(chunk_off[c + 1])]
+        sl = order[int(chunk_off[c, 0]):int(chunk_off[c, 1])]
         o.sched_accumulate(sl, np.array([0, len(sl)], np.uint64), seed, sweep)
         if batches > 1 or c + 1 == n_chunks:
             o.sched_apply(stepsize, hess)

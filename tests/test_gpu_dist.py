@@ -67,14 +67,14 @@ def test_two_ranks_share_one_gpu_over_gloo(stepsize, mixed):
     o = orc.Oracle(union, reg_param=0.01)
     sweep = 0
     for k in range(6):
-        n_chunks = max(len(res[r]["chunks%d" % k]) - 1 for r in range(world))
+        n_chunks = max(len(res[r]["chunks%d" % k]) for r in range(world))
         batches, eta = int(res[0]["batches"][k]), float(res[0]["eta"][k])
         for c in range(n_chunks):
             parts = []
             for r in range(world):
                 off = res[r]["chunks%d" % k]
-                if c + 1 < len(off):
-                    parts.append(res[r]["order"][int(off[c]):int(off[c + 1])] + np.uint64(res[r]["begin"]))
+                if c < len(off):
+                    parts.append(res[r]["order"][int(off[c, 0]):int(off[c, 1])] + np.uint64(res[r]["begin"]))
             sl = np.concatenate(parts)
             o.sched_accumulate(sl, np.array([0, len(sl)], np.uint64), 4242, sweep)
             if batches > 1 or c + 1 == n_chunks:
