@@ -93,6 +93,10 @@ typedef struct dwx_compile_opts {
   uint32_t no_pull_unary;      /* 1: tiles with non-unary factors scatter the gradient of all their
                                   records (default 0: their unary records take the pull gradient
                                   of all-unary tiles when the graph has more than 1024 weights) */
+  uint32_t no_sorted_records;  /* 1: no weight-sorted second copy of the records of boolean all-unary
+                                  tiles (default 0: compact-record graphs with >= 4096 weights get
+                                  one, and their sweeps gather weights in sorted order)        */
+  uint32_t super_tiles;        /* tiles per weight-sorted super-tile (default 32 = 8192 variables) */
 } dwx_compile_opts;
 
 typedef struct dwx_graph_info {
@@ -112,6 +116,8 @@ typedef struct dwx_graph_info {
                                   dwx_compile_opts.wide_min_records)                   */
   uint64_t num_staged_tiles;   /* tiles whose non-unary factors (arity <= 3) are evaluated
                                   edge-parallel while the tile is staged  */
+  uint64_t num_super_tiles;    /* weight-sorted super-tiles (sorted_sweep_kernel) and the records of */
+  uint64_t num_sorted_records; /* their sorted second copy; 0: no sorted copy             */
 } dwx_graph_info;
 
 /* Runtime options of one sampler (the CmdParser fields the hot path reads:
@@ -150,6 +156,12 @@ int dwx_graph_get_info(const dwx_graph *g, dwx_graph_info *out);
  * launch_off[num_launches+1] = offsets into order; every launch is an independent
  * set of the variable conflict graph. */
 int dwx_graph_get_schedule(const dwx_graph *g, uint64_t *order, uint64_t *launch_off);
+/* mask[num_variables] (reference numbering): 1 where the device sums the variable's potentials
+ * in fixed point (2^-32; boolean variables of an all-unary graph on the lane path -- the sums
+ * are then independent of the order of the records, which the weight-sorted sweep relies on),
+ * 0 where it adds f64 terms in the reference's row order (src/factor_graph.h:127-145).  Test
+ * hook: the CPU oracle's schedule mode follows it, so device-vs-oracle parity stays exact. */
+int dwx_graph_get_fixed_point_mask(const dwx_graph *g, uint8_t *mask);
 /* Value table for result dumps (src/inference_result.cc:211-243):
  * var_val_base[V] (reference numbering) and value_sparse[num_values]. */
 int dwx_graph_get_values(const dwx_graph *g, uint64_t *var_val_base, uint64_t *value_sparse);

@@ -72,6 +72,7 @@ def lib():
         L.orc_grad.restype = vp; L.orc_grad.argtypes = [vp]
         L.orc_set_var_id_offset.argtypes = [vp, u64]
         L.orc_set_sampling_weight_f32.argtypes = [vp, i32]
+        L.orc_set_fixed_point_mask.argtypes = [vp, vp]; L.orc_set_fixed_point_mask.restype = None
         L.orc_sched_check_independent.restype = i32
         L.orc_sched_check_independent.argtypes = [vp, vp]
         L.orc_philox_uniforms.argtypes = [u64, u64, u64, vp]
@@ -151,6 +152,16 @@ class Oracle:
 
     def clear_tallies(self):
         self.L.orc_clear_tallies(self.h)
+
+    def set_fixed_point_mask(self, mask):
+        """Schedule mode: uint8[V], 1 where the device sums a variable's potentials in fixed point
+        (sampler_amd.dwx.Graph.fixed_point_mask); None clears it."""
+        if mask is None:
+            self.L.orc_set_fixed_point_mask(self.h, None)
+        else:
+            m = np.ascontiguousarray(mask, np.uint8)
+            assert len(m) == self.V
+            self.L.orc_set_fixed_point_mask(self.h, m.ctypes.data)
 
     # ---- reference mode ----
     def set_workers(self, n):

@@ -116,6 +116,7 @@ struct orc_sampler {
   // schedule-mode accumulators
   std::vector<int64_t> GT;   // G[W], T[W], then H[W] (curvature bounds, schedule mode)
   uint64_t vid_offset = 0;
+  std::vector<uint8_t> fixed_mask;  // schedule mode: variables whose potentials the device sums in fixed point
   bool f32w = false;  // schedule mode: potentials use the weight rounded to f32 (device's sampling copy)
 
   // ---- src/factor.h:94-100 is_variable_satisfied ----
@@ -203,14 +204,32 @@ struct orc_sampler {
     return pot;
   }
 
+  // Schedule mode, variables the device sums in fixed point (dwx_graph_get_fixed_point_mask:
+  // boolean variables of an all-unary graph): pp - pn = 2^-32 * sum over the row of
+  // round(2^32 * clamp(w * (term(1) - term(0)))) -- an integer sum, independent of the order of
+  // the records (pot_fix in sampler_amd/csrc/factor_functions.h).
+  double fixed_point_pot_diff(const Var &var, uint64_t vid, const uint64_t *assign, const double *w) const {
+    long long acc = 0;
+    const Value &vv = values[var.var_val_base];
+    for (uint64_t i = 0; i < vv.index_len; ++i) {
+      const Factor &f = factors[factor_index[vv.index_base + i]];
+      const double wv = f32w ? (double)(float)w[f.weight_id] : w[f.weight_id];
+      double p = wv * factor_potential(f, assign, vid, 1) - wv * factor_potential(f, assign, vid, 0);
+      p = p < -524288.0 ? -524288.0 : (p > 524288.0 ? 524288.0 : p);
+      acc += (long long)nearbyint(p * 4294967296.0);
+    }
+    return (double)acc * (1.0 / 4294967296.0);
+  }
+
   // ---- src/gibbs_sampler.h:192-254 draw_sample, with the uniform r supplied ----
   template <class Rng>
   uint64_t draw_sample(uint64_t vid, const uint64_t *assign, const double *w, Rng &&next_r,
                        std::vector<double> &buf) const {
     const Var &var = vars[vid];
     if (var.is_bool) {                          // :198-215
-      double pp = potential(var, vid, 1, assign, w);
-      double pn = potential(var, vid, 0, assign, w);
+      const bool fixed = !fixed_mask.empty() && fixed_mask[vid];
+      double pp = fixed ? fixed_point_pot_diff(var, vid, assign, w) : potential(var, vid, 1, assign, w);
+      double pn = fixed ? 0.0 : potential(var, vid, 0, assign, w);
       double r = next_r();
       return (r * (1.0 + exp(pn - pp)) < 1.0) ? 1 : 0;
     }
@@ -680,6 +699,9 @@ extern "C" int orc_sched_check_independent(orc_sampler *s, const orc_schedule *s
 
 extern "C" void orc_set_var_id_offset(orc_sampler *s, uint64_t off) { s->vid_offset = off; }
 extern "C" void orc_set_sampling_weight_f32(orc_sampler *s, int on) { s->f32w = on != 0; }
+extern "C" void orc_set_fixed_point_mask(orc_sampler *s, const uint8_t *mask) {
+  if (mask) s->fixed_mask.assign(mask, mask + s->V); else s->fixed_mask.clear();
+}
 extern "C" int64_t *orc_grad(orc_sampler *s) { return s->GT.data(); }
 
 extern "C" void orc_sched_sample(orc_sampler *s, const orc_schedule *sch, uint64_t seed, uint64_t sweep) {

@@ -135,6 +135,9 @@ void orc_set_var_id_offset(orc_sampler *s, uint64_t off);
 /* device semantics: FactorGraph::potential multiplies with the weight rounded to f32
  * (the device's L2-resident sampling copy); off in reference mode */
 void orc_set_sampling_weight_f32(orc_sampler *s, int on);
+/* schedule mode: mask[V] != 0 where the device sums a boolean variable's potentials in fixed
+ * point (dwx_graph_get_fixed_point_mask); null clears it */
+void orc_set_fixed_point_mask(orc_sampler *s, const uint8_t *mask);
 /* returns 1 if every launch of the schedule is an independent set */
 int orc_sched_check_independent(orc_sampler *s, const orc_schedule *sch);
 /* two uniforms in [0,1) from Philox4x32-10 (test hook) */

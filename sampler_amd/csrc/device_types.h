@@ -68,6 +68,30 @@ static_assert(sizeof(EdgeRec8) == 8, "EdgeRec8 must be 8 bytes");
 constexpr uint32_t REC8_WID_BITS = 27, REC8_WID_MASK = (1u << REC8_WID_BITS) - 1;
 constexpr uint32_t REC8_FIXED = 1u << 27, REC8_HIT_SHIFT = 28, REC8_MISS_SHIFT = 30;
 
+// Weight-sorted super-tiles (sorted_sweep_kernel): SUPER_TILES consecutive
+// boolean all-unary tiles of one launch whose records exist a SECOND time, sorted by weight id
+// -- neighbouring lanes of the record stream then gather neighbouring weights: a fraction of an
+// L2 request per record instead of one.  A record adds w * d to its owner's potential
+// difference pp - pn, d = (sign(hit) - sign(miss)) * f, summed in fixed point in LDS (pot_fix).
+//   wid: the weight id;  od: bits 0-12 the owner's slot in the super-tile (variable position -
+//   SuperTile::v0), bits 13-31 the index of d in the table of distinct values (entry 0 is 0.0:
+//   the zero-filled lanes past a super-tile's end add nothing).
+struct alignas(8) SortRec8 {
+  uint32_t wid, od;
+};
+static_assert(sizeof(SortRec8) == 8, "SortRec8 must be 8 bytes");
+constexpr uint32_t SORT_OWNER_BITS = 13, SORT_OWNER_MASK = (1u << SORT_OWNER_BITS) - 1;
+constexpr uint32_t SUPER_NV_MAX = 1u << SORT_OWNER_BITS;      // 8192 variables: 64 KiB of sums
+constexpr uint32_t SUPER_TILES_DEFAULT = 32;
+constexpr uint32_t SORT_MAX_DVALS = 1024;                     // distinct d values (8 KiB in LDS), else no sorted copy
+struct alignas(16) SuperTile {
+  uint32_t tile0, ntiles;   // tiles [tile0, tile0 + ntiles)
+  uint32_t v0, nv;          // variables [v0, v0 + nv), nv <= SUPER_NV_MAX
+  uint32_t lo, hi;          // sorted records [lo | hi << 32, ... + nrec)
+  uint32_t nrec, pad;
+};
+static_assert(sizeof(SuperTile) == 32, "SuperTile must be 32 bytes");
+
 // factor -> variable entry (src/variable.h:154-167), 8 bytes, device variable ids
 struct alignas(8) VifRec {
   uint32_t vid;       // DEVICE position of the variable

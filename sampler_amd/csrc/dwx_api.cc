@@ -145,6 +145,13 @@ struct dwx_sampler {
   size_t lds_tab = 0;                    // inference on the 8-byte terms table: 8 bytes staged per record
   unsigned persistent_blocks_tab = 1;
   EdgeRec8 *d_edges8 = nullptr;
+  // weight-sorted super-tiles (sorted_sweep_kernel)
+  SortRec8 *d_sorted = nullptr;
+  SuperTile *d_supers = nullptr;
+  double *d_sort_dvals = nullptr;
+  uint32_t n_sort_dvals = 0;
+  size_t lds_sorted = 0;
+  bool sorted_learn = false;            // ... also in learning sweeps (the super-tiles' tiles pull their gradient)
   double *d_row_truth = nullptr, *d_edge_fval64 = nullptr;
   EdgeRec *d_edges = nullptr;
   VifRec *d_vifs = nullptr;
@@ -209,6 +216,7 @@ struct dwx_sampler {
     rt::dfree(d_v_meta); rt::dfree(d_v_orig); rt::dfree(d_v_row); rt::dfree(d_v_init);
     rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_wide); rt::dfree(d_bgiant); rt::dfree(d_bgiant_piece_off);
     rt::dfree(d_bgiant_decision); rt::dfree(d_bgiant_pieces); rt::dfree(d_bgiant_partial); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
+    rt::dfree(d_sorted); rt::dfree(d_supers); rt::dfree(d_sort_dvals);
     rt::dfree(d_edges); rt::dfree(d_edges8); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
     rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_terms); rt::dfree(d_delta);
     rt::dfree(d_w_fixed); rt::dfree(d_grad);
@@ -259,6 +267,12 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
     if (any_giant) rt::stream_wait_event(st_giant, s->ev_fork);
     if (any_wide) rt::stream_wait_event(st_wide, s->ev_fork);
   }
+  // the lane-bin tiles of [a, b): the persistent tile sweep
+  auto launch_lane_tiles = [&](uint32_t a, uint32_t b) {
+  if (b <= a) return;
+  P.tile_begin = a;
+  P.tile_end = b;
+  const uint32_t t0 = a, t1 = b;
   // persistent grid: as many workgroups as stay resident, each striding over tiles
   // all-unary graph: 8-byte record stream (a run on the terms table streams those instead)
   const bool rec8 = s->rec8;
@@ -298,6 +312,43 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
     }
   }
   ++launches;
+  };
+  // Weight-sorted super-tiles lying wholly inside [t0, t1): sorted_sweep_kernel, one workgroup
+  // each (not on the terms table: repeated inference gathers nothing; not when this sweep
+  // scatters its gradient or counts updates dynamically -- the kernel only publishes ballots);
+  // the tiles before, between and behind them: the tile sweep.
+  bool used_sorted = false;
+  if (s->d_supers && !P.edge_terms && (!LEARN || (s->sorted_learn && !(P.flags & (OPT_NO_PULL | OPT_DYNAMIC_T))))) {
+    const std::vector<SuperTile> &sv = c.supers;
+    size_t a = std::lower_bound(sv.begin(), sv.end(), t0, [](const SuperTile &x, uint32_t t) { return x.tile0 < t; }) - sv.begin();
+    size_t b = a;
+    while (b < sv.size() && sv[b].tile0 + sv[b].ntiles <= t1) ++b;
+    // gap-free runs of super-tiles
+    struct Run { size_t a, b; };
+    std::vector<Run> runs;
+    for (size_t i = a; i < b;) {
+      size_t j = i + 1;
+      while (j < b && sv[j].tile0 == sv[j - 1].tile0 + sv[j - 1].ntiles) ++j;
+      runs.push_back({i, j});
+      i = j;
+    }
+    if (!runs.empty() && runs.size() <= 8) {
+      used_sorted = true;
+      uint32_t cursor = t0;
+      for (const Run &r : runs) {
+        launch_lane_tiles(cursor, sv[r.a].tile0);
+        rt::launch(sorted_sweep_kernel<LEARN>, (unsigned)(r.b - r.a), SORT_THREADS, s->lds_sorted, s->stream, P,
+                   (const SuperTile *)(s->d_supers + r.a), (uint32_t)(r.b - r.a), (const SortRec8 *)s->d_sorted,
+                   (const double *)s->d_sort_dvals, s->n_sort_dvals);
+        ++launches;
+        cursor = sv[r.b - 1].tile0 + sv[r.b - 1].ntiles;
+      }
+      launch_lane_tiles(cursor, t1);
+    }
+  }
+  if (!used_sorted) launch_lane_tiles(t0, t1);
+  P.tile_begin = t0;
+  P.tile_end = t1;
   // categorical oversized variables: a workgroup each
   if (cg1 > cg0) {
     rt::launch(giant_kernel<LEARN>, cg1 - cg0, GIANT_THREADS, 0, st_giant, P,
@@ -1147,6 +1198,7 @@ int dwx_graph_get_info(const dwx_graph *g, dwx_graph_info *out) {
   out->max_cardinality = c.max_card; out->device_bytes = c.device_bytes();
   out->num_query_variables = c.n_query;
   out->has_categorical = c.has_categorical; out->order_is_identity = c.order_is_identity;
+  out->num_super_tiles = c.supers.size(); out->num_sorted_records = c.n_sorted;
   return DWX_OK;
 }
 
@@ -1155,6 +1207,18 @@ int dwx_graph_get_schedule(const dwx_graph *g, uint64_t *order, uint64_t *launch
   const CompiledGraph &c = *g->cg;
   for (uint64_t p = 0; p < c.Vo; ++p) order[p] = c.perm[p];
   std::copy(c.launch_off.begin(), c.launch_off.end(), launch_off);
+  return DWX_OK;
+}
+
+int dwx_graph_get_fixed_point_mask(const dwx_graph *g, uint8_t *mask) {
+  if (!g || !mask) return fail(DWX_E_INVALID, "null argument");
+  const CompiledGraph &c = *g->cg;
+  std::fill(mask, mask + c.V, (uint8_t)0);
+  if (c.edges8.size() == 0) return DWX_OK;      // compact records only (sweep8_kernel, sorted_sweep_kernel)
+  for (const TileDesc &t : c.tiles) {
+    if (t.flags & (TILE_OUTSIDE | TILE_CATEGORICAL)) continue;   // wave / workgroup bins, value rows: f64 sums
+    for (uint32_t l = 0; l < t.nv; ++l) mask[c.perm[t.v0 + l]] = 1;
+  }
   return DWX_OK;
 }
 
@@ -1250,6 +1314,16 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     s->d_edges = upload(c.edges, st, 1);
     s->rec8 = c.edges8.size() != 0;
     if (s->rec8) s->d_edges8 = upload(c.edges8, st, 1);
+    if (!c.supers.empty()) {
+      s->d_sorted = upload(c.sorted_recs, st, 1);
+      s->d_supers = upload(c.supers, st);
+      s->d_sort_dvals = upload(c.sort_dvals, st);
+      s->n_sort_dvals = (uint32_t)c.sort_dvals.size();
+      s->lds_sorted = (size_t)SUPER_NV_MAX * 8 + (size_t)s->n_sort_dvals * 8;
+      s->sorted_learn = c.W > LDS_AGG_MAX_W;     // == their tiles are TILE_PULL
+      rt::allow_dynamic_lds(sorted_sweep_kernel<false>, s->lds_sorted);
+      rt::allow_dynamic_lds(sorted_sweep_kernel<true>, s->lds_sorted);
+    }
     {
       // the batched walks load a factor's first entries branch-free (a unary record reads entry
       // 0 and ignores it): the array is never empty, entry 0 names a real variable

@@ -69,6 +69,28 @@ DWX_DEV double logadd(double a, double b) {
   return a + log1p(exp(nd));
 }
 
+// Potentials of the boolean variables of an all-unary graph (compact records) are summed in
+// FIXED POINT, 2^-32: pp - pn = sum over the row of fix(w * d), d = (sign(hit) - sign(miss)) * f
+// (an exact f64 product of two f32-exact factors).  Integer sums do not depend on the order of
+// the records, which is what lets the weight-sorted sweep (sorted_sweep_kernel) add a variable's
+// terms in the order of their WEIGHTS; every kernel that can meet such a variable uses the same
+// sum, and the oracle's schedule mode restates it (fixed-point mask), so parity stays exact.
+// (The reference's own sums are -Ofast doubles in row order: neither is "the" value.)
+// The conversion is the round-to-nearest of one f64 addition: exact for |p| < 2^19 (clamped;
+// a single term of half a million is far past where exp() saturates).
+constexpr double POT_FIX_SCALE = 4294967296.0;   // 2^32
+constexpr double POT_FIX_CLAMP = 524288.0;       // 2^19
+DWX_DEV long long pot_fix(double p) {
+  p = p < -POT_FIX_CLAMP ? -POT_FIX_CLAMP : (p > POT_FIX_CLAMP ? POT_FIX_CLAMP : p);
+  const double magic = 6755399441055744.0 / POT_FIX_SCALE;   // 1.5 * 2^52 * 2^-32
+  const double sh = p + magic;
+  long long a, b;
+  __builtin_memcpy(&a, &sh, 8);
+  __builtin_memcpy(&b, &magic, 8);
+  return a - b;
+}
+DWX_DEV double pot_unfix(long long q) { return (double)q * (1.0 / POT_FIX_SCALE); }
+
 DWX_DEV bool is_linear_zero(double x) {
   return x <= LINEAR_ZERO_THRESHOLD && x >= -LINEAR_ZERO_THRESHOLD;
 }

@@ -45,7 +45,7 @@ uint64_t CompiledGraph::device_bytes() const {
   uint64_t b = 0;
   b += 4 * (V * 4 + 1);                       // v_meta, v_orig, v_init, v_row
   b += 4 * (R + 1) + (row_truth.empty() ? 0 : 8 * R);
-  b += 16 * NIdx + 8 * edges8.size() + (edge_fval64.empty() ? 0 : 8 * NIdx) + 8 * NVif;
+  b += 16 * NIdx + 8 * edges8.size() + 8 * n_sorted + 32 * supers.size() + (edge_fval64.empty() ? 0 : 8 * NIdx) + 8 * NVif;
   b += 32 * tiles.size();
   b += 4 * V * 2 + 4 * R;                     // assignments x2, tallies
   b += W * (8 + 4 + 1 + 16 + 8);              // weights f64 + f32 copy, fixed, grad G/T, T static
@@ -683,6 +683,111 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
         });
       }
     }
+    // Weight-sorted super-tiles over the boolean lane-bin tiles of a compact-record graph.
+    g.sorted_recs.clear(); g.supers.clear(); g.sort_dvals.clear(); g.n_sorted = 0;
+    {
+      uint64_t min_w = 4096;   // (a smaller table sits in the CU's L1: the plain stream gathers as fast)
+      if (const char *e = getenv("DWX_SORTED_MIN_W")) min_w = (uint64_t)std::max(0L, atol(e));   // test hook
+      uint32_t per_super = o.super_tiles ? o.super_tiles : SUPER_TILES_DEFAULT;
+      auto eligible = [&](uint32_t i) {
+        const uint32_t f = g.tiles[i].flags;
+        return (f & TILE_SIMPLE) && !(f & (TILE_CATEGORICAL | TILE_OUTSIDE));
+      };
+      if (g.edges8.size() && W >= min_w && !o.no_sorted_records) {
+        // (1) super-tiles: runs of eligible tiles, cut at launch ends and at the end of a launch's query tiles
+        for (uint64_t l = 0; l < nl; ++l) {
+          uint32_t run0 = 0, nv = 0;
+          bool open = false;
+          auto close = [&](uint32_t end) {
+            if (open) {
+              SuperTile st{};
+              st.tile0 = run0; st.ntiles = end - run0; st.v0 = g.tiles[run0].v0; st.nv = nv;
+              g.supers.push_back(st);
+            }
+            open = false; nv = 0;
+          };
+          for (uint32_t i = g.launch_tile[l]; i < g.launch_tile[l + 1]; ++i) {
+            if (i == g.launch_query_tile_end[l]) close(i);
+            if (!eligible(i)) { close(i); continue; }
+            if (open && (i - run0 >= per_super || nv + g.tiles[i].nv > SUPER_NV_MAX)) close(i);
+            if (!open) { open = true; run0 = i; }
+            nv += g.tiles[i].nv;
+          }
+          close(g.launch_tile[l + 1]);
+        }
+        // (2) the distinct values of d = (sign(hit) - sign(miss)) * f (few: feature values repeat)
+        auto rec_d = [&](const EdgeRec8 &c) -> float {
+          const int sh = (int)((c.key >> REC8_HIT_SHIFT) & 3u) - 1, sm = (int)((c.key >> REC8_MISS_SHIFT) & 3u) - 1;
+          return (float)(sh - sm) * c.f;     // exact: a factor in {-2 .. 2}
+        };
+        const size_t ns = g.supers.size();
+        const uint32_t T = (uint32_t)std::max<size_t>(1, std::min<size_t>(nth, ns));
+        std::vector<std::vector<uint32_t>> local(T);
+        std::vector<uint64_t> count(ns + 1, 0);
+        parallel_parts(ns, T, [&](uint32_t t, uint64_t sb, uint64_t se) {
+          std::vector<uint32_t> &v = local[t];
+          uint32_t last = 0; bool have = false;
+          for (uint64_t si = sb; si < se; ++si) {
+            const SuperTile &st = g.supers[si];
+            const uint64_t e0 = g.tiles[st.tile0].e0, e1 = (uint64_t)g.tiles[st.tile0 + st.ntiles - 1].e0 + g.tiles[st.tile0 + st.ntiles - 1].nedges;
+            uint64_t n = 0;
+            for (uint64_t e = e0; e < e1; ++e) {
+              const float dv = rec_d(g.edges8[e]);
+              if (dv == 0.0f) continue;
+              ++n;
+              uint32_t bits; std::memcpy(&bits, &dv, 4);
+              if (have && bits == last) continue;
+              last = bits; have = true;
+              if (v.size() <= 4 * SORT_MAX_DVALS) v.push_back(bits);
+              if (v.size() % 1024 == 0) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+            }
+            count[si + 1] = n;
+          }
+          std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
+        }, 0);
+        std::vector<uint32_t> dbits;
+        for (auto &v : local) dbits.insert(dbits.end(), v.begin(), v.end());
+        std::sort(dbits.begin(), dbits.end()); dbits.erase(std::unique(dbits.begin(), dbits.end()), dbits.end());
+        if (dbits.size() + 1 > SORT_MAX_DVALS || ns == 0) {
+          g.supers.clear();
+        } else {
+          g.sort_dvals.push_back(0.0);
+          for (uint32_t b : dbits) { float f; std::memcpy(&f, &b, 4); g.sort_dvals.push_back((double)f); }
+          for (size_t i = 0; i < ns; ++i) count[i + 1] += count[i];
+          g.n_sorted = count[ns];
+          // (3) the records, super-tile by super-tile, sorted by (weight id, owner)
+          g.sorted_recs.reset(g.n_sorted + 1);
+          g.sorted_recs[g.n_sorted] = SortRec8{0u, 0u};
+          parallel_ranges(ns, nth, [&](uint64_t sb, uint64_t se) {
+            std::vector<uint64_t> keys;
+            for (uint64_t si = sb; si < se; ++si) {
+              SuperTile &st = g.supers[si];
+              keys.clear();
+              for (uint32_t ti = st.tile0; ti < st.tile0 + st.ntiles; ++ti) {
+                const TileDesc &td = g.tiles[ti];
+                for (uint32_t l = 0; l < td.nv; ++l) {
+                  const uint32_t p = td.v0 + l, slot = p - st.v0;
+                  for (uint32_t e = g.row_ptr[g.v_row[p]]; e < g.row_ptr[g.v_row[p + 1]]; ++e) {
+                    const EdgeRec8 &c = g.edges8[e];
+                    const float dv = rec_d(c);
+                    if (dv == 0.0f) continue;
+                    uint32_t bits; std::memcpy(&bits, &dv, 4);
+                    const uint32_t di = 1u + (uint32_t)(std::lower_bound(dbits.begin(), dbits.end(), bits) - dbits.begin());
+                    keys.push_back(((uint64_t)(c.key & REC8_WID_MASK) << 32) | (di << SORT_OWNER_BITS) | slot);
+                  }
+                }
+              }
+              std::sort(keys.begin(), keys.end());
+              const uint64_t at = count[si];
+              st.lo = (uint32_t)at; st.hi = (uint32_t)(at >> 32); st.nrec = (uint32_t)keys.size();
+              for (size_t i = 0; i < keys.size(); ++i)
+                g.sorted_recs[at + i] = SortRec8{(uint32_t)(keys[i] >> 32), (uint32_t)keys[i]};
+            }
+          }, 1);
+        }
+      }
+    }
+    phase("sorted records");
     g.giant_tiles.clear(); g.launch_giant.clear(); g.launch_giant_query_end.clear();
     g.wide_tiles.clear(); g.launch_wide.clear();
     for (uint64_t l = 0; l < nl; ++l) {

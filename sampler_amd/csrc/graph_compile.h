@@ -48,6 +48,12 @@ struct CompiledGraph {
   std::vector<double> row_truth;   // [R] or empty
   RawArray<EdgeRec> edges;         // [NIdx] (uninitialised storage: first touch inside the parallel fill)
   RawArray<EdgeRec8> edges8;       // [NIdx] when every tile is TILE_SIMPLE (and W < 2^27), else empty
+  // weight-sorted second copy of the boolean all-unary tiles' records (compact-record graphs
+  // with enough weights for the gathers to matter), super-tile by super-tile
+  RawArray<SortRec8> sorted_recs;   // [n_sorted] or empty
+  std::vector<SuperTile> supers;    // ascending tile0; a super-tile never crosses a launch or its query end
+  std::vector<double> sort_dvals;   // distinct (sign(hit) - sign(miss)) * f values, [0] = 0.0
+  uint64_t n_sorted = 0;
   std::vector<double> edge_fval64; // [NIdx] or empty
   std::vector<VifRec> vifs;        // [NVif]
   std::vector<uint32_t> tile_v;       // [n_tiles+1]

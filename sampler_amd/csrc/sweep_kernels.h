@@ -664,9 +664,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
       if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
-        delta = process_variable<LEARN, W_TERMS8, true>(P, T, d.v0 + t, pre, A, B, true);
-      else
-        process_variable<LEARN, LEARN ? W_ARRAY : (TAB ? W_TERMS8 : W_TERMS), true>(P, T, d.v0 + t, pre, A, B, false);
+        delta = process_variable<LEARN, W_TERMS8, true, true>(P, T, d.v0 + t, pre, A, B, true);
+      else   // (FIXED: boolean variables of a compact-record graph sum their potentials in fixed point)
+        process_variable<LEARN, LEARN ? W_ARRAY : (TAB ? W_TERMS8 : W_TERMS), true, true>(P, T, d.v0 + t, pre, A, B, false);
     }
     if (pull) {
       const unsigned long long nz = DWX_BALLOT(delta != 0), ng = DWX_BALLOT(delta < 0);
@@ -686,6 +686,105 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
     for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) {
       const long long v = s_agg[i];
       if (v) atomicAdd((unsigned long long *)&P.grad[i], (unsigned long long)v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weight-sorted super-tiles
+// What bounded sweep8_kernel on a graph with a million weights was one L2 request per record:
+// the weight gathers of a variable-major record stream are random.  Here ONE WORKGROUP takes a
+// super-tile -- up to 8192 consecutive boolean variables of an all-unary graph (32 tiles) -- and
+// streams the super-tile's records in the order of their WEIGHT IDS (the second, sorted copy of
+// graph_compile.cc): the 64 lanes of a wave-instruction gather ascending, neighbouring weights,
+// a fraction of a 128-byte line per lane instead of a line each (config 3: 82 k records over a
+// 4 MB table = 0.38 lines per record; tools/sorted_bench.hip: 0.32 ms per 10^8 records against
+// 0.59 ms for the same loop over unsorted records).  A record adds w * d, d = (sign(hit) -
+// sign(miss)) * f, to its owner's potential difference pp - pn in LDS -- a 64-bit fixed-point
+// atomic add (pot_fix: integer sums are order-independent, so the result does not depend on
+// the sorting and equals what sweep8_kernel's row walks compute; the oracle restates it).
+// Then the workgroup walks the super-tile's tiles, a lane per variable: the tiles' own
+// process_variable (W_FIXSUM: the potential is given) draws, stores, tallies, and -- learning --
+// publishes the wave ballots of the pull gradient exactly where sweep8_kernel puts them.
+// 64 KiB of sums + the table of distinct d values: two workgroups per CU, one streaming while
+// the other draws.  Replaces, for these variables, FactorGraph::potential's loop
+// (src/factor_graph.h:127-145) and draw_sample (src/gibbs_sampler.h:198-215).
+constexpr uint32_t SORT_THREADS = 512;
+constexpr int SORT_K = 8;      // records in flight per lane
+#ifndef DWX_LOAD_SORTED_RECORDS
+template <int K>
+DWX_DEV void load_sorted_records(const SortRec8 *base, uint32_t nrec, uint32_t first, uint32_t t, SortRec8 (&rec)[K]) {
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(nrec * sizeof(SortRec8)), 0x00020000);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const dwx_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(
+        rsrc, (int)(t * sizeof(SortRec8)), (int)((first + k * SORT_THREADS) * sizeof(SortRec8)), /*nt*/ 2);
+    rec[k].wid = v.x; rec[k].od = v.y;
+  }
+}
+#define DWX_LOAD_SORTED_RECORDS(K, base, nrec, first, t, rec) load_sorted_records<K>(base, nrec, first, t, rec)
+#endif
+
+template <bool LEARN>
+__global__ void __launch_bounds__(SORT_THREADS, 2)
+sorted_sweep_kernel(const KernelParams P, const SuperTile *supers, uint32_t n_supers, const SortRec8 *recs,
+                    const double *dvals, uint32_t n_dvals) {
+  DWX_DYN_LDS(dyn_lds);
+  unsigned long long *s_acc = (unsigned long long *)dyn_lds;            // [SUPER_NV_MAX]
+  double *s_d = (double *)(dyn_lds + SUPER_NV_MAX * sizeof(long long));   // [n_dvals]
+  const uint32_t t = threadIdx.x;
+  if (blockIdx.x >= n_supers) return;
+  SuperTile S = supers[blockIdx.x];
+  S.tile0 = DWX_UNIFORM(S.tile0); S.ntiles = DWX_UNIFORM(S.ntiles); S.v0 = DWX_UNIFORM(S.v0); S.nv = DWX_UNIFORM(S.nv);
+  S.lo = DWX_UNIFORM(S.lo); S.hi = DWX_UNIFORM(S.hi); S.nrec = DWX_UNIFORM(S.nrec);
+  const SortRec8 *base = recs + (((uint64_t)S.hi << 32) | S.lo);
+  SortRec8 rec[SORT_K];
+  DWX_LOAD_SORTED_RECORDS(SORT_K, base, S.nrec, 0u, t, rec);
+  for (uint32_t i = t; i < n_dvals; i += SORT_THREADS) s_d[i] = dvals[i];
+  for (uint32_t i = t; i < S.nv; i += SORT_THREADS) s_acc[i] = 0ull;
+  __syncthreads();
+  constexpr uint32_t STEP = SORT_K * SORT_THREADS;
+  for (uint32_t first = 0; first < S.nrec; first += STEP) {
+    float w[SORT_K];
+#pragma unroll
+    for (int k = 0; k < SORT_K; ++k) w[k] = P.w32[rec[k].wid];
+    SortRec8 cur[SORT_K];
+#pragma unroll
+    for (int k = 0; k < SORT_K; ++k) cur[k] = rec[k];
+    // (the next step's records under this step's gathers; past the end the descriptor zero-fills)
+    DWX_LOAD_SORTED_RECORDS(SORT_K, base, S.nrec, first + STEP, t, rec);
+#pragma unroll
+    for (int k = 0; k < SORT_K; ++k) {
+      const uint32_t di = cur[k].od >> SORT_OWNER_BITS;     // 0: a lane past the end
+      const long long q = pot_fix((double)w[k] * s_d[di]);
+      if (di) atomicAdd(&s_acc[cur[k].od & SORT_OWNER_MASK], (unsigned long long)q);
+    }
+  }
+  __syncthreads();
+  // the draws: BLOCK_THREADS lanes per tile, SORT_THREADS / BLOCK_THREADS tiles at a time
+  constexpr uint32_t TPB = SORT_THREADS / BLOCK_THREADS;
+  const uint32_t lane = t & (BLOCK_THREADS - 1), sub = t / BLOCK_THREADS;
+  for (uint32_t j0 = 0; j0 < S.ntiles; j0 += TPB) {
+    const bool have = j0 + sub < S.ntiles;
+    const uint32_t tile = S.tile0 + (have ? j0 + sub : 0u);
+    const uint32_t tv0 = DWX_UNIFORM(P.tiles[tile].v0), tnv = DWX_UNIFORM(P.tiles[tile].nv);
+    int delta = 0;
+    if (have && lane < tnv) {
+      const uint32_t p = tv0 + lane;
+      const VarPre pre = load_var_pre<LEARN>(P, p);
+      double A, B;
+      philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
+      const double x = pot_unfix((long long)s_acc[p - S.v0]);
+      TileView T{nullptr, 0u, nullptr, 0u, nullptr, nullptr, nullptr};
+      T.presum = &x;
+      delta = process_variable<LEARN, W_FIXSUM, true>(P, T, p, pre, A, B, true);
+    }
+    if (LEARN) {
+      const unsigned long long nz = DWX_BALLOT(delta != 0), ng = DWX_BALLOT(delta < 0);
+      if (have && (t & 63u) == 0) {
+        unsigned long long *wd = P.delta + ((size_t)tile * 4 + (lane >> 6)) * 2;
+        DWX_NT_STORE(nz, &wd[0]); DWX_NT_STORE(ng, &wd[1]);
+      }
     }
   }
 }

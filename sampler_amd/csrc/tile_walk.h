@@ -32,7 +32,7 @@ namespace dwx {
 //              (TileView::presum); one lane decides, the gradient rows are walked elsewhere
 //   W_LREC     (learning, categorical TILE_TERMS3 tiles) the staged records are LearnRecs: weight and
 //              the four products per record come out of LDS, for the draws and the gradient alike
-enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4, W_COOP = 5, W_COOPB = 6, W_PRESUM = 7, W_LREC = 8 };
+enum { W_GLOBAL = 0, W_ARRAY = 1, W_INRECORD = 2, W_TERMS = 3, W_TERMS8 = 4, W_COOP = 5, W_COOPB = 6, W_PRESUM = 7, W_LREC = 8, W_FIXSUM = 9 };
 #ifndef DWX_GIANT_PIECE
 #define DWX_GIANT_PIECE 4096   // (one batched step of 4 records per lane: half the latency of 8192, hub graph learning 16.8 -> 13.5 ms)
 #endif
@@ -376,14 +376,53 @@ DWX_DEV double row_potential(const KernelParams &P, const TileView &T, uint32_t 
 
 // boolean variable: both proposals in one pass over the row (same sums, same order
 // as two calls of FactorGraph::potential, src/gibbs_sampler.h:201-202)
-template <int WMODE, bool SIMPLE>
+// FIXED (all-unary graphs, compact records): pp - pn as ONE fixed-point sum of the records'
+// t1 - t0 (pot_fix, factor_functions.h); returned as pp = that sum, pn = 0.
+template <int WMODE, bool SIMPLE, bool FIXED = false>
 DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t row,
                              const uint32_t *assign, uint32_t me, double &pp, double &pn) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   pp = 0.0; pn = 0.0;
+  static_assert(!FIXED || (SIMPLE && (WMODE == W_TERMS8 || WMODE == W_TERMS || WMODE == W_ARRAY)),
+                "fixed-point potentials: staged all-unary tiles only");
+  if (FIXED) {
+    long long acc = 0;
+    if (WMODE == W_TERMS8) {
+      const unsigned long long *tab = (const unsigned long long *)T.edges;
+      for (uint32_t e = es; e < ee; e += WALK_BATCH) {
+        unsigned long long u[WALK_BATCH];
+#pragma unroll
+        for (uint32_t k = 0; k < WALK_BATCH; ++k) u[k] = tab[umin(e + k, ee - 1) - T.edge_bias];
+#pragma unroll
+        for (uint32_t k = 0; k < WALK_BATCH; ++k)
+          acc += (e + k < ee) ? pot_fix(terms8_hit(u[k]) - terms8_miss(u[k])) : 0ll;
+      }
+    } else if (WMODE == W_TERMS) {
+      const EdgeTerms *terms = (const EdgeTerms *)T.edges;
+      for (uint32_t e = es; e < ee; e += WALK_BATCH) {
+        EdgeTerms tt[WALK_BATCH];
+#pragma unroll
+        for (uint32_t u = 0; u < WALK_BATCH; ++u) tt[u] = terms[umin(e + u, ee - 1) - T.edge_bias];
+#pragma unroll
+        for (uint32_t u = 0; u < WALK_BATCH; ++u) acc += (e + u < ee) ? pot_fix(tt[u].t1 - tt[u].t0) : 0ll;
+      }
+    } else {
+      for (uint32_t e = es; e < ee; ++e) {
+        const EdgeRec er = T.edges[e - T.edge_bias];
+        const double w = edge_weight<WMODE>(P, T, er, e);
+        acc += pot_fix(w * (double)er.fval - w * (double)bits_to_float(er.aux));
+      }
+    }
+    pp = pot_unfix(acc);
+    return;
+  }
   if (WMODE == W_PRESUM) {   // (inference: the evidence chain's sums; learning, free chain only: the free chain's)
     const bool evid = assign == P.assign_evid;
     pp = T.presum[evid ? 2 : 0]; pn = T.presum[evid ? 3 : 1];
+    return;
+  }
+  if (WMODE == W_FIXSUM) {   // sorted_sweep_kernel: pp - pn, summed in fixed point over the weight-sorted records
+    pp = T.presum[0];
     return;
   }
   if (Coop<WMODE>::on) {
@@ -697,6 +736,7 @@ DWX_DEV void sgd_row(const KernelParams &P, const TileView &T, uint32_t row, uin
                      uint32_t evid_value, uint32_t free_value, uint32_t hit_value, double t,
                      const bool count_t) {
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
+  if (WMODE == W_FIXSUM) return;   // (never reached: those tiles take the pull gradient)
   if (WMODE == W_PRESUM) {   // boolean only (hit_value 1, t 1): the pieces' workgroups walk the row
     T.decision[0] = evid_value; T.decision[1] = free_value; T.decision[2] = 1u | (count_t ? 2u : 0u);
     return;
@@ -784,7 +824,7 @@ DWX_DEV VarPre load_var_pre(const KernelParams &P, uint32_t p) {
 
 // want_delta (learning, TILE_PULL tiles only): instead of scattering gradient atomics,
 // return hit(free) - hit(evid) in {-1,0,+1} for a variable that triggers SGD (0 otherwise).
-template <bool LEARN, int WMODE, bool SIMPLE>
+template <bool LEARN, int WMODE, bool SIMPLE, bool FIXED = false>
 DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t p,
                              const VarPre pre, double A, double B, const bool want_delta = false) {
   const uint32_t meta = pre.meta;
@@ -803,7 +843,7 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
     uint32_t prop;
     if (!is_cat) {
       double pp, pn;
-      bool_potentials<WMODE, SIMPLE>(P, T, row0, P.assign_evid, p, pp, pn);
+      bool_potentials<WMODE, SIMPLE, FIXED>(P, T, row0, P.assign_evid, p, pp, pn);
       prop = bool_draw(A, pp, pn);
       // single owner per row: a no-return atomic is a fire-and-forget increment the
       // wave never waits for (a load-add-store would stall on the load)
@@ -827,7 +867,7 @@ DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t 
   double pp_e = 0.0, pn_e = 0.0;
   if (!is_cat) {
     if (both) bool_potentials_both<WMODE>(P, T, row0, p, pp_f, pn_f, pp_e, pn_e);
-    else bool_potentials<WMODE, SIMPLE>(P, T, row0, P.assign_free, p, pp_f, pn_f);
+    else bool_potentials<WMODE, SIMPLE, FIXED>(P, T, row0, P.assign_free, p, pp_f, pn_f);
     p_free = bool_draw(A, pp_f, pn_f);
   } else {
     p_free = cat_draw<WMODE, SIMPLE>(P, T, row0, card, P.assign_free, p, A);

@@ -23,7 +23,7 @@ BUF_WEIGHTS, BUF_GRAD, BUF_ASSIGN_FREE, BUF_ASSIGN_EVID, BUF_TALLIES, BUF_TSTATI
 SYMBOLS = [
     "dwx_last_error", "dwx_version", "dwx_default_options",
     "dwx_graph_create", "dwx_graph_destroy", "dwx_graph_get_info", "dwx_graph_get_schedule",
-    "dwx_graph_get_values", "dwx_graph_get_positions", "dwx_graph_get_index",
+    "dwx_graph_get_values", "dwx_graph_get_fixed_point_mask", "dwx_graph_get_positions", "dwx_graph_get_index",
     "dwx_sampler_create", "dwx_device_init", "dwx_device_count", "dwx_buffer_copy", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
     "dwx_wait", "dwx_sgd_plan", "dwx_sgd_curvature", "dwx_sgd_plan_rows", "dwx_sgd_plan_force_dynamic", "dwx_sgd_get_chunks", "dwx_sgd_accumulate_async",
     "dwx_sgd_apply_async", "dwx_sgd_finish",
@@ -47,7 +47,8 @@ class CompileOpts(C.Structure):
                 ("conflict_arity_cap", C.c_uint32), ("n_threads", C.c_uint32),
                 ("no_compact_records", C.c_uint32), ("no_weight_order", C.c_uint32),
                 ("wide_min_records", C.c_uint32), ("no_record_vifs", C.c_uint32),
-                ("no_pull_unary", C.c_uint32)]
+                ("no_pull_unary", C.c_uint32), ("no_sorted_records", C.c_uint32),
+                ("super_tiles", C.c_uint32)]
 
 
 class GraphInfo(C.Structure):
@@ -56,7 +57,7 @@ class GraphInfo(C.Structure):
         "num_index_entries", "num_vif_entries", "num_colors", "num_launches", "num_tiles",
         "num_giant_tiles", "max_cardinality", "num_query_variables", "device_bytes")] + [
         ("has_categorical", C.c_uint32), ("order_is_identity", C.c_uint32), ("num_wide_tiles", C.c_uint64),
-        ("num_staged_tiles", C.c_uint64)]
+        ("num_staged_tiles", C.c_uint64), ("num_super_tiles", C.c_uint64), ("num_sorted_records", C.c_uint64)]
 
 
 class Options(C.Structure):
@@ -89,6 +90,7 @@ class Library:
         L.dwx_graph_get_values.argtypes = [vp, vp, vp]
         L.dwx_graph_get_index.argtypes = [vp, vp, vp, vp]
         L.dwx_graph_get_positions.argtypes = [vp, vp, u64, vp]
+        L.dwx_graph_get_fixed_point_mask.argtypes = [vp, vp]
         L.dwx_sampler_create.argtypes = [vp, vp, vp]
         L.dwx_device_init.argtypes = [C.c_int32]
         L.dwx_device_count.argtypes = [vp]
@@ -178,6 +180,13 @@ class Graph:
         off = np.zeros(self.info.num_launches + 1, np.uint64)
         self.lib.check(self.lib.L.dwx_graph_get_schedule(self.h, order.ctypes.data, off.ctypes.data))
         return order, off
+
+    def fixed_point_mask(self):
+        """uint8[V]: 1 where the device sums a variable's potentials in fixed point (test hook:
+        orc.Oracle.set_fixed_point_mask)."""
+        m = np.zeros(self.info.num_variables, np.uint8)
+        self.lib.check(self.lib.L.dwx_graph_get_fixed_point_mask(self.h, m.ctypes.data))
+        return m
 
     def positions(self, vids):
         vids = np.ascontiguousarray(vids, np.uint64)

@@ -60,6 +60,7 @@ def main():
     t, n = s.tallies()
     np.savez(os.path.join(out, "rank%d.npz" % rank), weights=s.weights, tallies=t,
              free=s.assignments("free"), evid=s.assignments("evid"), begin=begin, order=order,
+             fixed_mask=g.fixed_point_mask(),
              batches=np.array([r[0] for r in eng.record]), eta=np.array([r[1] for r in eng.record]),
              **{"chunks%d" % i: r[2] for i, r in enumerate(eng.record)})
     dist.barrier()

@@ -104,5 +104,14 @@ inline void emu_load_tile_records8(const dwx::EdgeRec8 *base, uint32_t nedges, u
   }
 }
 #define DWX_LOAD_TILE_RECORDS8(K, base, nedges, t, rec) emu_load_tile_records8<K>(base, nedges, t, rec)
+template <int K>
+inline void emu_load_sorted_records(const dwx::SortRec8 *base, uint32_t nrec, uint32_t first, uint32_t t,
+                                    dwx::SortRec8 (&rec)[K]) {
+  for (int k = 0; k < K; ++k) {
+    const uint64_t i = (uint64_t)first + t + (uint64_t)k * 512u;   // SORT_THREADS
+    rec[k] = i < nrec ? base[i] : dwx::SortRec8{0u, 0u};
+  }
+}
+#define DWX_LOAD_SORTED_RECORDS(K, base, nrec, first, t, rec) emu_load_sorted_records<K>(base, nrec, first, t, rec)
 
 #endif

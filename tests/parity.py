@@ -68,6 +68,7 @@ def run_parity(lib, raw, n_learn=3, n_infer=5, stepsize=0.05, decay=0.9, seed=77
               noise_aware=noise_aware, regularization=regularization, reg_param=reg_param)
     g = dwx.Graph(raw, lib=lib, **(compile_opts or {}))
     o = orc.Oracle(raw, **kw)
+    o.set_fixed_point_mask(g.fixed_point_mask())   # (boolean variables of compact-record graphs)
     if check_index:
         check_index_parity(g, o)
     order, off = g.schedule()

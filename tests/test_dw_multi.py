@@ -235,6 +235,9 @@ def test_product_dw_cross_shard_graph_at_size_matches_single_gpu_statistically()
                             np.array([float(l.split()[2]) for l in m.splitlines()])))
     (w1, p1), (w2, p2) = res
     assert len(p1) == len(p2) > 90_000
-    assert abs(w1.mean() - w2.mean()) < 0.01 and np.corrcoef(w1, w2)[0, 1] > 0.8
+    # (2 000 weights x 1 000 factors after ten epochs at 0.01 are mostly SGD noise: two runs of the
+    # REFERENCE on this graph -- other thread counts -- correlate at 0.30 .. 0.35, sigma 0.10 per
+    # weight; this build's batched updates average more, so its two runs agree better than that)
+    assert abs(w1.mean() - w2.mean()) < 0.01 and np.corrcoef(w1, w2)[0, 1] > 0.5
     assert abs(p1.mean() - p2.mean()) < 0.005
     assert stats.ks_two_sample(p1, p2) > 0.001

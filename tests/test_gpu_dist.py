@@ -65,6 +65,7 @@ def test_two_ranks_share_one_gpu_over_gloo(stepsize, mixed):
     shards = [shard_graph(total, W, r, world, 1234, mixed=mixed)[0] for r in range(world)]
     union = _concat(shards)
     o = orc.Oracle(union, reg_param=0.01)
+    o.set_fixed_point_mask(np.concatenate([res[r]["fixed_mask"] for r in range(world)]))
     sweep = 0
     for k in range(6):
         n_chunks = max(len(res[r]["chunks%d" % k]) for r in range(world))

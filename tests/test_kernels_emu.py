@@ -489,6 +489,7 @@ def test_tabulated_inference_terms_follow_every_weight_change(lib):
                 random_graph(21, V=1200, F=6000, W=60, p_cat=0.3, max_arity=2, exact_fvals=True)):
         g = dwx.Graph(raw, lib=lib, tile_vars=64)
         s, o = dwx.GibbsSampler(g, seed=13), orc.Oracle(raw)
+        o.set_fixed_point_mask(g.fixed_point_mask())
         order, off = g.schedule()
         sweep = 0
 
