@@ -96,7 +96,9 @@ typedef struct dwx_compile_opts {
   uint32_t no_sorted_records;  /* 1: no weight-sorted second copy of the records of boolean all-unary
                                   tiles (default 0: compact-record graphs with >= 4096 weights get
                                   one, and their sweeps gather weights in sorted order)        */
-  uint32_t super_tiles;        /* tiles per weight-sorted super-tile (default 32 = 8192 variables) */
+  uint32_t super_tiles;        /* tiles per weight-sorted super-tile, at most (default 32 = 8192 variables) */
+  uint32_t sorted_slots;       /* workgroups of sorted_sweep_kernel resident at once (default 512: two per
+                                  CU of an MI355X); runs of tiles are cut into multiples of it          */
 } dwx_compile_opts;
 
 typedef struct dwx_graph_info {

@@ -83,6 +83,14 @@ static_assert(sizeof(SortRec8) == 8, "SortRec8 must be 8 bytes");
 constexpr uint32_t SORT_OWNER_BITS = 13, SORT_OWNER_MASK = (1u << SORT_OWNER_BITS) - 1;
 constexpr uint32_t SUPER_NV_MAX = 1u << SORT_OWNER_BITS;      // 8192 variables: 64 KiB of sums
 constexpr uint32_t SUPER_TILES_DEFAULT = 32;
+#ifndef DWX_SORT_THREADS
+#define DWX_SORT_THREADS 512
+#endif
+#ifndef DWX_SORT_K
+#define DWX_SORT_K 12
+#endif
+constexpr uint32_t SORT_THREADS = DWX_SORT_THREADS;   // sorted_sweep_kernel's workgroup
+constexpr int SORT_K = DWX_SORT_K;                    // ... and its records in flight per lane
 constexpr uint32_t SORT_MAX_DVALS = 1024;                     // distinct d values (8 KiB in LDS), else no sorted copy
 struct alignas(16) SuperTile {
   uint32_t tile0, ntiles;   // tiles [tile0, tile0 + ntiles)

@@ -1319,7 +1319,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       s->d_supers = upload(c.supers, st);
       s->d_sort_dvals = upload(c.sort_dvals, st);
       s->n_sort_dvals = (uint32_t)c.sort_dvals.size();
-      s->lds_sorted = (size_t)SUPER_NV_MAX * 8 + (size_t)s->n_sort_dvals * 8;
+      s->lds_sorted = (size_t)SUPER_NV_MAX * 8 + SORT_TV_SLOTS * 4 + (size_t)s->n_sort_dvals * 8;
       s->sorted_learn = c.W > LDS_AGG_MAX_W;     // == their tiles are TILE_PULL
       rt::allow_dynamic_lds(sorted_sweep_kernel<false>, s->lds_sorted);
       rt::allow_dynamic_lds(sorted_sweep_kernel<true>, s->lds_sorted);

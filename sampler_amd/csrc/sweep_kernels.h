@@ -708,8 +708,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
 // 64 KiB of sums + the table of distinct d values: two workgroups per CU, one streaming while
 // the other draws.  Replaces, for these variables, FactorGraph::potential's loop
 // (src/factor_graph.h:127-145) and draw_sample (src/gibbs_sampler.h:198-215).
-constexpr uint32_t SORT_THREADS = 512;
-constexpr int SORT_K = 8;      // records in flight per lane
+constexpr uint32_t SORT_TV_SLOTS = 64;   // tiles per super-tile + 1, padded (the default cuts at 32)
 #ifndef DWX_LOAD_SORTED_RECORDS
 template <int K>
 DWX_DEV void load_sorted_records(const SortRec8 *base, uint32_t nrec, uint32_t first, uint32_t t, SortRec8 (&rec)[K]) {
@@ -731,7 +730,8 @@ sorted_sweep_kernel(const KernelParams P, const SuperTile *supers, uint32_t n_su
                     const double *dvals, uint32_t n_dvals) {
   DWX_DYN_LDS(dyn_lds);
   unsigned long long *s_acc = (unsigned long long *)dyn_lds;            // [SUPER_NV_MAX]
-  double *s_d = (double *)(dyn_lds + SUPER_NV_MAX * sizeof(long long));   // [n_dvals]
+  uint32_t *s_tv = (uint32_t *)(dyn_lds + SUPER_NV_MAX * sizeof(long long));   // [SORT_TV_SLOTS] first variable of every tile (+ end)
+  double *s_d = (double *)(dyn_lds + SUPER_NV_MAX * sizeof(long long) + SORT_TV_SLOTS * sizeof(uint32_t));   // [n_dvals]
   const uint32_t t = threadIdx.x;
   if (blockIdx.x >= n_supers) return;
   SuperTile S = supers[blockIdx.x];
@@ -741,6 +741,8 @@ sorted_sweep_kernel(const KernelParams P, const SuperTile *supers, uint32_t n_su
   SortRec8 rec[SORT_K];
   DWX_LOAD_SORTED_RECORDS(SORT_K, base, S.nrec, 0u, t, rec);
   for (uint32_t i = t; i < n_dvals; i += SORT_THREADS) s_d[i] = dvals[i];
+  for (uint32_t i = t; i < S.ntiles; i += SORT_THREADS) s_tv[i] = P.tiles[S.tile0 + i].v0;
+  if (t == 0) s_tv[S.ntiles] = S.v0 + S.nv;
   for (uint32_t i = t; i < S.nv; i += SORT_THREADS) s_acc[i] = 0ull;
   __syncthreads();
   constexpr uint32_t STEP = SORT_K * SORT_THREADS;
@@ -760,29 +762,41 @@ sorted_sweep_kernel(const KernelParams P, const SuperTile *supers, uint32_t n_su
       if (di) atomicAdd(&s_acc[cur[k].od & SORT_OWNER_MASK], (unsigned long long)q);
     }
   }
-  __syncthreads();
-  // the draws: BLOCK_THREADS lanes per tile, SORT_THREADS / BLOCK_THREADS tiles at a time
+  // the draws: BLOCK_THREADS lanes per tile, SORT_THREADS / BLOCK_THREADS tiles at a time; the
+  // per-variable words of the next pass are in flight under the current one (branch-free loads,
+  // clamped inside the super-tile)
   constexpr uint32_t TPB = SORT_THREADS / BLOCK_THREADS;
   const uint32_t lane = t & (BLOCK_THREADS - 1), sub = t / BLOCK_THREADS;
+  struct Pass { bool have; uint32_t tile, p; bool live; VarPre pre; };
+  auto issue = [&](uint32_t j0) {
+    Pass ps;
+    ps.have = j0 + sub < S.ntiles;
+    const uint32_t j = ps.have ? j0 + sub : 0u;
+    const uint32_t tv0 = s_tv[j], tnv = s_tv[j + 1] - tv0;
+    ps.tile = S.tile0 + j;
+    ps.live = ps.have && lane < tnv;
+    ps.p = tv0 + (lane < tnv ? lane : tnv - 1u);
+    ps.pre = load_var_pre<LEARN>(P, ps.p);
+    return ps;
+  };
+  Pass nxt = issue(0u);
+  __syncthreads();     // every record's term is in its owner's sum
   for (uint32_t j0 = 0; j0 < S.ntiles; j0 += TPB) {
-    const bool have = j0 + sub < S.ntiles;
-    const uint32_t tile = S.tile0 + (have ? j0 + sub : 0u);
-    const uint32_t tv0 = DWX_UNIFORM(P.tiles[tile].v0), tnv = DWX_UNIFORM(P.tiles[tile].nv);
+    const Pass ps = nxt;
+    nxt = issue(j0 + TPB < S.ntiles ? j0 + TPB : j0);
     int delta = 0;
-    if (have && lane < tnv) {
-      const uint32_t p = tv0 + lane;
-      const VarPre pre = load_var_pre<LEARN>(P, p);
+    if (ps.live) {
       double A, B;
-      philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
-      const double x = pot_unfix((long long)s_acc[p - S.v0]);
+      philox_uniforms(P.seed, P.vid_offset + ps.pre.orig, P.sweep, A, B);
+      const double x = pot_unfix((long long)s_acc[ps.p - S.v0]);
       TileView T{nullptr, 0u, nullptr, 0u, nullptr, nullptr, nullptr};
       T.presum = &x;
-      delta = process_variable<LEARN, W_FIXSUM, true>(P, T, p, pre, A, B, true);
+      delta = process_variable<LEARN, W_FIXSUM, true>(P, T, ps.p, ps.pre, A, B, true);
     }
     if (LEARN) {
       const unsigned long long nz = DWX_BALLOT(delta != 0), ng = DWX_BALLOT(delta < 0);
-      if (have && (t & 63u) == 0) {
-        unsigned long long *wd = P.delta + ((size_t)tile * 4 + (lane >> 6)) * 2;
+      if (ps.have && (t & 63u) == 0) {
+        unsigned long long *wd = P.delta + ((size_t)ps.tile * 4 + (lane >> 6)) * 2;
         DWX_NT_STORE(nz, &wd[0]); DWX_NT_STORE(ng, &wd[1]);
       }
     }

@@ -108,7 +108,7 @@ template <int K>
 inline void emu_load_sorted_records(const dwx::SortRec8 *base, uint32_t nrec, uint32_t first, uint32_t t,
                                     dwx::SortRec8 (&rec)[K]) {
   for (int k = 0; k < K; ++k) {
-    const uint64_t i = (uint64_t)first + t + (uint64_t)k * 512u;   // SORT_THREADS
+    const uint64_t i = (uint64_t)first + t + (uint64_t)k * dwx::SORT_THREADS;
     rec[k] = i < nrec ? base[i] : dwx::SortRec8{0u, 0u};
   }
 }

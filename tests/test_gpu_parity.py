@@ -237,6 +237,12 @@ def test_all_unary_compact_records(lib, compact):
     E.test_all_unary_compact_records(lib, compact)
 
 
+@pytest.mark.parametrize("min_w", [0, 10 ** 9])
+def test_weight_sorted_super_tiles(lib, monkeypatch, min_w):
+    import test_kernels_emu as E
+    E.test_weight_sorted_super_tiles(lib, monkeypatch, min_w)
+
+
 @pytest.mark.parametrize("block_tiles, depth_hint", [(8, 1), (32, 2), (2048, 2)])
 def test_block_pull(lib, monkeypatch, block_tiles, depth_hint):
     import test_kernels_emu as E

@@ -83,6 +83,43 @@ def test_all_unary_compact_records(lib, compact):
                compile_opts=dict(no_compact_records=0 if compact else 1))
 
 
+@pytest.mark.parametrize("min_w", [0, 10 ** 9])
+def test_weight_sorted_super_tiles(lib, monkeypatch, min_w):
+    """sorted_sweep_kernel (boolean all-unary tiles of compact-record graphs; here forced onto
+    small graphs, and -- min_w = 10^9 -- switched off: the tile sweep must give the same state,
+    the potential sums are fixed point either way): every sign class and mixed feature values
+    (several distinct record deltas, records that add nothing), fixed weights, ragged tiles and
+    super-tiles cut at the query/evidence boundary, boolean next to categorical tiles, few
+    weights (learning falls back to the LDS accumulators), split sweeps (the sorted kernel serves
+    whole super-tiles inside a chunk, the tile sweep the rest), sample_evidence /
+    learn_non_evidence."""
+    from randgraph import random_graph
+    monkeypatch.setenv("DWX_SORTED_MIN_W", str(min_w))
+    want = (lambda s: s.graph.info.num_super_tiles > 0) if min_w == 0 else (lambda s: s.graph.info.num_super_tiles == 0)
+    for seed in (31, 32):
+        raw = random_graph(seed, V=700, F=5000, W=1500, max_arity=1, exact_fvals=True, with_domains=False)
+        raw.fac_feature_value[::13] = 0.0
+        s, _ = run_parity(lib, raw, n_learn=4, n_infer=4, stepsize=0.05, learn_non_evidence=seed == 32,
+                          compile_opts=dict(tile_vars=32, super_tiles=4))
+        assert want(s)
+        s, _ = run_parity(lib, raw, n_learn=3, n_infer=3, stepsize=0.05, sample_evidence=True,
+                          compile_opts=dict(tile_vars=9, tile_edges=48, tile_rows=12, super_tiles=5))
+        assert want(s)
+    s, _ = run_parity(lib, synthetic.cfg3(4000, n_weights=3000, seed=4), n_learn=3, n_infer=3)
+    assert want(s)
+    # few weights: inference sorted, learning through the tile sweep's LDS accumulators
+    s, _ = run_parity(lib, synthetic.cfg3(3000, n_weights=40, seed=5), n_learn=3, n_infer=3, compile_opts=dict(tile_vars=64))
+    assert want(s)
+    # a split sweep: chunks cut inside super-tiles
+    s, _ = run_parity(lib, synthetic.cfg3(6000, n_weights=1200, seed=6), n_learn=3, n_infer=2, stepsize=0.5,
+                      compile_opts=dict(tile_vars=32, super_tiles=6))
+    assert want(s) and s.sgd_plan(0.5)[0] > 1
+    # categorical rows stay with the tile sweep (config 4's shape beside boolean variables)
+    raw = random_graph(33, V=600, F=4000, W=1300, max_arity=1, exact_fvals=True, p_cat=0.4)
+    s, _ = run_parity(lib, raw, n_learn=3, n_infer=3, compile_opts=dict(tile_vars=32, super_tiles=3))
+    assert want(s)
+
+
 @pytest.mark.parametrize("block_tiles, depth_hint", [(8, 1), (32, 2), (1024, 2)])
 def test_block_pull(lib, monkeypatch, block_tiles, depth_hint):
     # pull_ell_kernel (un-split sweeps of graphs with many weights; here forced onto a small

@@ -11,6 +11,10 @@ out = sys.argv[1]
 
 
 def short(name):
+    if "sorted_sweep_kernel<true" in name or "sorted_sweep_kernelILb1" in name:
+        return "sorted_sweep_kernel<LEARN=true>"
+    if "sorted_sweep_kernel<false" in name or "sorted_sweep_kernelILb0" in name:
+        return "sorted_sweep_kernel<LEARN=false>"
     if "sweep8_kernel<true" in name or "sweep8_kernelILb1" in name:
         return "sweep8_kernel<LEARN=true>"
     if "sweep8_kernel<false" in name or "sweep8_kernelILb0" in name:
@@ -72,7 +76,7 @@ for pdir, store in (("pmc_FETCH_SIZE", fetch), ("pmc_WRITE_SIZE", write)):
             acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
         for k, v in acc.items():
             store[k] = sum(v) / len(v)
-traffic = {k: (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0 for k in fetch if k.startswith("sweep")}
+traffic = {k: (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0 for k in fetch if "sweep" in k}
 if traffic:
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1, sort_keys=True)
     print("== traffic.json (bytes per launch, 2*FETCH_SIZE + WRITE_SIZE)")
