@@ -62,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--vars-per-gpu", type=int, default=0,
                     help="override the per-GPU variable count (default 10M at 1 GPU, 12.5M else)")
     ap.add_argument("--cpu-sample-vars", type=int, default=1_000_000)
+    ap.add_argument("--cpu-small-only", action="store_true",
+                    help="CPU baseline on the bounded sample only (skip the run on the bench's own 10 M-variable graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-repeat-infer", action="store_true",
                     help="skip the untimed repeated-inference leg (profiling runs: keeps the kernel stats clean)")
@@ -125,48 +127,77 @@ def self_launch(args, argv):
 
 
 # --------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(n_vars, stepsize, decay, reg):
-    """Time the CPU side on a bounded sample of the same workload: the same generator at
-    n_vars variables, 3 learning + 10 inference epochs on all host cores.  Uses the real
-    reference binary (oracle/_ref/dw) when it travelled with the repo, else the oracle's
-    threaded restatement."""
+def _reference_epochs(raw, stepsize, decay, reg, n_learn, n_infer, timeout):
+    """The real reference binary (oracle/_ref/dw) on `raw`, all host cores: per-epoch times as
+    the reference prints them (src/dimmwitted.cc:150-154, 229-236) -> (learn[], infer[])."""
     from oracle import binding as orc
-    from sampler_amd import binary_format, synthetic
-    raw = synthetic.cfg3(n_vars, n_weights=max(1, n_vars // 10), seed=1234)
-    cores = os.cpu_count() or 1
-    sample = ("config-3 generator at V=%d (10 unary ISTRUE factors/var, W=V/10, 50%% evidence); "
-              "3 learning + 10 inference epochs, all host cores; value = 2V / (median learn "
-              "epoch + median inference epoch)" % n_vars)
-    extra = {"sample_is_smaller": True,
-             "note": "a smaller graph than the GPU's (its tables sit higher in the CPU's caches: "
-                     "conservative for the CPU); the GPU/CPU ratio is not like-for-like"}
-    if orc.have_reference():
-        with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
-            binary_format.write_graph(raw, d)
-            out = orc.run_reference_dw(d, ["-l", "3", "-i", "10", "--alpha", str(stepsize),
-                                           "--diminish", str(decay), "--reg_param", str(reg)],
-                                       d, quiet=False)
-        tl = [float(x) for x in re.findall(r"LEARNING EPOCH[^\n]*?\.\.\.\.([0-9.eE+-]+) sec\.", out)]
-        ti = [float(x) for x in re.findall(r"INFERENCE EPOCH[^\n]*?\.\.\.\.([0-9.eE+-]+) sec\.", out)]
-        if tl and ti:
-            t = statistics.median(tl) + statistics.median(ti)
-            return dict({"value": 2.0 * n_vars / t, "unit": "variables/s", "cores": cores,
-                         "kind": "reference", "sample": sample,
-                         "learn_vars_per_sec": n_vars / statistics.median(tl),
-                         "infer_vars_per_sec": n_vars / statistics.median(ti)}, **extra)
+    from sampler_amd import binary_format
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
+        binary_format.write_graph(raw, d)
+        out = orc.run_reference_dw(d, ["-l", str(n_learn), "-i", str(n_infer), "--alpha", str(stepsize),
+                                       "--diminish", str(decay), "--reg_param", str(reg)],
+                                   d, quiet=False, timeout=timeout)
+    tl = [float(x) for x in re.findall(r"LEARNING EPOCH[^\n]*?\.\.\.\.([0-9.eE+-]+) sec\.", out)]
+    ti = [float(x) for x in re.findall(r"INFERENCE EPOCH[^\n]*?\.\.\.\.([0-9.eE+-]+) sec\.", out)]
+    return tl, ti
+
+
+def _port_epochs(raw, stepsize, decay, reg, n_learn, n_infer):
+    """The oracle's threaded restatement of the reference (the fallback when the reference
+    binary did not travel with the repo)."""
+    from oracle import binding as orc
     o = orc.Oracle(raw, reg_param=reg)
-    o.set_workers(cores)
+    o.set_workers(os.cpu_count() or 1)
     tl, ti = [], []
     cur = stepsize
-    for _ in range(3):
+    for _ in range(n_learn):
         t0 = time.perf_counter(); o.sample_sgd(cur, threaded=True); tl.append(time.perf_counter() - t0)
         cur *= decay
-    for _ in range(10):
+    for _ in range(n_infer):
         t0 = time.perf_counter(); o.sample(threaded=True); ti.append(time.perf_counter() - t0)
+    return tl, ti
+
+
+def cpu_baseline(raw, stepsize, decay, reg, what, smaller, timeout=420):
+    """Time the CPU side on `raw` -- 3 learning + 10 inference epochs on all host cores, the
+    epoch loops the step of this bench stands for (src/dimmwitted.cc:143-154, 191-236) -- with the
+    real reference binary when it travelled with the repo, else the oracle's restatement.
+    value = 2V / (median learning epoch + median inference epoch): the bench's own metric."""
+    from oracle import binding as orc
+    n_vars = raw.num_variables
+    cores = os.cpu_count() or 1
+    sample = what + "; 3 learning + 10 inference epochs, all host cores; value = 2V / (median learn epoch + median inference epoch)"
+    extra = {"sample_is_smaller": bool(smaller)}
+    if smaller:
+        extra["note"] = ("a smaller graph than the GPU's (its tables sit higher in the CPU's caches: "
+                         "conservative for the CPU); the GPU/CPU ratio is not like-for-like")
+    kind = "reference" if orc.have_reference() else "port"
+    tl, ti = (_reference_epochs(raw, stepsize, decay, reg, 3, 10, timeout) if kind == "reference" else ([], []))
+    if not (tl and ti):
+        kind = "port"
+        tl, ti = _port_epochs(raw, stepsize, decay, reg, 3, 10)
     t = statistics.median(tl) + statistics.median(ti)
-    return dict({"value": 2.0 * n_vars / t, "unit": "variables/s", "cores": cores, "kind": "port",
+    return dict({"value": 2.0 * n_vars / t, "unit": "variables/s", "cores": cores, "kind": kind,
                  "sample": sample, "learn_vars_per_sec": n_vars / statistics.median(tl),
                  "infer_vars_per_sec": n_vars / statistics.median(ti)}, **extra)
+
+
+def sorted_ceiling():
+    """tools/sorted_bench --ceiling: the sorted sweep's own access shape -- a weight-sorted
+    8-byte record stream, the gathers of neighbouring weights out of a 4 MB table, a 64-bit LDS
+    atomic per record, a trivial draw per variable -- on one full round of 512 super-tiles of 8192
+    variables.  -> records per second, or None."""
+    exe = os.path.join(ROOT, "tools", "sorted_bench")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "--ceiling"], capture_output=True, text=True, timeout=180)
+        for line in r.stdout.splitlines():
+            if line.startswith('{"nv"'):
+                return float(json.loads(line)["records_per_s"])
+    except Exception as e:                  # the ceiling must never lose the measurement
+        log("bench.py: sorted_bench failed: %r" % (e,))
+    return None
 
 
 def gather_ceiling():
@@ -279,6 +310,8 @@ def main():
         log("setup: %s V/GPU=%d W=%d tiles=%d colours=%d ghosts=%d device_bytes=%.2f GB (%.1f s)"
             % (wl, V, W, graph.info.num_tiles, graph.info.num_colors, raw.num_ghost_variables,
                graph.info.device_bytes / 1e9, time.time() - t0))
+    # (kept for the like-for-like CPU baseline: the reference runs on this very graph)
+    raw_full = raw if (n_gpus == 1 and wl == "cfg3" and not args.no_cpu_baseline) else None
     del raw
     engine = HipEngine(sampler)
     halo = None
@@ -384,7 +417,9 @@ def main():
         B_INFER, B_LEARN = ALGO_BYTES[wl]
         if wl == "cfg3":
             # all-unary: the sweeps run sweep8_kernel (8-byte records) unless --wide-records
-            kern = "sweep_kernel" if args.wide_records else "sweep8_kernel"
+            # (8-byte records; weight-sorted super-tiles when the graph has them: sorted_sweep_kernel)
+            sorted_path = int(graph.info.num_super_tiles) > 0 and not args.wide_records
+            kern = "sweep_kernel" if args.wide_records else ("sorted_sweep_kernel" if sorted_path else "sweep8_kernel")
         else:
             kern = "sweep_kernel"
         # a sweep is one launch per colour: per-launch figures are per colour launch, the
@@ -417,7 +452,21 @@ def main():
         # weight table per record = one 128-byte L2 request each (tools/gather_bench: ~13.7
         # requests/clk/XCD whatever the occupancy).  Ceiling = the same stream + gather shape
         # with nothing else, measured on this box right now.
-        if wl == "cfg3":
+        if wl == "cfg3" and kern == "sorted_sweep_kernel":
+            # What bounds the sorted sweep: the CU's vector-memory path -- per 64 records one
+            # coalesced 512-byte stream request and one gather instruction over ~24 lines of the
+            # weight table (tools/sorted_bench: the same loop with a trivial draw phase).
+            recs = RECORDS_PER_VAR[wl] * units
+            peak = None if args.no_gather_ceiling else sorted_ceiling()
+            committed = 3.1e11      # profiles/r03/sorted_bench.jsonl: 8192 variables, 512 threads, 2 per CU
+            r_ach = recs / (per_sweep_ms * 1e-3)
+            roofline["secondary"] = {"bound": "cu_vector_memory", "what": "weight-sorted 8-byte record stream + "
+                                     "sorted 4-byte weight gathers (about 0.4 L2 requests per record) + one LDS atomic per record",
+                                     "achieved": r_ach / 1e9, "peak": (peak or committed) / 1e9,
+                                     "unit": "Grecord/s", "frac": r_ach / (peak or committed),
+                                     "peak_source": "tools/sorted_bench --ceiling, this run" if peak else
+                                     "profiles/r03/sorted_bench.jsonl (committed)"}
+        elif wl == "cfg3":
             gathers = RECORDS_PER_VAR[wl] * units
             peak = None if args.no_gather_ceiling else gather_ceiling()
             committed = 1.874e11    # profiles/r02/gather_bench.jsonl: stream mode, 4 MB, 3 waves/SIMD
@@ -481,11 +530,23 @@ def main():
             out["halo_ms_per_step"] = hl[0] / n_steps_timed
             out["halo_bytes_per_step"] = hl[2] / n_steps_timed
         if n_gpus == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_sample_vars, stepsize, decay, reg)
-            except Exception as e:  # the baseline must never lose the GPU measurement
-                out["cpu_baseline"] = {"value": None, "unit": "variables/s", "cores": os.cpu_count(),
-                                       "kind": "port", "sample": "failed: %r" % (e,)}
+            # the reference on the SAME graph the GPU number is quoted on (like for like), and on
+            # the bounded 1 M-variable sample of the same generator earlier rounds reported
+            for key, make, smaller in (
+                    ("cpu_baseline", lambda: (raw_full, "the bench's own config-3 graph: V=%d, W=%d" % (V, W)), False),
+                    ("cpu_baseline_small", lambda: (synthetic.cfg3(args.cpu_sample_vars, n_weights=max(1, args.cpu_sample_vars // 10), seed=1234),
+                                                    "config-3 generator at V=%d (W=V/10)" % args.cpu_sample_vars), True)):
+                if key == "cpu_baseline" and (raw_full is None or args.cpu_small_only):
+                    continue
+                try:
+                    g_, what = make()
+                    out[key] = cpu_baseline(g_, stepsize, decay, reg, what, smaller)
+                except Exception as e:  # the baseline must never lose the GPU measurement
+                    out[key] = {"value": None, "unit": "variables/s", "cores": os.cpu_count(),
+                                "kind": "port", "sample": "failed: %r" % (e,)}
+            raw_full = None
+            if "cpu_baseline" not in out:      # (no full-size run: the sample is the baseline)
+                out["cpu_baseline"] = out.pop("cpu_baseline_small")
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     sampler.close()
     if use_dist:

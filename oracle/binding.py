@@ -303,7 +303,7 @@ def philox_uniforms(seed, vid, sweep):
     return out[0], out[1]
 
 
-def run_reference_dw(graph_dir, args, out_dir, quiet=True):
+def run_reference_dw(graph_dir, args, out_dir, quiet=True, timeout=None):
     """Run the REAL reference binary (oracle/_ref/dw gibbs ...) on binary files."""
     p = lambda n: os.path.join(graph_dir, n)
     cmd = [REF_DW, "gibbs", "-m", p("graph.meta"), "-w", p("graph.weights"),
@@ -313,7 +313,7 @@ def run_reference_dw(graph_dir, args, out_dir, quiet=True):
     if quiet:
         cmd.append("--quiet")
     cmd += list(args)
-    return subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+    return subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=timeout).stdout
 
 
 def have_reference():

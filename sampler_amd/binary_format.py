@@ -122,12 +122,16 @@ def write_graph(g: RawGraph, d):
             a = int(arity[0])
             dt = np.dtype([("func", ">u2"), ("arity", ">u8"), ("pairs", ">u8", (a, 2)),
                            ("wid", ">u8"), ("val", ">f8")])
-            rec = np.zeros(F, dt)
-            rec["func"] = g.fac_func; rec["arity"] = a
-            rec["pairs"][:, :, 0] = g.edge_vid.reshape(F, a)
-            rec["pairs"][:, :, 1] = g.edge_equal_to.reshape(F, a)
-            rec["wid"] = g.fac_weight_id; rec["val"] = g.fac_feature_value
-            rec.tofile(f)
+            ev, eq = g.edge_vid.reshape(F, a), g.edge_equal_to.reshape(F, a)
+            step = 8_000_000          # (slices: the 10^8 factors of config 3 are 4.2 GB of records)
+            for lo in range(0, F, step):
+                hi = min(F, lo + step)
+                rec = np.zeros(hi - lo, dt)
+                rec["func"] = g.fac_func[lo:hi]; rec["arity"] = a
+                rec["pairs"][:, :, 0] = ev[lo:hi]
+                rec["pairs"][:, :, 1] = eq[lo:hi]
+                rec["wid"] = g.fac_weight_id[lo:hi]; rec["val"] = g.fac_feature_value[lo:hi]
+                rec.tofile(f)
         else:
             for i in range(F):
                 lo, hi = int(g.fac_edge_offset[i]), int(g.fac_edge_offset[i + 1])

@@ -239,5 +239,10 @@ def test_product_dw_cross_shard_graph_at_size_matches_single_gpu_statistically()
     # REFERENCE on this graph -- other thread counts -- correlate at 0.30 .. 0.35, sigma 0.10 per
     # weight; this build's batched updates average more, so its two runs agree better than that)
     assert abs(w1.mean() - w2.mean()) < 0.01 and np.corrcoef(w1, w2)[0, 1] > 0.5
-    assert abs(p1.mean() - p2.mean()) < 0.005
-    assert stats.ks_two_sample(p1, p2) > 0.001
+    # marginals computed with two noisy sets of learned weights: four runs of the REFERENCE on this
+    # graph (-t 2 / 3 / 5 / 8) differ pairwise by 0.001 .. 0.011 in the mean marginal and by
+    # D = 0.017 .. 0.063 in the two-sample KS distance of the marginals; one rank against two ranks
+    # of this build must not be further apart than the reference is from itself
+    from scipy.stats import ks_2samp
+    assert abs(p1.mean() - p2.mean()) < 0.012
+    assert ks_2samp(p1, p2).statistic < 0.065

@@ -8,8 +8,9 @@
 //
 // Not product code: a calibration tool (run by hand; results in profiles/r03/sorted_bench.jsonl).
 //
-//   sorted_bench [--records N] [--weights W]
-// one JSON line per (NV, threads, workgroups per CU, sorted?, atomics?)
+//   sorted_bench [--records N] [--weights W] [--ceiling]
+// one JSON line per (NV, threads, workgroups per CU, sorted?, atomics?); --ceiling: only the
+// product kernel's shape, on one full round of 512 super-tiles (bench.py: roofline.secondary)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -88,9 +89,11 @@ struct Cfg { uint32_t nv; int threads, wg_per_cu; bool sorted, atomics; };
 int main(int argc, char **argv) {
   uint64_t nrec = 100ull * 1000 * 1000;
   uint32_t W = 1u << 20;
-  for (int i = 1; i + 1 < argc; ++i) {
-    if (!strcmp(argv[i], "--records")) nrec = strtoull(argv[i + 1], nullptr, 10);
-    if (!strcmp(argv[i], "--weights")) W = (uint32_t)strtoul(argv[i + 1], nullptr, 10);
+  bool ceiling_only = false;    // one line: the product kernel's shape (8192 variables, 512 threads, 2 per CU)
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--ceiling")) { ceiling_only = true; nrec = 42ull * 1000 * 1000; }
+    if (i + 1 < argc && !strcmp(argv[i], "--records")) nrec = strtoull(argv[i + 1], nullptr, 10);
+    if (i + 1 < argc && !strcmp(argv[i], "--weights")) W = (uint32_t)strtoul(argv[i + 1], nullptr, 10);
   }
   int dev = 0, cus = 0;
   CK(hipGetDevice(&dev));
@@ -116,6 +119,7 @@ int main(int argc, char **argv) {
   };
   std::vector<u32x2> h(nrec);
   for (const Cfg &c : cfgs) {
+    if (ceiling_only && !(c.nv == 8192 && c.threads == 512 && c.sorted && c.atomics)) continue;
     const uint32_t per = c.nv * PER_VAR;
     const uint32_t n_super = (uint32_t)(nrec / per);
     // super-tile contents: random weight ids (sorted or not), owners = a random permutation of the
