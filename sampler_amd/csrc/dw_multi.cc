@@ -3,8 +3,10 @@
 #include "dw_multi.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -136,25 +138,46 @@ void make_shard(const LoadedGraph &w, uint64_t begin, uint64_t end, ShardGraph &
   const uint32_t nth = dwx::host_threads();
   const uint64_t F = w.n_factors, n_owned = end - begin;
   auto owned = [&](uint64_t v) { return v >= begin && v < end; };
-  // factors that touch an owned variable; their edges
-  std::vector<uint8_t> keep(F, 0);
-  dwx::parallel_ranges(F, nth, [&](uint64_t fb, uint64_t fe) {
-    for (uint64_t f = fb; f < fe; ++f)
-      for (uint64_t e = w.fac_edge_offset[f]; e < w.fac_edge_offset[f + 1]; ++e)
-        if (owned(w.edge_vid[e])) { keep[f] = 1; break; }
-  });
-  std::vector<uint64_t> new_f(F + 1, 0), new_e(F + 1, 0);
-  for (uint64_t f = 0; f < F; ++f) {
-    new_f[f + 1] = new_f[f] + keep[f];
-    new_e[f + 1] = new_e[f] + (keep[f] ? w.fac_edge_offset[f + 1] - w.fac_edge_offset[f] : 0);
-  }
-  const uint64_t nf = new_f[F], ne = new_e[F];
+  // Two passes over the factor list in blocks of 64 k factors, both parallel, with nothing of
+  // the size of the list kept in between (eight rank threads cut their shards side by side: at
+  // config 5's 10^9 factors three F-sized arrays each were 136 GB, and the prefix sums between
+  // the passes were serial): pass 1 counts the factors that touch an owned variable and their
+  // edges per block and collects the ghosts, pass 2 (below) re-tests and copies.
+  auto keeps = [&](uint64_t f) {
+    for (uint64_t e = w.fac_edge_offset[f]; e < w.fac_edge_offset[f + 1]; ++e)
+      if (owned(w.edge_vid[e])) return true;
+    return false;
+  };
+  const uint64_t BLK = 1u << 16, nblk = (F + BLK - 1) / BLK;
+  std::vector<uint64_t> blk_f(nblk + 1, 0), blk_e(nblk + 1, 0);
+  const uint32_t T = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nth, nblk));
+  std::vector<std::vector<uint64_t>> gh_part(T);
+  dwx::parallel_parts(nblk, T, [&](uint32_t t, uint64_t bb, uint64_t be) {
+    std::vector<uint64_t> &gp = gh_part[t];
+    size_t sorted_upto = 0;
+    for (uint64_t b = bb; b < be; ++b) {
+      uint64_t nfk = 0, nek = 0;
+      for (uint64_t f = b * BLK; f < std::min(F, (b + 1) * BLK); ++f) {
+        if (!keeps(f)) continue;
+        ++nfk; nek += w.fac_edge_offset[f + 1] - w.fac_edge_offset[f];
+        for (uint64_t e = w.fac_edge_offset[f]; e < w.fac_edge_offset[f + 1]; ++e)
+          if (!owned(w.edge_vid[e])) gp.push_back(w.edge_vid[e]);
+      }
+      blk_f[b + 1] = nfk; blk_e[b + 1] = nek;
+      if (gp.size() - sorted_upto > (1u << 20)) {    // (a ghost is named by every factor that reads it)
+        std::sort(gp.begin(), gp.end());
+        gp.erase(std::unique(gp.begin(), gp.end()), gp.end());
+        sorted_upto = gp.size();
+      }
+    }
+    std::sort(gp.begin(), gp.end());
+    gp.erase(std::unique(gp.begin(), gp.end()), gp.end());
+  }, 2);
+  for (uint64_t b = 0; b < nblk; ++b) { blk_f[b + 1] += blk_f[b]; blk_e[b + 1] += blk_e[b]; }
+  const uint64_t nf = blk_f[nblk], ne = blk_e[nblk];
   // ghosts: remote endpoints of kept factors, ascending
   std::vector<uint64_t> gh;
-  for (uint64_t f = 0; f < F; ++f)
-    if (keep[f])
-      for (uint64_t e = w.fac_edge_offset[f]; e < w.fac_edge_offset[f + 1]; ++e)
-        if (!owned(w.edge_vid[e])) gh.push_back(w.edge_vid[e]);
+  for (auto &gp : gh_part) { gh.insert(gh.end(), gp.begin(), gp.end()); std::vector<uint64_t>().swap(gp); }
   std::sort(gh.begin(), gh.end());
   gh.erase(std::unique(gh.begin(), gh.end()), gh.end());
   out.ghosts = gh;
@@ -189,21 +212,23 @@ void make_shard(const LoadedGraph &w, uint64_t begin, uint64_t end, ShardGraph &
   }
   g.fac_func.reset(nf); g.fac_edge_offset.reset(nf + 1); g.fac_weight_id.reset(nf); g.fac_feature_value.reset(nf);
   g.edge_vid.reset(ne); g.edge_equal_to.reset(ne);
-  dwx::parallel_ranges(F, nth, [&](uint64_t fb, uint64_t fe) {
-    for (uint64_t f = fb; f < fe; ++f) {
-      if (!keep[f]) continue;
-      const uint64_t nfid = new_f[f];
-      uint64_t o = new_e[f];
-      g.fac_func[nfid] = w.fac_func[f];
-      g.fac_edge_offset[nfid] = o;
-      g.fac_weight_id[nfid] = w.fac_weight_id[f];
-      g.fac_feature_value[nfid] = w.fac_feature_value[f];
-      for (uint64_t e = w.fac_edge_offset[f]; e < w.fac_edge_offset[f + 1]; ++e, ++o) {
-        g.edge_vid[o] = local_id(w.edge_vid[e]);
-        g.edge_equal_to[o] = w.edge_equal_to[e];
+  dwx::parallel_ranges(nblk, nth, [&](uint64_t bb, uint64_t be) {
+    for (uint64_t b = bb; b < be; ++b) {
+      uint64_t nfid = blk_f[b], o = blk_e[b];
+      for (uint64_t f = b * BLK; f < std::min(F, (b + 1) * BLK); ++f) {
+        if (!keeps(f)) continue;
+        g.fac_func[nfid] = w.fac_func[f];
+        g.fac_edge_offset[nfid] = o;
+        g.fac_weight_id[nfid] = w.fac_weight_id[f];
+        g.fac_feature_value[nfid] = w.fac_feature_value[f];
+        for (uint64_t e = w.fac_edge_offset[f]; e < w.fac_edge_offset[f + 1]; ++e, ++o) {
+          g.edge_vid[o] = local_id(w.edge_vid[e]);
+          g.edge_equal_to[o] = w.edge_equal_to[e];
+        }
+        ++nfid;
       }
     }
-  });
+  }, 2);
   g.fac_edge_offset[nf] = ne;
   g.w_initial_value = w.w_initial_value;
   g.w_is_fixed = w.w_is_fixed;
@@ -258,6 +283,7 @@ class Rank {
   // curvature: a weight's curvature adds up over the shards)
   double global_curvature(uint32_t batches);
   void plan(double stepsize, uint32_t &batches, uint32_t &n_chunks, double &min_step);
+  void test_fault(uint64_t epoch);
   bool root() const { return rank_ == 0; }
   bool progress() const { return root() && !args_.should_be_quiet; }
 
@@ -300,6 +326,11 @@ void Rank::setup() {
   } else {
     uint64_t b, e;
     shard_range(whole.n_variables, rank_, sh_.world, b, e);
+    if (e <= b)
+      throw std::runtime_error("--gpus " + std::to_string(sh_.world) + ": rank " + std::to_string(rank_) +
+                               " would own no variable (" + std::to_string(whole.n_variables) +
+                               " variables in blocks of " + std::to_string((whole.n_variables + sh_.world - 1) / sh_.world) +
+                               "): use fewer GPUs");
     make_shard(whole, b, e, shard_);
     sh_.bounds[rank_] = {b, e};
     sh_.ghosts[rank_] = &shard_.ghosts;
@@ -384,6 +415,19 @@ void Rank::halo(int chains) {
   for (auto &p : recv_) ok(dwx_halo_unpack_async(p.h, chains));
 }
 
+// Test hook (tests/test_dw_multi.py): DWX_DW_TEST_FAULT="rank:epoch[:block]" -- that rank throws at
+// the start of that learning epoch; with "block" every other rank then sits in a call that
+// never returns (what a collective without its dead peer does), so that only the watchdog of
+// gibbs_multi can end the run.
+void Rank::test_fault(uint64_t epoch) {
+  const char *e = getenv("DWX_DW_TEST_FAULT");
+  if (!e) return;
+  int r = -1; unsigned long long ep = 0; char mode[16] = {0};
+  if (sscanf(e, "%d:%llu:%15s", &r, &ep, mode) < 2 || ep != epoch) return;
+  if (r == rank_) throw std::runtime_error("injected fault (DWX_DW_TEST_FAULT)");
+  if (!strcmp(mode, "block")) for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+}
+
 double Rank::global_curvature(uint32_t batches) {
   auto it = lam_.find(batches);
   if (it != lam_.end()) return it->second;
@@ -420,6 +464,10 @@ void Rank::plan(double stepsize, uint32_t &batches, uint32_t &n_chunks, double &
         if (b > 1 && cap > 0) (void)global_curvature(b);
         uint32_t got_b = 0, n_mine = 0;
         ok(dwx_sgd_plan(s_, stepsize, b, &got_b, &n_mine, nullptr));
+        // (a forced count is honoured whatever this shard's size; a rank that ran another plan
+        // than its peers would enter other collectives than they do)
+        if (sh_.agree->max_u64(rank_, got_b != b ? 1 : 0) != 0)
+          throw std::runtime_error("the ranks could not agree on " + std::to_string(b) + " mini-batches per sweep");
         level_chunks_[b] = (uint32_t)sh_.agree->max_u64(rank_, n_mine);
         if (b > 1) {
           void *tp = nullptr;
@@ -456,6 +504,7 @@ void Rank::learn_shards() {
     const double t0 = now();
     uint32_t batches = 1, n_chunks = 1;
     double min_step = stepsize;
+    test_fault(e);
     plan(stepsize, batches, n_chunks, min_step);
     for (uint32_t c = 0; c < n_chunks; ++c) {
       ok(dwx_sgd_accumulate_async(s_, c));        // ranks with fewer chunks idle through the rest
@@ -685,6 +734,9 @@ int gibbs_multi(const CmdLine &args) {
     std::vector<std::unique_ptr<Rank>> ranks;
     for (int r = 0; r < n; ++r) ranks.emplace_back(new Rank(sh, r));
     std::vector<std::thread> th;
+    std::atomic<int> done{0};
+    std::atomic<bool> failed{false};
+    std::chrono::steady_clock::time_point t_fail;
     for (int r = 0; r < n; ++r)
       th.emplace_back([&, r]() {
         try {
@@ -694,10 +746,28 @@ int gibbs_multi(const CmdLine &args) {
             std::lock_guard<std::mutex> lk(sh.err_mutex);
             if (sh.first_error.empty() && std::string(e.what()) != "another rank failed")
               sh.first_error = "rank " + std::to_string(r) + ": " + e.what();
+            if (!failed.load()) { t_fail = std::chrono::steady_clock::now(); failed.store(true); }
           }
+          // release the others: the host-side agreements throw, the device-side collectives abort
           agree.abort();
+          comm->abort();
         }
+        ++done;
       });
+    // A rank that failed takes the run down: the others are woken out of host barriers and
+    // collectives (above); one that still sits in a runtime call that never returns -- a
+    // collective its dead peer will not join -- must not keep `dw` alive: five seconds after
+    // the first failure the process reports it and exits 1 (no re-exec, no retry).
+    while (done.load() < n) {
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+      if (failed.load() && std::chrono::steady_clock::now() - t_fail > std::chrono::seconds(5)) {
+        std::string msg;
+        { std::lock_guard<std::mutex> lk(sh.err_mutex); msg = sh.first_error; }
+        std::cerr << "dw: " << (msg.empty() ? "a rank failed" : msg) << " (the other ranks did not stop within 5 s: exiting)" << std::endl;
+        std::cout.flush();
+        std::_Exit(1);
+      }
+    }
     for (auto &t : th) t.join();
     if (!sh.first_error.empty()) throw std::runtime_error(sh.first_error);
 

@@ -67,6 +67,9 @@ class Comm {
   // one grouped exchange: every send has a matching recv on the peer, same byte count
   virtual void exchange(int rank, dwx_sampler *s, const std::vector<Xfer> &sends,
                         const std::vector<Xfer> &recvs) = 0;
+  // a rank failed: make every collective that is queued or will be entered return (with an
+  // error) instead of waiting for the rank that will never join it.  Any thread, any time, once.
+  virtual void abort() {}
 };
 
 std::unique_ptr<Comm> make_host_comm(int n_ranks, HostAgree *agree);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <stdexcept>
 #include <string>
 
@@ -28,7 +29,17 @@ class RcclComm : public Comm {
     DW_NCCL(ncclCommInitAll(comms_.data(), (int)devices.size(), devices.data()));
   }
   ~RcclComm() override {
+    if (aborted_.load()) return;          // (ncclCommAbort freed them)
     for (ncclComm_t c : comms_) if (c) (void)ncclCommDestroy(c);
+  }
+  // ncclCommAbort makes the operations in flight on the communicator fail instead of waiting for
+  // a peer that died: the surviving ranks' next dwx_wait / dwx_get_weights returns, their threads
+  // end, `dw` exits 1 with the first error (the watchdog in gibbs_multi covers a runtime that
+  // does not come back even then).
+  void abort() override {
+    if (aborted_.exchange(true)) return;
+    for (size_t i = 0; i < comms_.size(); ++i)
+      if (comms_[i]) { (void)hipSetDevice(devices_[i]); (void)ncclCommAbort(comms_[i]); }
   }
   const char *name() const override { return "RCCL"; }
   void allreduce_sum_i64(int rank, dwx_sampler *s, void *dev, uint64_t n) override { reduce(rank, s, dev, n, ncclInt64); }
@@ -56,6 +67,7 @@ class RcclComm : public Comm {
   }
   std::vector<int> devices_;
   std::vector<ncclComm_t> comms_;
+  std::atomic<bool> aborted_{false};
 };
 }  // namespace
 

@@ -988,7 +988,12 @@ void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
   uint32_t B = 1;
   const double eta = stepsize;
   if (force_batches) {
-    B = std::min(force_batches, max_tiles);
+    // A forced count is the caller's GLOBAL plan (multi-GPU: every rank must run the same number
+    // of batches, apply after each chunk and put the same vectors through the collectives): it is
+    // NOT clamped by this shard's own tile count -- a shard with fewer tiles than batches simply
+    // has fewer chunks and idles through the rest (a one-tile shard used to fall
+    // back to plan_batches = 1, skip collectives its peers entered and apply whole-sweep counts).
+    B = std::min(force_batches, MAX_PLAN_BATCHES);
   } else if (cap > 0 && stepsize > 0) {
     // Double the cut while the batches' curvature is above the cap AND cutting still lowers it:
     // a batch can be no finer than one variable, so a hub with 10^5 factors sets a floor no cut

@@ -504,4 +504,8 @@ def shard_range(total, rank, world):
     """Contiguous variable block of a rank: [begin, end)."""
     per = (total + world - 1) // world
     b = min(total, per * rank)
-    return b, min(total, b + per)
+    e = min(total, b + per)
+    if e <= b:
+        raise ValueError("rank %d of %d would own no variable (%d variables in blocks of %d): use fewer ranks"
+                         % (rank, world, total, per))
+    return b, e

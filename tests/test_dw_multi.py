@@ -68,6 +68,72 @@ def test_shards_of_a_unary_graph_reproduce_the_single_rank_run_byte_for_byte(dw_
         assert outputs(a) == outputs(b)
 
 
+@pytest.mark.parametrize("mode", ["throw", "block"])
+def test_a_rank_that_fails_mid_epoch_takes_the_run_down_within_seconds(dw_emu, mode):
+    """VERDICT r02 #7b / ADVICE: a rank that throws in the middle of learning must not leave
+    `dw --gpus N` hanging.  DWX_DW_TEST_FAULT makes rank 1 throw at the start of its second
+    learning epoch: the other ranks are released from their host barriers (HostAgree::abort) and
+    collectives (Comm::abort; ncclCommAbort under RCCL) and the run ends with exit code 1 and the
+    first error on stderr; with `block` the other ranks sit in a call that never returns -- what a
+    collective without its dead peer does -- and only the watchdog can end the run, 5 s after the
+    failure."""
+    import time
+    env = dict(os.environ, DWX_DW_TEST_FAULT="1:1" + (":block" if mode == "block" else ""))
+    d = os.path.join(GOLDEN, "biased_coin")
+    with tempfile.TemporaryDirectory() as out:
+        cmd = [dw_emu, "gibbs", "-m", d + "/graph.meta", "-w", d + "/graph.weights", "-v", d + "/graph.variables",
+               "-f", d + "/graph.factors", "-o", out, "-l", "50", "-i", "10", "--alpha", "0.1", "-q",
+               "--gpus", "3", "--comm", "host"]
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=60)
+        dt = time.time() - t0
+    assert r.returncode == 1, (r.returncode, r.stderr)
+    assert "rank 1: injected fault" in r.stderr
+    assert dt < (12.0 if mode == "block" else 5.0), dt
+    if mode == "block":
+        assert "did not stop within 5 s" in r.stderr and dt > 4.0
+
+
+def test_a_shard_with_a_single_tile_runs_the_split_plan_of_its_peers(dw_emu):
+    """three shards of 230 variables, the first with 40 factors per variable
+    (several tiles), the others with one (ONE tile per colour launch each); three weights tied to
+    thousands of factors and a large step force a split plan.  The one-tile shards used to fall
+    back to plan_batches = 1 -- other collectives than their peers, whole-sweep counts applied at
+    chunk 0, a host-staged sum reading past a short buffer.  Now a forced batch count is honoured
+    whatever the shard's size: the run ends -- under ASan / UBSan too -- with finite, regularised
+    weights.  (They are not the single-rank run's: tied this heavily every batch's update is the
+    equilibrium of THAT batch, the weights after a sweep are those of its last batch, and the two
+    runs cut their sweeps differently.)"""
+    from sampler_amd.rawgraph import RawGraph, FUNC_ISTRUE, DTYPE_BOOLEAN
+    rng = np.random.default_rng(3)
+    V, per = 690, 230
+    deg = np.where(np.arange(V) < per, 40, 1)
+    F = int(deg.sum())
+    owner = np.repeat(np.arange(V, dtype=np.uint64), deg)
+    wid = (owner % 3).astype(np.uint64)
+    role = np.ones(V, np.uint8)
+    val = (rng.random(V) < np.array([0.8, 0.3, 0.6])[np.arange(V) % 3]).astype(np.uint64)
+    raw = RawGraph(var_role=role, var_init_value=val, var_dtype=np.full(V, DTYPE_BOOLEAN, np.uint16),
+                   var_cardinality=np.full(V, 2, np.uint64), fac_func=np.full(F, FUNC_ISTRUE, np.uint16),
+                   fac_edge_offset=np.arange(F + 1, dtype=np.uint64), fac_weight_id=wid,
+                   fac_feature_value=np.ones(F), edge_vid=owner, edge_equal_to=np.ones(F, np.uint64),
+                   w_initial_value=np.zeros(3), w_is_fixed=np.zeros(3, np.uint8))
+    args = ["-l", "30", "-i", "0", "--alpha", "0.05", "--diminish", "0.95", "--reg_param", "0.01", "--seed", "5"]
+    libasan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+    with tempfile.TemporaryDirectory() as d:
+        files = _write(raw, d)
+        for exe, env in ((dw_emu, None),
+                         (dw_emu + "_asan", dict(os.environ, LD_PRELOAD=libasan,
+                                                 ASAN_OPTIONS="detect_leaks=0:abort_on_error=1"))):
+            with tempfile.TemporaryDirectory() as out:
+                r = subprocess.run([exe, "gibbs"] + files + ["-o", out] + args + ["--gpus", "3", "--comm", "host"],
+                                   capture_output=True, text=True, timeout=600, env=env)
+                assert r.returncode == 0, r.stderr[-3000:]
+                assert "batches=" in r.stdout, r.stdout[-2000:]      # the plan was split
+                w = np.array([float(l.split()[1]) for l in outputs(out)[0].splitlines()])
+                assert np.all(np.isfinite(w)) and np.abs(w).max() < 1.0, w
+
+
 def _write(raw, d):
     binary_format.write_graph(raw, d)
     return ["-m", d + "/graph.meta", "-w", d + "/graph.weights", "-v", d + "/graph.variables", "-f", d + "/graph.factors"]

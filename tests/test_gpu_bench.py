@@ -34,11 +34,16 @@ def test_bench_single_process_small():
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _check(r.stdout, 1)
+    # like for like: the reference timed on the very graph the GPU number is quoted on, and on the
+    # bounded sample of the same generator next to it
     assert d["cpu_baseline"]["value"] and d["cpu_baseline"]["kind"] in ("reference", "port")
-    assert d["cpu_baseline"]["sample_is_smaller"] is True
-    # the second ceiling: random weight gathers, calibrated on this box by tools/gather_bench
+    assert d["cpu_baseline"]["sample_is_smaller"] is False and "V=200000" in d["cpu_baseline"]["sample"]
+    assert d["cpu_baseline_small"]["value"] and d["cpu_baseline_small"]["sample_is_smaller"] is True
+    # the second ceiling: the weight-sorted stream (20 000 weights: the graph has sorted super-tiles),
+    # calibrated on this box by tools/sorted_bench
     sec = d["roofline"]["secondary"]
-    assert sec["bound"] == "l2_req" and sec["peak"] > 0 and 0 < sec["frac"] < 1.5
+    assert d["roofline"]["kernel"].startswith("sorted_sweep_kernel")
+    assert sec["bound"] == "cu_vector_memory" and sec["peak"] > 0 and 0 < sec["frac"] < 1.5
     assert "this run" in sec["peak_source"]
     # (200k variables: a block of 3 steps takes 0.2 ms, so the repeat cap ends the run, not --min-time)
     assert d["rccl_ranks"] is None and (d["timed_seconds"] >= 0.4 or d["repeats"] == 200)
