@@ -19,7 +19,6 @@ namespace dwx {
 // lanes hit neighbouring weights.  Integer sums: the result is independent of the order
 // and identical to what the per-record atomics would have produced.
 struct alignas(16) DeltaPair { unsigned long long nz, ng; };
-struct alignas(16) U32x4 { uint32_t v[4]; };
 struct alignas(16) F32x4 { float v[4]; };
 
 // One lane owns PULL_RUN consecutive entries (a multiple of 4: 16-byte loads straight
@@ -92,18 +91,6 @@ pull_grad_kernel(const uint32_t *inc_wid, const uint32_t *inc_slot, const float 
 // streams its share of b's rows -- coalesced 16-byte loads, independent iterations, no
 // barrier -- and stores one partial sum per weight; fold_partials_kernel adds the blocks'
 // partials into grad.  Integer sums: the result equals pull_grad_kernel's.
-// a 16-byte row, read once per sweep: non-temporal
-#ifndef DWX_LOAD_ROW_NT
-typedef uint32_t dwx_row_u32x4 __attribute__((ext_vector_type(4)));
-DWX_DEV U32x4 load_row_nt(const U32x4 *p) {
-  const dwx_row_u32x4 v = __builtin_nontemporal_load((const dwx_row_u32x4 *)p);
-  U32x4 r;
-  r.v[0] = v.x; r.v[1] = v.y; r.v[2] = v.z; r.v[3] = v.w;
-  return r;
-}
-#else
-DWX_DEV U32x4 load_row_nt(const U32x4 *p) { return *p; }
-#endif
 
 // UNIFORM: every record delta of the graph is the same (one feature value, one factor
 // function -- the usual case): its step comes in as an argument instead of an LDS table.
@@ -143,7 +130,7 @@ pull_ell_kernel(const U32x4 *__restrict__ ell, const uint32_t *block_tile0, uint
     for (uint32_t u = 0; u < BP_UNROLL; ++u) {
       const uint32_t w = umin(g + u, g1 - 1) * BP_THREADS + tid;
 #pragma unroll
-      for (int dd = 0; dd < DEPTH; ++dd) row[u][dd] = load_row_nt(&rows[(size_t)dd * Wp + w]);
+      for (int dd = 0; dd < DEPTH; ++dd) row[u][dd] = DWX_LOAD_ROW_NT(&rows[(size_t)dd * Wp + w]);
     }
 #pragma unroll
     for (uint32_t u = 0; u < BP_UNROLL; ++u) {

@@ -100,6 +100,9 @@ struct alignas(16) SuperTile {
 };
 static_assert(sizeof(SuperTile) == 32, "SuperTile must be 32 bytes");
 
+// four entries of a block-pull row (aux_kernels.h)
+struct alignas(16) U32x4 { uint32_t v[4]; };
+
 // factor -> variable entry (src/variable.h:154-167), 8 bytes, device variable ids
 struct alignas(8) VifRec {
   uint32_t vid;       // DEVICE position of the variable

@@ -22,13 +22,7 @@
 #include "graph_compile.h"
 #include "host_parallel.h"
 
-#ifdef DWX_EMU
-#include "rt_emu.h"
-#else
-#include "rt_hip.h"
-#endif
-
-#include "sweep_kernels.h"
+#include "sweep_kernels.h"   // (device_intrinsics.h: the HIP runtime shim rt_hip.h comes with it)
 
 // a finer cut must lower the batches' curvature estimate to this fraction, else the plan stops
 // (dwx_sgd_plan; multi-GPU drivers apply the same rule to the global estimate)

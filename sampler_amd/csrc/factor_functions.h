@@ -5,25 +5,8 @@
 #ifndef DWX_FACTOR_FUNCTIONS_H_
 #define DWX_FACTOR_FUNCTIONS_H_
 
-#include "device_types.h"
+#include "device_intrinsics.h"
 
-#include "device_types.h"
-
-#ifndef DWX_DEV
-#define DWX_DEV __device__ __forceinline__
-#endif
-
-// Streamed-once loads / stores (per-variable words, row pointers, assignments of an all-unary
-// graph): non-temporal, so that they do not evict the re-used f32 weight table from L2.
-#ifndef DWX_NT_LOAD
-#ifdef DWX_NO_NT_META
-#define DWX_NT_LOAD(p) (*(p))
-#define DWX_NT_STORE(v, p) (*(p) = (v))
-#else
-#define DWX_NT_LOAD(p) __builtin_nontemporal_load(p)
-#define DWX_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#endif
-#endif
 
 
 namespace dwx {

@@ -38,50 +38,6 @@
 namespace dwx {
 
 // ---------------------------------------------------------------- kernels
-#ifndef DWX_DYN_LDS
-#define DWX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
-#endif
-
-// The tile's edge records: lane t takes records t, t + 256, ...  (16 B per lane,
-// consecutive lanes -> consecutive records: one coalesced stream).  Read through a
-// buffer descriptor of exactly the tile's range: the hardware bounds check returns
-// zeros for lanes past the last record (no clamping arithmetic, no branch, no memory
-// traffic), and the K loads differ only in their scalar offset, so they cost no
-// per-load address VALU.  "nt": the stream is read once per sweep and must not evict
-// the re-used f32 weight table from the XCD's L2.
-#ifndef DWX_LOAD_TILE_RECORDS
-typedef uint32_t dwx_u32x4 __attribute__((ext_vector_type(4)));
-template <int K>
-DWX_DEV void load_tile_records(const EdgeRec *base, uint32_t nedges, uint32_t t, EdgeRec (&rec)[K]) {
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(nedges * sizeof(EdgeRec)), 0x00020000);
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const dwx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
-        rsrc, (int)(t * sizeof(EdgeRec)), (int)(k * BLOCK_THREADS * sizeof(EdgeRec)), /*nt*/ 2);
-    rec[k].wid = v.x; rec[k].aux = v.y; rec[k].packed = v.z; rec[k].fval = bits_to_float(v.w);
-  }
-}
-#define DWX_LOAD_TILE_RECORDS(K, base, nedges, t, rec) load_tile_records<K>(base, nedges, t, rec)
-#endif
-
-// The same stream for the 8-byte records of an all-TILE_SIMPLE graph (buffer_load_dwordx2).
-#ifndef DWX_LOAD_TILE_RECORDS8
-typedef uint32_t dwx_u32x2 __attribute__((ext_vector_type(2)));
-template <int K>
-DWX_DEV void load_tile_records8(const EdgeRec8 *base, uint32_t nedges, uint32_t t, EdgeRec8 (&rec)[K]) {
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(nedges * sizeof(EdgeRec8)), 0x00020000);
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const dwx_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(
-        rsrc, (int)(t * sizeof(EdgeRec8)), (int)(k * BLOCK_THREADS * sizeof(EdgeRec8)), /*nt*/ 2);
-    rec[k].key = v.x; rec[k].f = bits_to_float(v.y);
-  }
-}
-#define DWX_LOAD_TILE_RECORDS8(K, base, nedges, t, rec) load_tile_records8<K>(base, nedges, t, rec)
-#endif
-
 // An 8-byte record back in its 16-byte pre-signed form (a zero-filled lane past the tile's
 // end decodes to weight 0 and two -0.0f: staged, never read).
 DWX_DEV float rec8_signed(uint32_t code, float f) {   // code = sign + 1
@@ -109,12 +65,6 @@ struct TilePrefetch {
 // The descriptor is workgroup-uniform: keep it in scalar registers.  Loading (vector
 // registers, no wait) and scalarising (needs the data) are separate steps so that the
 // load of the descriptor two tiles ahead can stay in flight across a whole tile.
-#ifndef DWX_UNIFORM
-#define DWX_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-#endif
-#ifndef DWX_BALLOT
-#define DWX_BALLOT(pred) ((unsigned long long)__ballot(pred))
-#endif
 DWX_DEV TileDesc scalarise(const TileDesc &v) {
   TileDesc d;
   d.v0 = DWX_UNIFORM(v.v0); d.nv = DWX_UNIFORM(v.nv);
@@ -709,20 +659,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
 // the other draws.  Replaces, for these variables, FactorGraph::potential's loop
 // (src/factor_graph.h:127-145) and draw_sample (src/gibbs_sampler.h:198-215).
 constexpr uint32_t SORT_TV_SLOTS = 64;   // tiles per super-tile + 1, padded (the default cuts at 32)
-#ifndef DWX_LOAD_SORTED_RECORDS
-template <int K>
-DWX_DEV void load_sorted_records(const SortRec8 *base, uint32_t nrec, uint32_t first, uint32_t t, SortRec8 (&rec)[K]) {
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(nrec * sizeof(SortRec8)), 0x00020000);
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const dwx_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(
-        rsrc, (int)(t * sizeof(SortRec8)), (int)((first + k * SORT_THREADS) * sizeof(SortRec8)), /*nt*/ 2);
-    rec[k].wid = v.x; rec[k].od = v.y;
-  }
-}
-#define DWX_LOAD_SORTED_RECORDS(K, base, nrec, first, t, rec) load_sorted_records<K>(base, nrec, first, t, rec)
-#endif
 
 template <bool LEARN>
 __global__ void __launch_bounds__(SORT_THREADS, 2)

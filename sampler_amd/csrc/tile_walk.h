@@ -43,41 +43,6 @@ constexpr uint32_t GIANT_PIECE = DWX_GIANT_PIECE;     // records per workgroup o
 constexpr uint32_t GIANT_THREADS = DWX_GIANT_THREADS;   // lanes per oversized variable (giant kernels)
 constexpr uint32_t COOP_U = 4;             // records per lane and step of a cooperative walk
 
-// sum over the 64 lanes of a wave, the same value (and the same association: the xor
-// butterfly) in every lane
-// Sums `acc` over the runs of equal `key` among the 64 lanes of a wave (equal keys sit in
-// neighbouring lanes); every lane gets the sum from itself to the end of its run, `head` says
-// whether it is the first lane of its run.  All 64 lanes call together.
-#ifndef DWX_WAVE_SEG_SUM_I64
-DWX_DEV long long wave_seg_sum_i64(uint32_t key, long long acc, bool &head) {
-  const uint32_t lane = threadIdx.x & 63u;
-  // (no two neighbouring lanes share a key -- lightly tied weights: every lane heads its own run)
-  const uint32_t nk = (uint32_t)__shfl_down((int)key, 1, 64);
-  if (__ballot(lane < 63u && nk == key) == 0ull) { head = true; return acc; }
-#pragma unroll
-  for (uint32_t off = 1; off < 64u; off <<= 1) {
-    const uint32_t ok = (uint32_t)__shfl_down((int)key, off, 64);
-    const long long oa = __shfl_down(acc, off, 64);
-    if (lane + off < 64u && ok == key) acc += oa;
-  }
-  const uint32_t pk = (uint32_t)__shfl_up((int)key, 1, 64);
-  head = lane == 0u || pk != key;
-  return acc;
-}
-#define DWX_WAVE_SEG_SUM_I64(key, acc, head) wave_seg_sum_i64(key, acc, head)
-#endif
-// the value of the neighbouring lane (lane ^ 1), both lanes of the pair calling together
-#ifndef DWX_PAIR_SWAP_U32
-#define DWX_PAIR_SWAP_U32(v) ((uint32_t)__shfl_xor((int)(v), 1, 64))
-#endif
-#ifndef DWX_WAVE_SUM_F64
-DWX_DEV double wave_sum_f64(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
-#define DWX_WAVE_SUM_F64(v) wave_sum_f64(v)
-#endif
 DWX_DEV uint32_t wave_lane() { return threadIdx.x & 63u; }
 
 // sum over all lanes of the workgroup through an LDS tree (every lane gets the total; must be
@@ -577,10 +542,6 @@ DWX_DEV void bool_potentials_both(const KernelParams &P, const TileView &T, uint
   }
 }
 
-// f32 exp for the guarded fast paths below (v_exp_f32; error ~1e-6 relative for |x| < 30)
-#ifndef DWX_FAST_EXPF
-#define DWX_FAST_EXPF(x) __expf(x)
-#endif
 constexpr double DRAW_GUARD = 1e-4;   // >> every f32 error bound below
 constexpr uint32_t SMALL_CARD = 8;    // domains up to this size are drawn out of registers
 

@@ -59,7 +59,7 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::functi
 #define DWX_WAVE_SEG_SUM_I64(key, acc, head) (::emu::wave_seg_sum(key, acc, head))
 #define DWX_UNIFORM(x) (x)
 #define DWX_NT_LOAD(p) (*(p))
-#define DWX_LOAD_ROW_NT 1
+#define DWX_LOAD_ROW_NT(p) (*(p))
 #define DWX_NT_STORE(v, p) (*(p) = (v))
 
 inline void __syncthreads() { ::emu::syncthreads(); }
