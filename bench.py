@@ -433,9 +433,11 @@ def main():
         achieved = bpv * units / (per_sweep_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and wl == "cfg3" and V == 10_000_000 and W == 1_000_000:
+        if os.path.exists(tp) and V == 10_000_000 and W == 1_000_000 and n_gpus == 1:
+            # (PMC bytes per launch of exactly this workload and size, profiles/r03: per colour launch)
             try:
-                traffic = json.load(open(tp)).get(kname)
+                tj = json.load(open(tp))
+                traffic = tj.get(wl, {}).get(kname)
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved,
@@ -447,7 +449,7 @@ def main():
         if traffic:
             # the fraction of PHYSICAL HBM bandwidth the kernel draws (PMC bytes, not the
             # survey's byte model): the layout moves 2.4x fewer bytes than section 8(d) assumed
-            roofline["physical_frac"] = traffic / (per_sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roofline["physical_frac"] = (traffic * max(launches_per_sweep, 1)) / (per_sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         # What actually bounds the all-unary sweeps: one random 4-byte gather out of the 4 MB f32
         # weight table per record = one 128-byte L2 request each (tools/gather_bench: ~13.7
         # requests/clk/XCD whatever the occupancy).  Ceiling = the same stream + gather shape

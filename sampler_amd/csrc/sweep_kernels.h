@@ -504,12 +504,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
 // rcap + 1 = 1537 -- with RP = 7 all of them ride the prefetch instead of being loaded and
 // awaited while staging (config 4: 0.296 -> 0.246 ms); boolean graphs keep 2 (the extra
 // loads cost config 3's repeated inference 15 %).
-// (3 workgroups per CU also when learning: pull-gradient tiles stage 16-byte terms only)
+// Learning: the register budget of three workgroups per CU (150 VGPRs, nothing spilled).  With the
+// budget of four (128) the K = 12 build spilled 15 VGPRs to scratch for 1.6 % on config 3 -- a
+// sweep the weight-sorted super-tiles now take; this kernel serves what is left (fewer than
+// 4096 weights, the tiles at the edges of a mini-batch, categorical rows).
 #ifndef DWX_S8_INFER_WG
 #define DWX_S8_INFER_WG 3
 #endif
 #ifndef DWX_S8_LEARN_WG
-#define DWX_S8_LEARN_WG 4
+#define DWX_S8_LEARN_WG 3
 #endif
 template <bool LEARN, int K, bool TAB = false, int RP = (int)ROWPTR_UNROLL>
 __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN_WG : DWX_S8_INFER_WG)) sweep8_kernel(const KernelParams P) {

@@ -346,6 +346,10 @@ DWX_DEV double row_potential(const KernelParams &P, const TileView &T, uint32_t 
 template <int WMODE, bool SIMPLE, bool FIXED = false>
 DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t row,
                              const uint32_t *assign, uint32_t me, double &pp, double &pn) {
+  if (WMODE == W_FIXSUM) {   // sorted_sweep_kernel: pp - pn, summed in fixed point over the weight-sorted records
+    pp = T.presum[0]; pn = 0.0;     // (no rows, no records: the view holds the sum only)
+    return;
+  }
   const uint32_t es = T.rowptr[row - T.row_bias], ee = T.rowptr[row + 1 - T.row_bias];
   pp = 0.0; pn = 0.0;
   static_assert(!FIXED || (SIMPLE && (WMODE == W_TERMS8 || WMODE == W_TERMS || WMODE == W_ARRAY)),
@@ -386,10 +390,7 @@ DWX_DEV void bool_potentials(const KernelParams &P, const TileView &T, uint32_t 
     pp = T.presum[evid ? 2 : 0]; pn = T.presum[evid ? 3 : 1];
     return;
   }
-  if (WMODE == W_FIXSUM) {   // sorted_sweep_kernel: pp - pn, summed in fixed point over the weight-sorted records
-    pp = T.presum[0];
-    return;
-  }
+
   if (Coop<WMODE>::on) {
     const uint32_t *const chains[1] = {assign};
     const int chain[2] = {0, 0};

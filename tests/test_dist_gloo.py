@@ -91,11 +91,19 @@ def test_two_rank_sharded_learning_equals_single_process(mixed):
 
 def test_shard_range_covers_everything():
     from sampler_amd.dist import shard_range
-    for total in (0, 1, 7, 100, 12_500_001):
+    for total in (1, 7, 100, 12_500_001):
         for world in (1, 2, 3, 8):
+            per = (total + world - 1) // world
+            if per * (world - 1) >= total:
+                # some rank would own nothing (9 variables over 4 ranks: blocks of 3, the last
+                # empty): refused loudly instead of running a rank that skips collectives
+                with pytest.raises(ValueError):
+                    [shard_range(total, k, world) for k in range(world)]
+                continue
             r = [shard_range(total, k, world) for k in range(world)]
             assert r[0][0] == 0 and r[-1][1] == total
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            assert all(e > b for b, e in r)
 
 
 def test_two_rank_split_sweeps_agree_on_the_plan_and_match_single_process():
