@@ -118,6 +118,23 @@ def test_weight_sorted_super_tiles(lib, monkeypatch, min_w):
     raw = random_graph(33, V=600, F=4000, W=1300, max_arity=1, exact_fvals=True, p_cat=0.4)
     s, _ = run_parity(lib, raw, n_learn=3, n_infer=3, compile_opts=dict(tile_vars=32, super_tiles=3))
     assert want(s)
+    if min_w == 0:
+        # a split plan WITHOUT per-chunk tables scatters its gradient and counts updates with
+        # atomics: such sweeps stay with the tile sweep (the sorted kernel only publishes ballots),
+        # inference sweeps of the same sampler take the sorted one
+        monkeypatch.setenv("DWX_PLAN_TABLE_CHUNKS", "1")
+        s, _ = run_parity(lib, synthetic.cfg3(6000, n_weights=1200, seed=7), n_learn=3, n_infer=2, stepsize=0.5,
+                          compile_opts=dict(tile_vars=32, super_tiles=6))
+        assert want(s) and s.sgd_plan(0.5)[0] > 1
+        monkeypatch.delenv("DWX_PLAN_TABLE_CHUNKS")
+        # more distinct record deltas than the LDS table holds (1024): no sorted copy, same results
+        raw = synthetic.cfg3(3000, n_weights=1500, seed=8)
+        raw.fac_feature_value[:] = 1.0 + (np.arange(raw.num_factors) % 1500) / 1024.0      # f32-exact
+        s, _ = run_parity(lib, raw, n_learn=2, n_infer=2)
+        assert s.graph.info.num_super_tiles == 0
+        raw.fac_feature_value[:] = 1.0 + (np.arange(raw.num_factors) % 400) / 1024.0       # 400 of them: sorted
+        s, _ = run_parity(lib, raw, n_learn=2, n_infer=2)
+        assert s.graph.info.num_super_tiles > 0
 
 
 @pytest.mark.parametrize("block_tiles, depth_hint", [(8, 1), (32, 2), (1024, 2)])
