@@ -316,8 +316,17 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     // every weight's factors into one stretch of the sweep, and a learning sweep that has to be cut
     // into mini-batches (heavily tied weights, section 3.5) wants every batch to see every weight's
     // factors evenly -- there the gathers hit few lines anyway.
-    const bool by_weight = E == F && F > 0 && W <= (1u << 24) && F / std::max<uint64_t>(W, 1) <= 256 &&
-                           !o.no_weight_order;
+    // (E == F alone would also hold for a mix of arity-0 and arity-2 factors: ask every factor)
+    bool all_unary = E == F && F > 0;
+    if (all_unary) {
+      std::atomic<bool> ok{true};
+      parallel_ranges(F, nth, [&](uint64_t fb, uint64_t fe) {
+        for (uint64_t f = fb; f < fe && ok.load(std::memory_order_relaxed); ++f)
+          if (d.fac_edge_offset[f + 1] - d.fac_edge_offset[f] != 1) ok.store(false, std::memory_order_relaxed);
+      });
+      all_unary = ok.load();
+    }
+    const bool by_weight = all_unary && W <= (1u << 24) && F / std::max<uint64_t>(W, 1) <= 256 && !o.no_weight_order;
     if (by_weight) {
       std::vector<uint32_t> first_wid(Vo, 0);
       parallel_ranges(Vo, nth, [&](uint64_t vb, uint64_t ve) {
@@ -326,14 +335,21 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
           first_wid[v] = r1 > r0 ? (uint32_t)d.fac_weight_id[g.ref_fidx[r0]] : 0u;
         }
       });
-      // stable counting sort by (class, first weight)
-      std::vector<uint32_t> cnt((size_t)nkeys * (W + 1) + 1, 0);
-      for (uint64_t v = 0; v < Vo; ++v) ++cnt[(size_t)key_of(v) * (W + 1) + first_wid[v] + 1];
-      for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
-      for (uint64_t v = 0; v < Vo; ++v) {
-        const uint64_t p = cnt[(size_t)key_of(v) * (W + 1) + first_wid[v]]++;
-        g.perm[p] = (uint32_t)v; g.pos[v] = (uint32_t)p;
-        if (p != v) g.order_is_identity = false;
+      // stable counting sort by first weight, class by class (an all-unary graph has one colour:
+      // four classes) -- one counter array of W + 1 entries, not one per class (the
+      // dense nkeys x (W + 1) table was 256 MB per colour group at 2^24 weights)
+      std::vector<uint32_t> cnt(W + 2);
+      for (uint32_t k = 0; k < nkeys; ++k) {
+        if (key_start[k + 1] == key_start[k]) continue;
+        std::fill(cnt.begin(), cnt.end(), 0u);
+        for (uint64_t v = 0; v < Vo; ++v) if (key_of(v) == k) ++cnt[first_wid[v] + 1];
+        for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+        for (uint64_t v = 0; v < Vo; ++v) {
+          if (key_of(v) != k) continue;
+          const uint64_t p = key_start[k] + cnt[first_wid[v]]++;
+          g.perm[p] = (uint32_t)v; g.pos[v] = (uint32_t)p;
+          if (p != v) g.order_is_identity = false;
+        }
       }
     } else {
       std::vector<uint64_t> cur(key_start.begin(), key_start.end() - 1);
