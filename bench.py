@@ -185,8 +185,8 @@ def cpu_baseline(raw, stepsize, decay, reg, what, smaller, timeout=420):
 def sorted_ceiling():
     """tools/sorted_bench --ceiling: the sorted sweep's own access shape -- a weight-sorted
     8-byte record stream, the gathers of neighbouring weights out of a 4 MB table, a 64-bit LDS
-    atomic per record, a trivial draw per variable -- on one full round of 512 super-tiles of 8192
-    variables.  -> records per second, or None."""
+    atomic per record, a trivial draw per variable -- on one full round of 256 super-tiles of 16 384
+    variables (the product kernel's shape: one 1024-thread workgroup per CU).  -> records per second, or None."""
     exe = os.path.join(ROOT, "tools", "sorted_bench")
     if not os.path.exists(exe):
         return None
@@ -460,10 +460,10 @@ def main():
             # weight table (tools/sorted_bench: the same loop with a trivial draw phase).
             recs = RECORDS_PER_VAR[wl] * units
             peak = None if args.no_gather_ceiling else sorted_ceiling()
-            committed = 3.1e11      # profiles/r03/sorted_bench.jsonl: 8192 variables, 512 threads, 2 per CU
+            committed = 3.5e11      # profiles/r03/sorted_bench.jsonl: 16 384 variables, 1024 threads, 1 per CU
             r_ach = recs / (per_sweep_ms * 1e-3)
             roofline["secondary"] = {"bound": "cu_vector_memory", "what": "weight-sorted 8-byte record stream + "
-                                     "sorted 4-byte weight gathers (about 0.4 L2 requests per record) + one LDS atomic per record",
+                                     "sorted 4-byte weight gathers (about 0.2 L2 requests per record) + one LDS atomic per record",
                                      "achieved": r_ach / 1e9, "peak": (peak or committed) / 1e9,
                                      "unit": "Grecord/s", "frac": r_ach / (peak or committed),
                                      "peak_source": "tools/sorted_bench --ceiling, this run" if peak else

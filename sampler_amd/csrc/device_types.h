@@ -80,14 +80,19 @@ struct alignas(8) SortRec8 {
   uint32_t wid, od;
 };
 static_assert(sizeof(SortRec8) == 8, "SortRec8 must be 8 bytes");
-constexpr uint32_t SORT_OWNER_BITS = 13, SORT_OWNER_MASK = (1u << SORT_OWNER_BITS) - 1;
+#ifndef DWX_SORT_OWNER_BITS
+#define DWX_SORT_OWNER_BITS 14
+#endif
+constexpr uint32_t SORT_OWNER_BITS = DWX_SORT_OWNER_BITS, SORT_OWNER_MASK = (1u << SORT_OWNER_BITS) - 1;
 constexpr uint32_t SUPER_NV_MAX = 1u << SORT_OWNER_BITS;      // 8192 variables: 64 KiB of sums
-constexpr uint32_t SUPER_TILES_DEFAULT = 32;
+constexpr uint32_t SUPER_TILES_DEFAULT = SUPER_NV_MAX / 256;  // 32 full tiles
+constexpr uint32_t SORT_WG_PER_CU = SORT_OWNER_BITS <= 13 ? 2 : 1;   // (16 384 variables: 128 KiB, the CU's LDS)
+constexpr uint32_t SORT_TV_SLOTS = 2 * SUPER_TILES_DEFAULT;   // tile starts of a super-tile in LDS (+ end), padded
 #ifndef DWX_SORT_THREADS
-#define DWX_SORT_THREADS 512
+#define DWX_SORT_THREADS 1024
 #endif
 #ifndef DWX_SORT_K
-#define DWX_SORT_K 12
+#define DWX_SORT_K 20
 #endif
 constexpr uint32_t SORT_THREADS = DWX_SORT_THREADS;   // sorted_sweep_kernel's workgroup
 constexpr int SORT_K = DWX_SORT_K;                    // ... and its records in flight per lane

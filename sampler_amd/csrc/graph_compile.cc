@@ -706,7 +706,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       if (const char *e = getenv("DWX_SORTED_MIN_W")) min_w = (uint64_t)std::max(0L, atol(e));   // test hook
       uint32_t want_super = o.super_tiles ? o.super_tiles : SUPER_TILES_DEFAULT;
       if (const char *e = getenv("DWX_SUPER_TILES")) want_super = (uint32_t)std::max(1L, atol(e));   // experiment hook
-      const uint32_t per_super = std::min(want_super, 63u);   // (sorted_sweep_kernel: SORT_TV_SLOTS - 1)
+      const uint32_t per_super = std::min(want_super, SORT_TV_SLOTS - 1);   // (sorted_sweep_kernel's tile table)
       auto eligible = [&](uint32_t i) {
         const uint32_t f = g.tiles[i].flags;
         return (f & TILE_SIMPLE) && !(f & (TILE_CATEGORICAL | TILE_OUTSIDE));
@@ -719,7 +719,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
         // sorted gathers -- and ONE round of `slots` small ones for the rest, last.  (610 equal
         // super-tiles on 512 slots would run as two rounds with the second a fifth full; cut into
         // 1024 equal ones they are half as dense: config 3's learning sweep 0.36 -> 0.40 ms.)
-        const uint32_t slots = o.sorted_slots ? o.sorted_slots : 512u;
+        const uint32_t slots = o.sorted_slots ? o.sorted_slots : 256u * SORT_WG_PER_CU;
         auto emit = [&](uint32_t &i, uint32_t end, uint32_t per) {
           SuperTile st{};
           st.tile0 = i; st.v0 = g.tiles[i].v0;

@@ -661,10 +661,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
 // 64 KiB of sums + the table of distinct d values: two workgroups per CU, one streaming while
 // the other draws.  Replaces, for these variables, FactorGraph::potential's loop
 // (src/factor_graph.h:127-145) and draw_sample (src/gibbs_sampler.h:198-215).
-constexpr uint32_t SORT_TV_SLOTS = 64;   // tiles per super-tile + 1, padded (the default cuts at 32)
 
 template <bool LEARN>
-__global__ void __launch_bounds__(SORT_THREADS, 2)
+__global__ void __launch_bounds__(SORT_THREADS, SORT_WG_PER_CU)
 sorted_sweep_kernel(const KernelParams P, const SuperTile *supers, uint32_t n_supers, const SortRec8 *recs,
                     const double *dvals, uint32_t n_dvals) {
   DWX_DYN_LDS(dyn_lds);

@@ -10,7 +10,7 @@
 //
 //   sorted_bench [--records N] [--weights W] [--ceiling]
 // one JSON line per (NV, threads, workgroups per CU, sorted?, atomics?); --ceiling: only the
-// product kernel's shape, on one full round of 512 super-tiles (bench.py: roofline.secondary)
+// product kernel's shape, on one full round of 256 super-tiles (bench.py: roofline.secondary)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -26,7 +26,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-constexpr int K = 8;          // records in flight per lane
+constexpr int K = 20;         // records in flight per lane (the product's SORT_K)
 constexpr int PER_VAR = 10;   // records per variable
 
 // fixed point 2^-32 through the round-to-nearest of an f64 add (|p| < 2^19)
@@ -89,7 +89,7 @@ struct Cfg { uint32_t nv; int threads, wg_per_cu; bool sorted, atomics; };
 int main(int argc, char **argv) {
   uint64_t nrec = 100ull * 1000 * 1000;
   uint32_t W = 1u << 20;
-  bool ceiling_only = false;    // one line: the product kernel's shape (8192 variables, 512 threads, 2 per CU)
+  bool ceiling_only = false;    // one line: the product kernel's shape (16 384 variables, 1024 threads, 1 per CU)
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--ceiling")) { ceiling_only = true; nrec = 42ull * 1000 * 1000; }
     if (i + 1 < argc && !strcmp(argv[i], "--records")) nrec = strtoull(argv[i + 1], nullptr, 10);
@@ -119,7 +119,7 @@ int main(int argc, char **argv) {
   };
   std::vector<u32x2> h(nrec);
   for (const Cfg &c : cfgs) {
-    if (ceiling_only && !(c.nv == 8192 && c.threads == 512 && c.sorted && c.atomics)) continue;
+    if (ceiling_only && !(c.nv == 16384 && c.threads == 1024 && c.sorted && c.atomics)) continue;
     const uint32_t per = c.nv * PER_VAR;
     const uint32_t n_super = (uint32_t)(nrec / per);
     // super-tile contents: random weight ids (sorted or not), owners = a random permutation of the

@@ -7,6 +7,8 @@ name=$1; shift
 mkdir -p variants
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function \
   "$@" -x hip -c -o variants/$name.o dwx_api.cc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/$name.so variants/$name.o graph_compile.o -pthread
-rm -f variants/$name.o
+# (the graph compiler shares device_types.h with the kernels: same flags)
+g++ -O2 -std=c++17 -fPIC -Wall -Wextra -pthread "$@" -c -o variants/$name.gc.o graph_compile.cc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/$name.so variants/$name.o variants/$name.gc.o -pthread
+rm -f variants/$name.o variants/$name.gc.o
 echo "built sampler_amd/csrc/variants/$name.so"
