@@ -371,26 +371,31 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     // ---- device rows ----
     g.v_meta.resize(V); g.v_init.resize(V); g.v_row.resize(V + 1);
     g.v_row[0] = 0;
-    for (uint64_t p = 0; p < V; ++p) {
-      uint64_t v = g.perm[p];
-      uint32_t m = (is_cat[v] ? VM_CATEGORICAL : 0) | (g.var_is_evid[v] ? VM_EVIDENCE : 0) |
-                   (!is_linear_zero(total_truth[v]) ? VM_TRUTHINESS : 0) |
-                   ((is_cat[v] ? card[v] : 2u) << VM_CARD_SHIFT);
-      g.v_meta[p] = m;
-      g.v_init[p] = assign_dense[v];
-      g.v_row[p + 1] = g.v_row[p] + (v < Vo ? (is_cat[v] ? card[v] : 1) : 0);
-    }
+    parallel_ranges(V, nth, [&](uint64_t pb, uint64_t pe) {
+      for (uint64_t p = pb; p < pe; ++p) {
+        uint64_t v = g.perm[p];
+        uint32_t m = (is_cat[v] ? VM_CATEGORICAL : 0) | (g.var_is_evid[v] ? VM_EVIDENCE : 0) |
+                     (!is_linear_zero(total_truth[v]) ? VM_TRUTHINESS : 0) |
+                     ((is_cat[v] ? card[v] : 2u) << VM_CARD_SHIFT);
+        g.v_meta[p] = m;
+        g.v_init[p] = assign_dense[v];
+        g.v_row[p + 1] = v < Vo ? (is_cat[v] ? card[v] : 1) : 0;      // (row counts; prefix below)
+      }
+    });
+    parallel_inclusive_prefix(g.v_row.data() + 1, V, nth);
     g.row_ptr.assign(R + 1, 0);
     if (g.has_truthiness) g.row_truth.assign(R, 0.0);
-    for (uint64_t p = 0; p < Vo; ++p) {
-      uint64_t v = g.perm[p], rb = g.ref_var_val_base[v];
-      uint32_t nr = g.v_row[p + 1] - g.v_row[p];
-      for (uint32_t j = 0; j < nr; ++j) {
-        g.row_ptr[g.v_row[p] + j + 1] = row_len[rb + j];
-        if (g.has_truthiness) g.row_truth[g.v_row[p] + j] = ref_truth[rb + j];
+    parallel_ranges(Vo, nth, [&](uint64_t pb, uint64_t pe) {
+      for (uint64_t p = pb; p < pe; ++p) {
+        uint64_t v = g.perm[p], rb = g.ref_var_val_base[v];
+        uint32_t nr = g.v_row[p + 1] - g.v_row[p];
+        for (uint32_t j = 0; j < nr; ++j) {
+          g.row_ptr[g.v_row[p] + j + 1] = row_len[rb + j];
+          if (g.has_truthiness) g.row_truth[g.v_row[p] + j] = ref_truth[rb + j];
+        }
       }
-    }
-    for (uint64_t r = 0; r < R; ++r) g.row_ptr[r + 1] += g.row_ptr[r];
+    });
+    parallel_inclusive_prefix(g.row_ptr.data() + 1, R, nth);
 
     phase("device rows");
     // ---- vifs of factors with arity >= 2 ----
@@ -776,6 +781,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
           }
           std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
         }, 0);
+        phase("sorted records: super-tiles, distinct deltas");
         std::vector<uint32_t> dbits;
         for (auto &v : local) dbits.insert(dbits.end(), v.begin(), v.end());
         std::sort(dbits.begin(), dbits.end()); dbits.erase(std::unique(dbits.begin(), dbits.end()), dbits.end());
@@ -790,7 +796,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
           g.sorted_recs.reset(g.n_sorted + 1);
           g.sorted_recs[g.n_sorted] = SortRec8{0u, 0u};
           parallel_ranges(ns, nth, [&](uint64_t sb, uint64_t se) {
-            std::vector<uint64_t> keys;
+            std::vector<uint64_t> keys, tmp;
             for (uint64_t si = sb; si < se; ++si) {
               SuperTile &st = g.supers[si];
               keys.clear();
@@ -808,7 +814,23 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
                   }
                 }
               }
-              std::sort(keys.begin(), keys.end());
+              // by (weight id, owner): a stable LSD radix sort on the weight id's bytes (the keys
+              // come in (owner, row) order, so ties end up ascending in the owner's slot)
+              {
+                const size_t n = keys.size();
+                tmp.resize(n);
+                uint32_t wmax = 0;
+                for (uint64_t k : keys) wmax = std::max(wmax, (uint32_t)(k >> 32));
+                uint64_t *src = keys.data(), *dst = tmp.data();
+                for (uint32_t shift = 32; shift < 64 && (wmax >> (shift - 32)) != 0; shift += 11) {
+                  uint32_t cnt[2049] = {0};
+                  for (size_t i = 0; i < n; ++i) ++cnt[((src[i] >> shift) & 2047u) + 1];
+                  for (uint32_t b = 0; b < 2048; ++b) cnt[b + 1] += cnt[b];
+                  for (size_t i = 0; i < n; ++i) dst[cnt[(src[i] >> shift) & 2047u]++] = src[i];
+                  std::swap(src, dst);
+                }
+                if (src != keys.data()) std::memcpy(keys.data(), src, n * sizeof(uint64_t));
+              }
               const uint64_t at = count[si];
               st.lo = (uint32_t)at; st.hi = (uint32_t)(at >> 32); st.nrec = (uint32_t)keys.size();
               for (size_t i = 0; i < keys.size(); ++i)

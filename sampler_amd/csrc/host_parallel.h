@@ -111,6 +111,33 @@ void parallel_ranges(uint64_t n, uint32_t n_threads, Fn &&fn, uint64_t serial_be
   parallel_parts(n, n_threads, [&](uint32_t, uint64_t b, uint64_t e) { fn(b, e); }, serial_below);
 }
 
+// In-place inclusive prefix sum of a[0 .. n) (two passes over contiguous parts: part totals,
+// then the parts again with their offsets).
+template <class T>
+void parallel_inclusive_prefix(T *a, uint64_t n, uint32_t n_threads) {
+  const uint32_t P = (n_threads <= 1 || n < (1u << 18)) ? 1u : n_threads;
+  if (P == 1) {
+    for (uint64_t i = 1; i < n; ++i) a[i] += a[i - 1];
+    return;
+  }
+  std::vector<T> total(P + 1, 0);
+  const uint64_t per = (n + P - 1) / P;
+  parallel_parts(P, P, [&](uint32_t, uint64_t tb, uint64_t te) {
+    for (uint64_t t = tb; t < te; ++t) {
+      T acc = 0;
+      for (uint64_t i = std::min(n, per * t); i < std::min(n, per * (t + 1)); ++i) acc += a[i];
+      total[t + 1] = acc;
+    }
+  }, 0);
+  for (uint32_t t = 0; t < P; ++t) total[t + 1] += total[t];
+  parallel_parts(P, P, [&](uint32_t, uint64_t tb, uint64_t te) {
+    for (uint64_t t = tb; t < te; ++t) {
+      T acc = total[t];
+      for (uint64_t i = std::min(n, per * t); i < std::min(n, per * (t + 1)); ++i) { acc += a[i]; a[i] = acc; }
+    }
+  }, 0);
+}
+
 // Stable parallel counting sort of generated records by an integer key in [0, n_keys).
 //   produce(begin, end, emit): enumerates, in order, the records of the source range
 //     [begin, end) of [0, n_src) calling emit(const Rec &); it runs TWICE per range (count,
