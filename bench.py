@@ -544,8 +544,12 @@ def main():
                     g_, what = make()
                     out[key] = cpu_baseline(g_, stepsize, decay, reg, what, smaller)
                 except Exception as e:  # the baseline must never lose the GPU measurement
-                    out[key] = {"value": None, "unit": "variables/s", "cores": os.cpu_count(),
-                                "kind": "port", "sample": "failed: %r" % (e,)}
+                    log("bench.py: %s failed: %r" % (key, e))
+                    if key == "cpu_baseline_small":
+                        out[key] = {"value": None, "unit": "variables/s", "cores": os.cpu_count(),
+                                    "kind": "port", "sample": "failed: %r" % (e,)}
+                    else:       # (no full-size run: the sample below becomes the baseline, and says so)
+                        out["cpu_baseline_full_error"] = repr(e)
             raw_full = None
             if "cpu_baseline" not in out:      # (no full-size run: the sample is the baseline)
                 out["cpu_baseline"] = out.pop("cpu_baseline_small")
