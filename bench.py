@@ -404,7 +404,7 @@ def main():
     assert np.isfinite(w).all()
     # mini-batch plan at the LARGEST step of the run: 1 = un-split sweeps
     plan_batches, _, plan_min_step = sampler.sgd_plan(stepsize)
-    if use_dist:
+    if use_dist or drv.plan_world:
         plan_batches = drv._plan(stepsize)[0]
 
     if rank == 0:
