@@ -183,7 +183,15 @@ struct dwx_sampler {
     std::vector<BlockTable> bp;           // [groups] or empty
     long long *d_bp_qtab = nullptr, *d_bp_partial = nullptr;   // shared: deltas; [max blocks][Wp] sums
     uint32_t bp_deltas = 0, bp_wp = 0;
+    // a split plan's own weight-sorted layout: super-tiles cut ALONG its chunks, as many per chunk
+    // as workgroups are resident, so that every chunk's launch of sorted_sweep_kernel is as wide as
+    // the chip (the graph's default super-tiles of 64 tiles leave a quarter-sweep chunk 95 workgroups
+    // for 256 CUs).  Empty: the chunks use the default layout (whole super-tiles inside a chunk).
+    std::vector<SuperTile> sorted_supers;
+    SuperTile *d_supers = nullptr;
+    SortRec8 *d_sorted = nullptr;
     ~Level() {
+      rt::dfree(d_supers); rt::dfree(d_sorted);
       rt::dfree(d_inc_wid); rt::dfree(d_inc_slot); rt::dfree(d_inc_d); rt::dfree(d_t_static);
       for (auto &t : bp) { rt::dfree(t.d_ell); rt::dfree(t.d_tile0); }
       rt::dfree(d_bp_qtab); rt::dfree(d_bp_partial);
@@ -313,7 +321,11 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   // the tiles before, between and behind them: the tile sweep.
   bool used_sorted = false;
   if (s->d_supers && !P.edge_terms && (!LEARN || (s->sorted_learn && !(P.flags & (OPT_NO_PULL | OPT_DYNAMIC_T))))) {
-    const std::vector<SuperTile> &sv = c.supers;
+    // (a chunk of a split learning sweep: the plan level's own layout, cut along the chunks)
+    const dwx_sampler::Level *lv = (LEARN && s->plan_batches > 1 && s->plan_level && s->plan_level->d_supers) ? s->plan_level : nullptr;
+    const std::vector<SuperTile> &sv = lv ? lv->sorted_supers : c.supers;
+    const SuperTile *d_sv = lv ? lv->d_supers : s->d_supers;
+    const SortRec8 *d_sr = lv ? lv->d_sorted : s->d_sorted;
     size_t a = std::lower_bound(sv.begin(), sv.end(), t0, [](const SuperTile &x, uint32_t t) { return x.tile0 < t; }) - sv.begin();
     size_t b = a;
     while (b < sv.size() && sv[b].tile0 + sv[b].ntiles <= t1) ++b;
@@ -332,7 +344,7 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
       for (const Run &r : runs) {
         launch_lane_tiles(cursor, sv[r.a].tile0);
         rt::launch(sorted_sweep_kernel<LEARN>, (unsigned)(r.b - r.a), SORT_THREADS, s->lds_sorted, s->stream, P,
-                   (const SuperTile *)(s->d_supers + r.a), (uint32_t)(r.b - r.a), (const SortRec8 *)s->d_sorted,
+                   (const SuperTile *)(d_sv + r.a), (uint32_t)(r.b - r.a), d_sr,
                    (const double *)s->d_sort_dvals, s->n_sort_dvals);
         ++launches;
         cursor = sv[r.b - 1].tile0 + sv[r.b - 1].ntiles;
@@ -552,6 +564,25 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
     }
     std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &a, const Piece &b) { return a.at < b.at; });
     for (const Piece &pc : pieces) L->chunks.push_back(pc.ch);
+  }
+  // the level's own weight-sorted layout (see Level::sorted_supers): worth it while a chunk still
+  // makes super-tiles of 8 tiles and more; finer plans keep the default layout's whole super-tiles
+  if (batches > 1 && !c.supers.empty() && s->sorted_learn && !L->chunks.empty()) {
+    uint64_t tiles_in_chunks = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+    for (const auto &ch : L->chunks) { ranges.push_back({ch.t0, ch.t1}); tiles_in_chunks += ch.t1 - ch.t0; }
+    if (tiles_in_chunks / L->chunks.size() >= 8ull * c.sorted_slots) {
+      SortedLayout lay;
+      build_sorted_layout(c, ranges, c.sorted_per_super, c.sorted_slots, false, nth, lay);
+      if (!lay.supers.empty()) {
+        // (launch_tiles looks super-tiles up by their first tile: ascending, like the default layout)
+        std::sort(lay.supers.begin(), lay.supers.end(), [](const SuperTile &a, const SuperTile &b) { return a.tile0 < b.tile0; });
+        L->d_sorted = upload(lay.recs, s->stream, 1);
+        L->d_supers = upload(lay.supers, s->stream);
+        rt::stream_sync(s->stream);   // (the host copies die with this scope)
+        L->sorted_supers.swap(lay.supers);
+      }
+    }
   }
   const uint32_t nc = (uint32_t)L->chunks.size();
   // beyond this the per-chunk tables cost more than they save: such plans keep the

@@ -52,6 +52,118 @@ uint64_t CompiledGraph::device_bytes() const {
   return b;
 }
 
+bool sorted_eligible(const TileDesc &td) {
+  return (td.flags & TILE_SIMPLE) && !(td.flags & (TILE_CATEGORICAL | TILE_OUTSIDE));
+}
+float sorted_rec_d(const EdgeRec8 &c) {
+  const int sh = (int)((c.key >> REC8_HIT_SHIFT) & 3u) - 1, sm = (int)((c.key >> REC8_MISS_SHIFT) & 3u) - 1;
+  return (float)(sh - sm) * c.f;     // exact: a factor in {-2 .. 2}
+}
+
+// Super-tiles over the eligible tiles of `ranges` (tile ranges of one launch each) and their
+// weight-sorted records.  One workgroup of sorted_sweep_kernel takes one super-tile, `slots`
+// workgroups are resident and start in the order of their super-tiles.  full_rounds (the default
+// layout of a graph): a run of eligible tiles is cut into full rounds of `slots` super-tiles of
+// per_super tiles -- the bigger a super-tile, the denser its sorted gathers -- and ONE round of
+// `slots` small ones for the rest, last (610 equal super-tiles on 512 slots would run as two rounds
+// with the second a fifth full; cut into 1024 equal ones they are half as dense: config 3's learning
+// sweep 0.36 -> 0.40 ms).  Otherwise (the layout of a split plan, one range per mini-batch chunk):
+// `slots` equal super-tiles per run, so that every chunk's launch is as wide as the chip.
+void build_sorted_layout(const CompiledGraph &g, const std::vector<std::pair<uint32_t, uint32_t>> &ranges,
+                         uint32_t per_super, uint32_t slots, bool full_rounds, uint32_t nth, SortedLayout &out) {
+  out.supers.clear(); out.recs.clear(); out.n = 0;
+  if (g.edges8.size() == 0 || g.sort_dvals.empty()) return;
+  per_super = std::max(1u, std::min(per_super, SORT_TV_SLOTS - 1));
+  slots = std::max(1u, slots);
+  auto emit = [&](uint32_t &i, uint32_t end, uint32_t per) {
+    SuperTile st{};
+    st.tile0 = i; st.v0 = g.tiles[i].v0;
+    uint32_t nv = 0, j = i;
+    while (j < end && j - i < per && nv + g.tiles[j].nv <= SUPER_NV_MAX) nv += g.tiles[j++].nv;
+    st.ntiles = j - i; st.nv = nv;
+    out.supers.push_back(st);
+    i = j;
+  };
+  auto cut_run = [&](uint32_t a, uint32_t b) {           // eligible tiles [a, b)
+    uint32_t i = a;
+    if (full_rounds)
+      while (b - i >= per_super * slots)
+        for (uint32_t k = 0; k < slots; ++k) emit(i, b, per_super);
+    if (i == b) return;
+    const uint32_t per = std::min(per_super, std::max((b - i + slots - 1) / slots, std::min(8u, per_super)));
+    while (i < b) emit(i, b, per);
+  };
+  for (const auto &rg : ranges) {
+    uint32_t run0 = 0;
+    bool open = false;
+    for (uint32_t i = rg.first; i <= rg.second; ++i) {
+      const bool stop = i == rg.second || !sorted_eligible(g.tiles[i]);
+      if (stop && open) { cut_run(run0, i); open = false; }
+      if (i < rg.second && sorted_eligible(g.tiles[i]) && !open) { open = true; run0 = i; }
+    }
+  }
+  const size_t ns = out.supers.size();
+  if (!ns) return;
+  std::vector<uint64_t> count(ns + 1, 0);
+  parallel_ranges(ns, nth, [&](uint64_t sb, uint64_t se) {
+    for (uint64_t si = sb; si < se; ++si) {
+      const SuperTile &st = out.supers[si];
+      const TileDesc &t0 = g.tiles[st.tile0], &t1 = g.tiles[st.tile0 + st.ntiles - 1];
+      uint64_t n = 0;
+      for (uint64_t e = t0.e0; e < (uint64_t)t1.e0 + t1.nedges; ++e) n += sorted_rec_d(g.edges8[e]) != 0.0f;
+      count[si + 1] = n;
+    }
+  }, 1);
+  for (size_t i = 0; i < ns; ++i) count[i + 1] += count[i];
+  out.n = count[ns];
+  // the records, super-tile by super-tile, sorted by (weight id, owner)
+  out.recs.reset(out.n + 1);
+  out.recs[out.n] = SortRec8{0u, 0u};
+  const std::vector<uint32_t> &dbits = g.sort_dbits;
+  parallel_ranges(ns, nth, [&](uint64_t sb, uint64_t se) {
+    std::vector<uint64_t> keys, tmp;
+    for (uint64_t si = sb; si < se; ++si) {
+      SuperTile &st = out.supers[si];
+      keys.clear();
+      for (uint32_t ti = st.tile0; ti < st.tile0 + st.ntiles; ++ti) {
+        const TileDesc &td = g.tiles[ti];
+        for (uint32_t l = 0; l < td.nv; ++l) {
+          const uint32_t p = td.v0 + l, slot = p - st.v0;
+          for (uint32_t e = g.row_ptr[g.v_row[p]]; e < g.row_ptr[g.v_row[p + 1]]; ++e) {
+            const EdgeRec8 &c = g.edges8[e];
+            const float dv = sorted_rec_d(c);
+            if (dv == 0.0f) continue;
+            uint32_t bits; std::memcpy(&bits, &dv, 4);
+            const uint32_t di = 1u + (uint32_t)(std::lower_bound(dbits.begin(), dbits.end(), bits) - dbits.begin());
+            keys.push_back(((uint64_t)(c.key & REC8_WID_MASK) << 32) | (di << SORT_OWNER_BITS) | slot);
+          }
+        }
+      }
+      // by (weight id, owner): a stable LSD radix sort on the weight id (the keys come in
+      // (owner, row) order, so ties end up ascending in the owner's slot)
+      {
+        const size_t n = keys.size();
+        tmp.resize(n);
+        uint32_t wmax = 0;
+        for (uint64_t k : keys) wmax = std::max(wmax, (uint32_t)(k >> 32));
+        uint64_t *src = keys.data(), *dst = tmp.data();
+        for (uint32_t shift = 32; shift < 64 && (wmax >> (shift - 32)) != 0; shift += 11) {
+          uint32_t cnt[2049] = {0};
+          for (size_t i = 0; i < n; ++i) ++cnt[((src[i] >> shift) & 2047u) + 1];
+          for (uint32_t b = 0; b < 2048; ++b) cnt[b + 1] += cnt[b];
+          for (size_t i = 0; i < n; ++i) dst[cnt[(src[i] >> shift) & 2047u]++] = src[i];
+          std::swap(src, dst);
+        }
+        if (src != keys.data()) std::memcpy(keys.data(), src, n * sizeof(uint64_t));
+      }
+      const uint64_t at = count[si];
+      st.lo = (uint32_t)at; st.hi = (uint32_t)(at >> 32); st.nrec = (uint32_t)keys.size();
+      for (size_t i = 0; i < keys.size(); ++i)
+        out.recs[at + i] = SortRec8{(uint32_t)(keys[i] >> 32), (uint32_t)keys[i]};
+    }
+  }, 1);
+}
+
 void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledGraph &g,
                    bool *limit) {
   *limit = false;
@@ -705,138 +817,62 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       }
     }
     // Weight-sorted super-tiles over the boolean lane-bin tiles of a compact-record graph.
-    g.sorted_recs.clear(); g.supers.clear(); g.sort_dvals.clear(); g.n_sorted = 0;
+    g.sorted_recs.clear(); g.supers.clear(); g.sort_dvals.clear(); g.sort_dbits.clear(); g.n_sorted = 0;
+    g.sorted_per_super = 0; g.sorted_slots = 0;
     {
       uint64_t min_w = 4096;   // (a smaller table sits in the CU's L1: the plain stream gathers as fast)
       if (const char *e = getenv("DWX_SORTED_MIN_W")) min_w = (uint64_t)std::max(0L, atol(e));   // test hook
       uint32_t want_super = o.super_tiles ? o.super_tiles : SUPER_TILES_DEFAULT;
       if (const char *e = getenv("DWX_SUPER_TILES")) want_super = (uint32_t)std::max(1L, atol(e));   // experiment hook
       const uint32_t per_super = std::min(want_super, SORT_TV_SLOTS - 1);   // (sorted_sweep_kernel's tile table)
-      auto eligible = [&](uint32_t i) {
-        const uint32_t f = g.tiles[i].flags;
-        return (f & TILE_SIMPLE) && !(f & (TILE_CATEGORICAL | TILE_OUTSIDE));
-      };
+      const uint32_t slots = o.sorted_slots ? o.sorted_slots : 256u * SORT_WG_PER_CU;
       if (g.edges8.size() && W >= min_w && !o.no_sorted_records) {
-        // (1) super-tiles: runs of eligible tiles, cut at launch ends and at the end of a launch's
-        // query tiles.  One workgroup takes one super-tile, `slots` workgroups are resident (two
-        // per CU) and workgroups start in the order of their super-tiles: a run is cut into full
-        // rounds of `slots` super-tiles of per_super tiles -- the bigger a super-tile, the denser its
-        // sorted gathers -- and ONE round of `slots` small ones for the rest, last.  (610 equal
-        // super-tiles on 512 slots would run as two rounds with the second a fifth full; cut into
-        // 1024 equal ones they are half as dense: config 3's learning sweep 0.36 -> 0.40 ms.)
-        const uint32_t slots = o.sorted_slots ? o.sorted_slots : 256u * SORT_WG_PER_CU;
-        auto emit = [&](uint32_t &i, uint32_t end, uint32_t per) {
-          SuperTile st{};
-          st.tile0 = i; st.v0 = g.tiles[i].v0;
-          uint32_t nv = 0, j = i;
-          while (j < end && j - i < per && nv + g.tiles[j].nv <= SUPER_NV_MAX) nv += g.tiles[j++].nv;
-          st.ntiles = j - i; st.nv = nv;
-          g.supers.push_back(st);
-          i = j;
-        };
-        auto cut_run = [&](uint32_t a, uint32_t b) {           // eligible tiles [a, b)
-          uint32_t i = a;
-          while (b - i >= per_super * slots)
-            for (uint32_t k = 0; k < slots; ++k) emit(i, b, per_super);
-          if (i == b) return;
-          const uint32_t per = std::min(per_super, std::max((b - i + slots - 1) / slots, std::min(8u, per_super)));
-          while (i < b) emit(i, b, per);
-        };
-        for (uint64_t l = 0; l < nl; ++l) {
-          uint32_t run0 = 0;
-          bool open = false;
-          for (uint32_t i = g.launch_tile[l]; i <= g.launch_tile[l + 1]; ++i) {
-            const bool stop = i == g.launch_tile[l + 1] || i == g.launch_query_tile_end[l] || !eligible(i);
-            if (stop && open) { cut_run(run0, i); open = false; }
-            if (i < g.launch_tile[l + 1] && eligible(i) && !open) { open = true; run0 = i; }
-          }
-        }
-        // (2) the distinct values of d = (sign(hit) - sign(miss)) * f (few: feature values repeat)
-        auto rec_d = [&](const EdgeRec8 &c) -> float {
-          const int sh = (int)((c.key >> REC8_HIT_SHIFT) & 3u) - 1, sm = (int)((c.key >> REC8_MISS_SHIFT) & 3u) - 1;
-          return (float)(sh - sm) * c.f;     // exact: a factor in {-2 .. 2}
-        };
-        const size_t ns = g.supers.size();
-        const uint32_t T = (uint32_t)std::max<size_t>(1, std::min<size_t>(nth, ns));
+        // the distinct values of d = (sign(hit) - sign(miss)) * f over the eligible tiles' records
+        // (few: feature values repeat); too many for the kernel's LDS table: no sorted copy
+        const size_t nt = g.tiles.size();
+        const uint32_t T = (uint32_t)std::max<size_t>(1, std::min<size_t>(nth, nt));
         std::vector<std::vector<uint32_t>> local(T);
-        std::vector<uint64_t> count(ns + 1, 0);
-        parallel_parts(ns, T, [&](uint32_t t, uint64_t sb, uint64_t se) {
+        std::atomic<bool> any{false};
+        parallel_parts(nt, T, [&](uint32_t t, uint64_t tb, uint64_t te) {
           std::vector<uint32_t> &v = local[t];
           uint32_t last = 0; bool have = false;
-          for (uint64_t si = sb; si < se; ++si) {
-            const SuperTile &st = g.supers[si];
-            const uint64_t e0 = g.tiles[st.tile0].e0, e1 = (uint64_t)g.tiles[st.tile0 + st.ntiles - 1].e0 + g.tiles[st.tile0 + st.ntiles - 1].nedges;
-            uint64_t n = 0;
-            for (uint64_t e = e0; e < e1; ++e) {
-              const float dv = rec_d(g.edges8[e]);
+          for (uint64_t ti = tb; ti < te; ++ti) {
+            const TileDesc &td = g.tiles[ti];
+            if (!sorted_eligible(td)) continue;
+            any.store(true, std::memory_order_relaxed);
+            for (uint64_t e = td.e0; e < (uint64_t)td.e0 + td.nedges && v.size() <= 4 * SORT_MAX_DVALS; ++e) {
+              const float dv = sorted_rec_d(g.edges8[e]);
               if (dv == 0.0f) continue;
-              ++n;
               uint32_t bits; std::memcpy(&bits, &dv, 4);
               if (have && bits == last) continue;
               last = bits; have = true;
-              if (v.size() <= 4 * SORT_MAX_DVALS) v.push_back(bits);
+              v.push_back(bits);
               if (v.size() % 1024 == 0) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
             }
-            count[si + 1] = n;
           }
           std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
         }, 0);
-        phase("sorted records: super-tiles, distinct deltas");
         std::vector<uint32_t> dbits;
         for (auto &v : local) dbits.insert(dbits.end(), v.begin(), v.end());
         std::sort(dbits.begin(), dbits.end()); dbits.erase(std::unique(dbits.begin(), dbits.end()), dbits.end());
-        if (dbits.size() + 1 > SORT_MAX_DVALS || ns == 0) {
-          g.supers.clear();
-        } else {
+        if (any.load() && dbits.size() + 1 <= SORT_MAX_DVALS) {
+          g.sort_dbits = dbits;
           g.sort_dvals.push_back(0.0);
           for (uint32_t b : dbits) { float f; std::memcpy(&f, &b, 4); g.sort_dvals.push_back((double)f); }
-          for (size_t i = 0; i < ns; ++i) count[i + 1] += count[i];
-          g.n_sorted = count[ns];
-          // (3) the records, super-tile by super-tile, sorted by (weight id, owner)
-          g.sorted_recs.reset(g.n_sorted + 1);
-          g.sorted_recs[g.n_sorted] = SortRec8{0u, 0u};
-          parallel_ranges(ns, nth, [&](uint64_t sb, uint64_t se) {
-            std::vector<uint64_t> keys, tmp;
-            for (uint64_t si = sb; si < se; ++si) {
-              SuperTile &st = g.supers[si];
-              keys.clear();
-              for (uint32_t ti = st.tile0; ti < st.tile0 + st.ntiles; ++ti) {
-                const TileDesc &td = g.tiles[ti];
-                for (uint32_t l = 0; l < td.nv; ++l) {
-                  const uint32_t p = td.v0 + l, slot = p - st.v0;
-                  for (uint32_t e = g.row_ptr[g.v_row[p]]; e < g.row_ptr[g.v_row[p + 1]]; ++e) {
-                    const EdgeRec8 &c = g.edges8[e];
-                    const float dv = rec_d(c);
-                    if (dv == 0.0f) continue;
-                    uint32_t bits; std::memcpy(&bits, &dv, 4);
-                    const uint32_t di = 1u + (uint32_t)(std::lower_bound(dbits.begin(), dbits.end(), bits) - dbits.begin());
-                    keys.push_back(((uint64_t)(c.key & REC8_WID_MASK) << 32) | (di << SORT_OWNER_BITS) | slot);
-                  }
-                }
-              }
-              // by (weight id, owner): a stable LSD radix sort on the weight id's bytes (the keys
-              // come in (owner, row) order, so ties end up ascending in the owner's slot)
-              {
-                const size_t n = keys.size();
-                tmp.resize(n);
-                uint32_t wmax = 0;
-                for (uint64_t k : keys) wmax = std::max(wmax, (uint32_t)(k >> 32));
-                uint64_t *src = keys.data(), *dst = tmp.data();
-                for (uint32_t shift = 32; shift < 64 && (wmax >> (shift - 32)) != 0; shift += 11) {
-                  uint32_t cnt[2049] = {0};
-                  for (size_t i = 0; i < n; ++i) ++cnt[((src[i] >> shift) & 2047u) + 1];
-                  for (uint32_t b = 0; b < 2048; ++b) cnt[b + 1] += cnt[b];
-                  for (size_t i = 0; i < n; ++i) dst[cnt[(src[i] >> shift) & 2047u]++] = src[i];
-                  std::swap(src, dst);
-                }
-                if (src != keys.data()) std::memcpy(keys.data(), src, n * sizeof(uint64_t));
-              }
-              const uint64_t at = count[si];
-              st.lo = (uint32_t)at; st.hi = (uint32_t)(at >> 32); st.nrec = (uint32_t)keys.size();
-              for (size_t i = 0; i < keys.size(); ++i)
-                g.sorted_recs[at + i] = SortRec8{(uint32_t)(keys[i] >> 32), (uint32_t)keys[i]};
-            }
-          }, 1);
+          g.sorted_per_super = per_super; g.sorted_slots = slots;
+          // the default layout: every launch's query tiles and evidence tiles on their own (an
+          // inference sweep launches over the query part only), full rounds first
+          std::vector<std::pair<uint32_t, uint32_t>> ranges;
+          for (uint64_t l = 0; l < nl; ++l) {
+            ranges.push_back({g.launch_tile[l], g.launch_query_tile_end[l]});
+            ranges.push_back({g.launch_query_tile_end[l], g.launch_tile[l + 1]});
+          }
+          SortedLayout lay;
+          build_sorted_layout(g, ranges, per_super, slots, true, nth, lay);
+          g.supers.swap(lay.supers);
+          g.sorted_recs = std::move(lay.recs);
+          g.n_sorted = lay.n;
+          if (g.supers.empty()) { g.sort_dvals.clear(); g.sort_dbits.clear(); }
         }
       }
     }

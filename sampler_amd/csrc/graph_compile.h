@@ -12,6 +12,7 @@
 
 #include <stdint.h>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/dwx.h"
@@ -53,7 +54,9 @@ struct CompiledGraph {
   RawArray<SortRec8> sorted_recs;   // [n_sorted] or empty
   std::vector<SuperTile> supers;    // ascending tile0; a super-tile never crosses a launch or its query end
   std::vector<double> sort_dvals;   // distinct (sign(hit) - sign(miss)) * f values, [0] = 0.0
+  std::vector<uint32_t> sort_dbits; // ... their f32 bit patterns, ascending (entry i <-> sort_dvals[i + 1])
   uint64_t n_sorted = 0;
+  uint32_t sorted_per_super = 0, sorted_slots = 0;   // the layout's parameters (0: no sorted copy)
   std::vector<double> edge_fval64; // [NIdx] or empty
   std::vector<VifRec> vifs;        // [NVif]
   std::vector<uint32_t> tile_v;       // [n_tiles+1]
@@ -74,6 +77,16 @@ struct CompiledGraph {
 
   uint64_t device_bytes() const;
 };
+
+// A weight-sorted layout: super-tiles + their sorted records (the graph's default one lives in
+// CompiledGraph; a split mini-batch plan builds one per level, cut along its chunks).
+struct SortedLayout {
+  std::vector<SuperTile> supers;
+  RawArray<SortRec8> recs;
+  uint64_t n = 0;
+};
+void build_sorted_layout(const CompiledGraph &g, const std::vector<std::pair<uint32_t, uint32_t>> &ranges,
+                         uint32_t per_super, uint32_t slots, bool full_rounds, uint32_t n_threads, SortedLayout &out);
 
 // Throws std::runtime_error (message for dwx_last_error) on malformed input;
 // `limit` is set when the failure is a 32-bit layout limit.

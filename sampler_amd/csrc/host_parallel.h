@@ -41,6 +41,15 @@ class RawArray {
   explicit RawArray(size_t n) { reset(n); }
   RawArray(const RawArray &) = delete;
   RawArray &operator=(const RawArray &) = delete;
+  RawArray(RawArray &&o) noexcept : p_(o.p_), n_(o.n_), mapped_(o.mapped_) { o.p_ = nullptr; o.n_ = 0; o.mapped_ = 0; }
+  RawArray &operator=(RawArray &&o) noexcept {
+    if (this != &o) {
+      release();
+      p_ = o.p_; n_ = o.n_; mapped_ = o.mapped_;
+      o.p_ = nullptr; o.n_ = 0; o.mapped_ = 0;
+    }
+    return *this;
+  }
   ~RawArray() { release(); }
   void reset(size_t n) {
     release();

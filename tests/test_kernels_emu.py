@@ -114,6 +114,20 @@ def test_weight_sorted_super_tiles(lib, monkeypatch, min_w):
     s, _ = run_parity(lib, synthetic.cfg3(6000, n_weights=1200, seed=6), n_learn=3, n_infer=2, stepsize=0.5,
                       compile_opts=dict(tile_vars=32, super_tiles=6))
     assert want(s) and s.sgd_plan(0.5)[0] > 1
+    if min_w == 0:
+        # ... and with chunks big enough for super-tiles of their own (8 tiles x sorted_slots and
+        # more): the plan level builds a layout cut ALONG its chunks, every chunk is one launch of
+        # the sorted kernel and nothing is left to the tile sweep
+        raw = synthetic.cfg3(6000, n_weights=1200, seed=6)
+        s, _ = run_parity(lib, raw, n_learn=3, n_infer=2, stepsize=0.5, decay=1.0, step_cap=48.0,
+                          compile_opts=dict(tile_vars=32, super_tiles=6, sorted_slots=2))
+        batches, n_chunks, _ = s.sgd_plan(0.5)
+        assert batches > 1 and s.graph.info.num_tiles // n_chunks >= 16
+        s.kernel_time_reset(True)
+        s.sample_sgd(0.5); s.wait()
+        _, launches, sweeps = s.kernel_time("learn")
+        assert sweeps == 1 and launches == n_chunks, (launches, n_chunks)
+        s.kernel_time_reset(False)
     # categorical rows stay with the tile sweep (config 4's shape beside boolean variables)
     raw = random_graph(33, V=600, F=4000, W=1300, max_arity=1, exact_fvals=True, p_cat=0.4)
     s, _ = run_parity(lib, raw, n_learn=3, n_infer=3, compile_opts=dict(tile_vars=32, super_tiles=3))
