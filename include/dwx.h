@@ -120,6 +120,12 @@ typedef struct dwx_graph_info {
                                   edge-parallel while the tile is staged  */
   uint64_t num_super_tiles;    /* weight-sorted super-tiles (sorted_sweep_kernel) and the records of */
   uint64_t num_sorted_records; /* their sorted second copy; 0: no sorted copy             */
+  /* Multi-GPU drivers: on an all-boolean all-unary graph every contribution to DWX_BUF_GRAD's
+   * gradient sums is a multiple of 2^grad_shift (fixed point 2^-30), at most grad_unit_max such
+   * units, and no weight has more than max_records_per_weight records -- so the sums may travel as
+   * 32-bit counts (G >> grad_shift) while ranks x max_records_per_weight x grad_unit_max < 2^31.
+   * grad_shift == 0: nothing is known (categorical variables, non-unary factors): send int64. */
+  uint64_t grad_shift, grad_unit_max, max_records_per_weight;
 } dwx_graph_info;
 
 /* Runtime options of one sampler (the CmdParser fields the hot path reads:

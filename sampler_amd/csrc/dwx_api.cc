@@ -1229,6 +1229,7 @@ int dwx_graph_get_info(const dwx_graph *g, dwx_graph_info *out) {
   out->num_query_variables = c.n_query;
   out->has_categorical = c.has_categorical; out->order_is_identity = c.order_is_identity;
   out->num_super_tiles = c.supers.size(); out->num_sorted_records = c.n_sorted;
+  out->grad_shift = c.grad_shift; out->grad_unit_max = c.grad_unit_max; out->max_records_per_weight = c.max_records_per_weight;
   return DWX_OK;
 }
 

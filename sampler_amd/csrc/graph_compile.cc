@@ -816,6 +816,32 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
         });
       }
     }
+    // What a multi-GPU driver may assume about the gradient sums (graph_compile.h: grad_shift)
+    g.grad_shift = 0; g.grad_unit_max = 0; g.max_records_per_weight = 0;
+    if (g.edges8.size() && !g.has_categorical && W > 0) {
+      const uint32_t T = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nth, g.NIdx / 65536 + 1));
+      std::vector<uint64_t> all_or(T, 0), qmax(T, 0);
+      std::vector<uint32_t> per_w(W, 0);
+      parallel_parts(g.NIdx, T, [&](uint32_t t, uint64_t eb, uint64_t ee) {
+        uint64_t o = 0, m = 0;
+        for (uint64_t e = eb; e < ee; ++e) {
+          const EdgeRec8 &c = g.edges8[e];
+          const double dv = std::fabs((double)sorted_rec_d(c));
+          if (dv == 0.0 || (c.key & REC8_FIXED)) continue;
+          const uint64_t q = (uint64_t)std::llrint(FIX_SCALE * dv);
+          o |= q; m = std::max(m, q);
+          __atomic_fetch_add(&per_w[c.key & REC8_WID_MASK], 1u, __ATOMIC_RELAXED);
+        }
+        all_or[t] = o; qmax[t] = m;
+      }, 0);
+      uint64_t o = 0, m = 0;
+      for (uint32_t t = 0; t < T; ++t) { o |= all_or[t]; m = std::max(m, qmax[t]); }
+      if (o) {
+        g.grad_shift = (uint32_t)__builtin_ctzll(o);      // (the lowest set bit of any contribution)
+        g.grad_unit_max = m >> g.grad_shift;
+        g.max_records_per_weight = *std::max_element(per_w.begin(), per_w.end());
+      }
+    }
     // Weight-sorted super-tiles over the boolean lane-bin tiles of a compact-record graph.
     g.sorted_recs.clear(); g.supers.clear(); g.sort_dvals.clear(); g.sort_dbits.clear(); g.n_sorted = 0;
     g.sorted_per_super = 0; g.sorted_slots = 0;

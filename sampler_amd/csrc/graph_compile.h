@@ -57,6 +57,12 @@ struct CompiledGraph {
   std::vector<uint32_t> sort_dbits; // ... their f32 bit patterns, ascending (entry i <-> sort_dvals[i + 1])
   uint64_t n_sorted = 0;
   uint32_t sorted_per_super = 0, sorted_slots = 0;   // the layout's parameters (0: no sorted copy)
+  // All-boolean compact-record graphs: every gradient contribution is +-round(2^30 * d_r),
+  // d_r = (sign(hit) - sign(miss)) * f -- a multiple of 2^grad_shift, at most grad_unit_max of
+  // those units, and no weight has more than max_records_per_weight records (a multi-GPU driver
+  // may then all-reduce the gradient sums as 32-bit counts).  grad_shift == 0: not known.
+  uint32_t grad_shift = 0;
+  uint64_t grad_unit_max = 0, max_records_per_weight = 0;
   std::vector<double> edge_fval64; // [NIdx] or empty
   std::vector<VifRec> vifs;        // [NVif]
   std::vector<uint32_t> tile_v;       // [n_tiles+1]

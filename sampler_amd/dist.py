@@ -13,6 +13,8 @@ tallies stay sharded (no collective) and are gathered only for the dump.
 The engine is abstract so that the collective logic is testable on CPU (gloo,
 world_size 2) with an oracle-backed engine living in tests/.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -83,6 +85,8 @@ class HipEngine:
         self._plan_batches, self._dynamic_counts, self._shared_levels = 1, False, set()
         self._level_dynamic = {}      # batches -> agreed "some rank counts dynamically"
         self.comm_timing = None       # CommTiming: device time of the collectives (bench.py)
+        # all-boolean all-unary graphs: the gradient sums travel as 32-bit counts (agree())
+        self._narrow_shift, self._g32, self._g64 = None, None, None
 
     def agree(self, group=None):
         """Once after create: what every rank must decide alike.  A shard without categorical
@@ -93,6 +97,23 @@ class HipEngine:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         self.has_categorical = bool(int(t[0]))
         self.grad_reduced = self.grad if self.has_categorical else self.grad[:self.s.W]
+        # Half the bytes of the gradient all-reduce where the graph allows it (config 3 / 5a: every
+        # contribution is +-2^31, a weight's sum a small count): all ranks must send the same type,
+        # so the shift is the smallest any rank knows and the bound covers the sum over all ranks.
+        info = self.s.graph.info
+        world = dist.get_world_size(group)
+        sh = int(info.grad_shift)
+        t = torch.tensor([-sh if sh > 0 else 0, int(info.grad_unit_max)], dtype=torch.int64, device=self.grad.device)
+        u = torch.tensor([int(info.max_records_per_weight)], dtype=torch.int64, device=self.grad.device)
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)      # (MAX of -shift = -MIN shift; 0 if any rank knows nothing)
+            dist.all_reduce(u, op=dist.ReduceOp.SUM, group=group)      # (>= the largest record count of a weight over all ranks)
+        shift, unit_max, recs = -int(t[0]), int(t[1]), int(u[0])
+        ok = (not self.has_categorical and shift > 0 and unit_max > 0 and recs * unit_max < 2 ** 31
+              and world > 1 and not os.environ.get("DWX_NO_NARROW_ALLREDUCE"))
+        self._narrow_shift = shift if ok else None
+        self._g32 = torch.empty(self.s.W, dtype=torch.int32, device=self.grad.device) if ok else None
+        self._g64 = torch.empty(self.s.W, dtype=torch.int64, device=self.grad.device) if ok else None   # (scratch: no allocation per call)
 
     def allreduce_static_counts(self, group=None):
         """Once after create: every rank only counted its own shard's boolean updates and
@@ -174,11 +195,23 @@ class HipEngine:
     def allreduce_grad(self, group=None):
         with torch.cuda.stream(self.stream):
             t = self.grad if self._dynamic_counts else self.grad_reduced
+            narrow = self._narrow_shift is not None and not self._dynamic_counts
+            if narrow:
+                # (exact: every sum is a multiple of 2^shift by construction; DWX_CHECK_NARROW=1 verifies)
+                g64, sh = t, self._narrow_shift
+                if os.environ.get("DWX_CHECK_NARROW"):
+                    assert bool(torch.equal((g64 >> sh) << sh, g64)), "a gradient sum is not a multiple of 2^%d" % sh
+                torch.bitwise_right_shift(g64, sh, out=self._g64)
+                self._g32.copy_(self._g64)
+                t = self._g32
             if self.comm_timing is not None:
                 self.comm_timing.begin("allreduce", self.stream, t.numel() * t.element_size())
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             if self.comm_timing is not None:
                 self.comm_timing.end("allreduce", self.stream)
+            if narrow:
+                self._g64.copy_(self._g32)
+                torch.bitwise_left_shift(self._g64, sh, out=g64)
 
     # ---- replicas (the reference's n_datacopy) ----
     def sample_sgd(self, stepsize):

@@ -57,7 +57,8 @@ class GraphInfo(C.Structure):
         "num_index_entries", "num_vif_entries", "num_colors", "num_launches", "num_tiles",
         "num_giant_tiles", "max_cardinality", "num_query_variables", "device_bytes")] + [
         ("has_categorical", C.c_uint32), ("order_is_identity", C.c_uint32), ("num_wide_tiles", C.c_uint64),
-        ("num_staged_tiles", C.c_uint64), ("num_super_tiles", C.c_uint64), ("num_sorted_records", C.c_uint64)]
+        ("num_staged_tiles", C.c_uint64), ("num_super_tiles", C.c_uint64), ("num_sorted_records", C.c_uint64),
+        ("grad_shift", C.c_uint64), ("grad_unit_max", C.c_uint64), ("max_records_per_weight", C.c_uint64)]
 
 
 class Options(C.Structure):

@@ -40,6 +40,7 @@ class RecordingEngine(HipEngine):
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out, total, W, stepsize = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])
+    os.environ["DWX_CHECK_NARROW"] = "1"
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mixed = os.environ.get("DWX_TEST_MIXED") == "1"
@@ -53,6 +54,11 @@ def main():
     assert drv.distributed
     if mixed:      # ... and the engines agreed on the whole graph's
         assert eng.has_categorical and eng.grad_reduced.numel() == 2 * W
+        assert eng._narrow_shift is None           # (counts and truthiness-weighted sums travel as int64)
+    else:
+        # all-boolean all-unary shards: the gradient sums travel as 32-bit counts (every contribution
+        # is +-2^31: dist.HipEngine.agree), verified exact on every call (DWX_CHECK_NARROW)
+        assert eng._narrow_shift == 31 and eng._g32 is not None
     drv.learn()
     s.clear_tallies()
     drv.inference()
