@@ -151,6 +151,32 @@ def test_weight_sorted_super_tiles(lib, monkeypatch, min_w):
         assert s.graph.info.num_super_tiles > 0
 
 
+def test_gradient_unit_reported_for_multi_gpu_drivers(lib):
+    """dwx_graph_info.grad_shift / grad_unit_max / max_records_per_weight (what lets
+    sampler_amd.dist send the gradient all-reduce as 32-bit counts): ISTRUE with f = 1 moves a
+    potential by d = 2, i.e. 2^31 in the 2^-30 fixed point of the gradient sums; mixed feature
+    values lower the common power of two; categorical variables or non-unary factors: unknown (0).
+    And the sums a learning sweep leaves in DWX_BUF_GRAD are indeed multiples of it."""
+    from randgraph import random_graph
+    raw = synthetic.cfg3(2000, n_weights=300, seed=3)
+    g = dwx.Graph(raw, lib=lib)
+    assert (g.info.grad_shift, g.info.grad_unit_max) == (31, 1)
+    per_w = np.bincount(raw.fac_weight_id.astype(np.int64), minlength=300)
+    assert g.info.max_records_per_weight == per_w.max()
+    raw.fac_feature_value[::3] = 0.75       # d = 1.5 = 3 * 2^-1  ->  q = 3 * 2^29
+    g2 = dwx.Graph(raw, lib=lib)
+    assert (g2.info.grad_shift, g2.info.grad_unit_max) == (29, 4)
+    assert dwx.Graph(synthetic.cfg4(500, card=4, learn=True), lib=lib).info.grad_shift == 0
+    assert dwx.Graph(synthetic.cfg3b(600, n_weights=50), lib=lib).info.grad_shift == 0
+    s = dwx.GibbsSampler(g2, seed=5, step_cap=0.0)
+    s.sgd_plan(0.01)
+    s.sgd_accumulate(0); s.wait()
+    ptr, nbytes = s.device_buffer(dwx.BUF_GRAD)
+    grad = np.frombuffer((__import__("ctypes").c_char * nbytes).from_address(ptr), np.int64)[:300].copy()
+    s.sgd_apply(); s.sgd_finish(); s.wait()
+    assert np.any(grad != 0) and np.all(grad % (1 << 29) == 0)
+
+
 @pytest.mark.parametrize("block_tiles, depth_hint", [(8, 1), (32, 2), (1024, 2)])
 def test_block_pull(lib, monkeypatch, block_tiles, depth_hint):
     # pull_ell_kernel (un-split sweeps of graphs with many weights; here forced onto a small
