@@ -256,6 +256,14 @@ int dwx_sgd_get_chunks(dwx_sampler *s, uint64_t *chunk_range);
 int dwx_sgd_accumulate_async(dwx_sampler *s, uint32_t chunk);
 int dwx_sgd_apply_async(dwx_sampler *s);
 int dwx_sgd_finish(dwx_sampler *s);
+/* Multi-GPU (shards), between dwx_sgd_accumulate_async and dwx_sgd_apply_async, when every rank's
+ * dwx_graph_info.grad_shift allows it: the gradient sums G[0, W) of DWX_BUF_GRAD as 32-bit counts
+ * (int32)(G[i] >> shift) in a device buffer of the library (*dev32, *n elements) for the caller's
+ * all-reduce -- half the bytes of the int64 vector -- and back, G[i] = (int64)count << shift.
+ * Replaces nothing in the reference (its replicas average weights once per epoch,
+ * src/dimmwitted.cc:209-216); dwx_wait fails if a sum was not a multiple of 2^shift or did not fit. */
+int dwx_grad_pack32_async(dwx_sampler *s, uint32_t shift, void **dev32, uint64_t *n);
+int dwx_grad_unpack32_async(dwx_sampler *s, uint32_t shift);
 
 /* infrs.weight_values access (src/dimmwitted.cc:209-216 merge/average, :245-258 dump) */
 int dwx_get_weights(dwx_sampler *s, double *out);

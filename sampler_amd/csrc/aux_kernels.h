@@ -329,6 +329,26 @@ build_terms8_kernel(const EdgeRec8 *edges8, uint64_t n, const float *w32, unsign
   }
 }
 
+// Multi-GPU, all-boolean all-unary graphs: every contribution to a gradient sum is a multiple of
+// 2^shift (dwx_graph_info.grad_shift), so the sums travel through the all-reduce as 32-bit counts
+// -- half the bytes -- and come back shifted.  `bad` is raised if a sum is not such a multiple or
+// does not fit (it never is by construction; dwx_wait reports it).
+__global__ void __launch_bounds__(BLOCK_THREADS)
+grad_pack32_kernel(const long long *grad, int *out, uint32_t W, uint32_t shift, uint32_t *bad) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride) {
+    const long long g = grad[i], v = g >> shift;
+    if ((long long)((unsigned long long)v << shift) != g || v != (long long)(int)v) atomicAdd(bad, 1u);
+    out[i] = (int)v;
+  }
+}
+__global__ void __launch_bounds__(BLOCK_THREADS)
+grad_unpack32_kernel(const int *in, long long *grad, uint32_t W, uint32_t shift) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride)
+    grad[i] = (long long)((unsigned long long)(long long)in[i] << shift);
+}
+
 // f64 master weights -> f32 sampling copy (after dwx_set_weights)
 __global__ void __launch_bounds__(BLOCK_THREADS)
 refresh_w32_kernel(const double *weights, float *w32, uint32_t W) {

@@ -298,6 +298,8 @@ class Rank {
   uint64_t W_ = 0;
   void *d_grad_ = nullptr, *d_weights_ = nullptr, *d_tallies_ = nullptr;
   bool has_categorical_ = false;
+  bool narrow_ = false;           // the gradient all-reduce travels as 32-bit counts
+  uint32_t narrow_shift_ = 0;
   std::vector<Peer> send_, recv_;
   std::map<uint32_t, double> lam_;
   std::map<uint32_t, uint32_t> level_chunks_;
@@ -356,6 +358,21 @@ void Rank::setup() {
     // what every rank must decide alike (a block without categorical variables next to one
     // with them must not reduce W elements against the other's 2 W)
     has_categorical_ = sh_.agree->max_u64(rank_, info_.has_categorical) != 0;
+    // The gradient sums as 32-bit counts (half the bytes of every all-reduce) where every rank's
+    // graph allows it (dwx_graph_info.grad_shift: all-boolean all-unary blocks): the smallest shift
+    // any rank knows, and the bound covers the sum over all ranks.
+    {
+      const uint64_t sh = info_.grad_shift;
+      const uint64_t m = sh_.agree->max_u64(rank_, sh ? 64 - sh : 64);          // (64 - min shift; 64: some rank knows nothing)
+      const uint64_t unit = sh_.agree->max_u64(rank_, info_.grad_unit_max);
+      const uint64_t recs = sh_.agree->max_u64(rank_, info_.max_records_per_weight) * (uint64_t)sh_.world;
+      narrow_shift_ = (uint32_t)(64 - m);
+      narrow_ = !has_categorical_ && narrow_shift_ > 0 && unit > 0 && recs * unit < (1ull << 31) && sh_.world > 1 &&
+                !getenv("DWX_NO_NARROW_ALLREDUCE");
+      if (root() && !args_.should_be_quiet)
+        std::cout << "Gradient all-reduce: " << (narrow_ ? "32-bit counts, shift " + std::to_string(narrow_shift_) : std::string("int64 sums"))
+                  << std::endl;
+    }
     // each rank counted its own block's boolean updates and curvature bounds: sum [T | h] once
     void *ts = nullptr;
     ok(dwx_device_buffer(s_, DWX_BUF_TSTATIC, &ts, &nb));
@@ -511,7 +528,16 @@ void Rank::learn_shards() {
       if (batches > 1 || c + 1 == n_chunks) {
         // [G | T]: the counts T travel only when somebody counts dynamically (categorical
         // variables; split plans without tables)
-        if (W_) sh_.comm->allreduce_sum_i64(rank_, s_, d_grad_, (has_categorical_ || dynamic_now_) ? 2 * W_ : W_);
+        if (W_ && narrow_ && !dynamic_now_) {
+          // (two's complement: the unsigned 32-bit sum of the ranks' signed counts is their signed sum)
+          void *d32 = nullptr;
+          uint64_t n32 = 0;
+          ok(dwx_grad_pack32_async(s_, narrow_shift_, &d32, &n32));
+          sh_.comm->allreduce_sum_u32(rank_, s_, d32, n32);
+          ok(dwx_grad_unpack32_async(s_, narrow_shift_));
+        } else if (W_) {
+          sh_.comm->allreduce_sum_i64(rank_, s_, d_grad_, (has_categorical_ || dynamic_now_) ? 2 * W_ : W_);
+        }
         ok(dwx_sgd_apply_async(s_));
       }
     }

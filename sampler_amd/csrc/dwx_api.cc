@@ -203,6 +203,9 @@ struct dwx_sampler {
   uint32_t cur_chunk = 0;             // last chunk handed to dwx_sgd_accumulate_async
   uint8_t *d_w_fixed = nullptr;
   long long *d_grad = nullptr;
+  int *d_grad32 = nullptr;              // dwx_grad_pack32_async: the gradient sums as 32-bit counts
+  uint32_t *d_pack_bad = nullptr;       // ... and its "not a multiple / does not fit" counter
+  bool pack_check_pending = false;
   KernelParams base{};
   size_t lds_bytes[2] = {0, 0};  // [0] inference kernel, [1] learning kernel
   uint64_t sweep = 0;
@@ -219,6 +222,7 @@ struct dwx_sampler {
     rt::dfree(d_row_ptr); rt::dfree(d_tiles); rt::dfree(d_giant); rt::dfree(d_wide); rt::dfree(d_bgiant); rt::dfree(d_bgiant_piece_off);
     rt::dfree(d_bgiant_decision); rt::dfree(d_bgiant_pieces); rt::dfree(d_bgiant_partial); rt::dfree(d_row_truth); rt::dfree(d_edge_fval64);
     rt::dfree(d_sorted); rt::dfree(d_supers); rt::dfree(d_sort_dvals);
+    rt::dfree(d_grad32); rt::dfree(d_pack_bad);
     rt::dfree(d_edges); rt::dfree(d_edges8); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
     rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_terms); rt::dfree(d_delta);
     rt::dfree(d_w_fixed); rt::dfree(d_grad);
@@ -1638,11 +1642,50 @@ int dwx_sample_sgd_async(dwx_sampler *s, double stepsize) {
   });
 }
 
+int dwx_grad_pack32_async(dwx_sampler *s, uint32_t shift, void **dev32, uint64_t *n) {
+  if (!s || !dev32 || !n) return fail(DWX_E_INVALID, "null argument");
+  if (shift == 0 || shift > 62) return fail(DWX_E_INVALID, "gradient shift out of range (dwx_graph_info.grad_shift)");
+  return guarded([&]() {
+    rt::set_device(s->device);
+    const uint32_t W = (uint32_t)s->cg->W;
+    if (!s->d_grad32) {
+      s->d_grad32 = (int *)rt::dmalloc((size_t)W * 4);
+      s->d_pack_bad = (uint32_t *)rt::dmalloc(4);
+      rt::dmemset(s->d_pack_bad, 0, 4, s->stream);
+    }
+    const unsigned grid = std::max(1u, std::min((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 1024u));
+    rt::launch(grad_pack32_kernel, grid, BLOCK_THREADS, 0, s->stream, (const long long *)s->d_grad, s->d_grad32, W, shift,
+               s->d_pack_bad);
+    s->pack_check_pending = true;
+    *dev32 = s->d_grad32;
+    *n = W;
+  });
+}
+
+int dwx_grad_unpack32_async(dwx_sampler *s, uint32_t shift) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  if (!s->d_grad32) return fail(DWX_E_INVALID, "dwx_grad_unpack32_async without dwx_grad_pack32_async");
+  return guarded([&]() {
+    rt::set_device(s->device);
+    const uint32_t W = (uint32_t)s->cg->W;
+    const unsigned grid = std::max(1u, std::min((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 1024u));
+    rt::launch(grad_unpack32_kernel, grid, BLOCK_THREADS, 0, s->stream, (const int *)s->d_grad32, s->d_grad, W, shift);
+  });
+}
+
 int dwx_wait(dwx_sampler *s) {
   if (!s) return fail(DWX_E_INVALID, "null sampler");
   return guarded([&]() {
     rt::set_device(s->device);
     rt::stream_sync(s->stream);
+    if (s->pack_check_pending) {      // (the 32-bit gradient counts: exact by construction, verified here)
+      uint32_t bad = 0;
+      rt::d2h(&bad, s->d_pack_bad, 4, s->stream);
+      rt::stream_sync(s->stream);
+      s->pack_check_pending = false;
+      if (bad) throw std::runtime_error("dwx_grad_pack32_async: " + std::to_string(bad) +
+                                        " gradient sums were not multiples of 2^shift or did not fit 32 bits");
+    }
   });
 }
 

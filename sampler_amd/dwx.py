@@ -25,7 +25,7 @@ SYMBOLS = [
     "dwx_graph_create", "dwx_graph_destroy", "dwx_graph_get_info", "dwx_graph_get_schedule",
     "dwx_graph_get_values", "dwx_graph_get_fixed_point_mask", "dwx_graph_get_positions", "dwx_graph_get_index",
     "dwx_sampler_create", "dwx_device_init", "dwx_device_count", "dwx_buffer_copy", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
-    "dwx_wait", "dwx_sgd_plan", "dwx_sgd_curvature", "dwx_sgd_plan_rows", "dwx_sgd_plan_force_dynamic", "dwx_sgd_get_chunks", "dwx_sgd_accumulate_async",
+    "dwx_wait", "dwx_sgd_plan", "dwx_sgd_curvature", "dwx_sgd_plan_rows", "dwx_sgd_plan_force_dynamic", "dwx_sgd_get_chunks", "dwx_grad_pack32_async", "dwx_grad_unpack32_async", "dwx_sgd_accumulate_async",
     "dwx_sgd_apply_async", "dwx_sgd_finish",
     "dwx_get_weights", "dwx_set_weights", "dwx_average_weights_async",
     "dwx_clear_tallies", "dwx_get_tallies",
@@ -105,6 +105,8 @@ class Library:
         L.dwx_sgd_curvature.argtypes = [vp, C.c_uint32, vp]
         L.dwx_sgd_plan_force_dynamic.argtypes = [vp, i32]
         L.dwx_sgd_get_chunks.argtypes = [vp, vp]
+        L.dwx_grad_pack32_async.argtypes = [vp, C.c_uint32, vp, vp]
+        L.dwx_grad_unpack32_async.argtypes = [vp, C.c_uint32]
         L.dwx_sgd_accumulate_async.argtypes = [vp, C.c_uint32]
         L.dwx_sgd_apply_async.argtypes = [vp]
         L.dwx_sgd_finish.argtypes = [vp]
