@@ -141,7 +141,7 @@ def test_gradient_travels_as_32_bit_counts_where_the_graph_allows_it(dw_emu):
     rank's (test_shards_of_a_unary_graph_reproduce_the_single_rank_run_byte_for_byte)."""
     for fx, want in (("biased_coin", "32-bit counts, shift 31"), ("biased_coin_with_multinomial", "int64 sums")):
         with tempfile.TemporaryDirectory() as a, tempfile.TemporaryDirectory() as b:
-            common = ["--seed", "11", "--step_cap", "0"]
+            common = ["--seed", "11", "--step_cap", "0", "-l", "150", "-i", "50"]    # (last value wins)
             r1 = run_dw(dw_emu, fx, a, common + ["--quiet"])
             r2 = run_dw(dw_emu, fx, b, common + ["--gpus", "2", "--comm", "host"])
             assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr
