@@ -190,6 +190,8 @@ struct dwx_sampler {
     std::vector<SuperTile> sorted_supers;
     SuperTile *d_supers = nullptr;
     SortRec8 *d_sorted = nullptr;
+    bool layout_done = false;          // ensure_level_layout ran (whatever it decided)
+    uint64_t sweeps = 0;               // learning sweeps run at this level (plan_layouts == 0: the layout comes after 2048)
     ~Level() {
       rt::dfree(d_supers); rt::dfree(d_sorted);
       rt::dfree(d_inc_wid); rt::dfree(d_inc_slot); rt::dfree(d_inc_d); rt::dfree(d_t_static);
@@ -326,7 +328,7 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   bool used_sorted = false;
   if (s->d_supers && !P.edge_terms && (!LEARN || (s->sorted_learn && !(P.flags & (OPT_NO_PULL | OPT_DYNAMIC_T))))) {
     // (a chunk of a split learning sweep: the plan level's own layout, cut along the chunks)
-    const dwx_sampler::Level *lv = (LEARN && s->plan_batches > 1 && s->plan_level && s->plan_level->d_supers) ? s->plan_level : nullptr;
+    const dwx_sampler::Level *lv = (LEARN && s->plan_level && s->plan_level->d_supers) ? s->plan_level : nullptr;
     const std::vector<SuperTile> &sv = lv ? lv->sorted_supers : c.supers;
     const SuperTile *d_sv = lv ? lv->d_supers : s->d_supers;
     const SortRec8 *d_sr = lv ? lv->d_sorted : s->d_sorted;
@@ -536,6 +538,39 @@ void for_each_record_bound(const CompiledGraph &c, uint32_t p, Fn &&fn) {
   }
 }
 
+// A plan level's own weight-sorted layout (Level::sorted_supers): for a split plan cut ALONG its
+// chunks, as many super-tiles per chunk as workgroups are resident; for an un-split sweep, where a
+// launch holds query AND evidence tiles, one run per launch -- the default layout cuts those apart
+// (an inference sweep launches over the query part only), so a learning launch over it ends two
+// runs with a round of small super-tiles each (config 3: learning sweep 0.288 -> 0.269 ms with one).
+// Worth it while a chunk still makes super-tiles of 8 tiles and more.  Costs 0.3 s of host time
+// and a second copy of the records: dwx_options.plan_layouts says when it is built.
+void ensure_level_layout(dwx_sampler *s, dwx_sampler::Level *L, uint32_t batches) {
+  if (L->layout_done) return;
+  L->layout_done = true;
+  const CompiledGraph &c = *s->cg;
+  bool mixed_launch = false;
+  for (size_t l = 0; l + 1 < c.launch_tile.size(); ++l)
+    mixed_launch = mixed_launch || (c.launch_query_tile_end[l] > c.launch_tile[l] && c.launch_query_tile_end[l] < c.launch_tile[l + 1]);
+  if (!(batches > 1 || mixed_launch) || c.supers.empty() || !s->sorted_learn || L->chunks.empty()) return;
+  uint64_t tiles_in_chunks = 0;
+  std::vector<std::pair<uint32_t, uint32_t>> ranges;
+  for (const auto &ch : L->chunks) { ranges.push_back({ch.t0, ch.t1}); tiles_in_chunks += ch.t1 - ch.t0; }
+  if (tiles_in_chunks / L->chunks.size() < 8ull * c.sorted_slots) return;
+  rt::set_device(s->device);
+  SortedLayout lay;
+  build_sorted_layout(c, ranges, c.sorted_per_super, c.sorted_slots, batches == 1, host_threads(), lay);
+  if (lay.supers.empty()) return;
+  // (launch_tiles looks super-tiles up by their first tile: ascending, like the default layout)
+  std::sort(lay.supers.begin(), lay.supers.end(), [](const SuperTile &a, const SuperTile &b) { return a.tile0 < b.tile0; });
+  SortRec8 *d_sorted = upload(lay.recs, s->stream, 1);
+  SuperTile *d_supers = upload(lay.supers, s->stream);
+  rt::stream_sync(s->stream);   // (the host copies die with this scope; the sweeps queued so far used the default layout)
+  L->sorted_supers.swap(lay.supers);
+  L->d_sorted = d_sorted;
+  L->d_supers = d_supers;
+}
+
 // Everything a plan level needs to run its chunks without per-record atomics: per chunk,
 // (a) the static update counts of its boolean variables -- a boolean variable that triggers
 // SGD visits every factor of its row once with t = 1 (src/factor_graph.cc:265-273),
@@ -569,25 +604,7 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
     std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &a, const Piece &b) { return a.at < b.at; });
     for (const Piece &pc : pieces) L->chunks.push_back(pc.ch);
   }
-  // the level's own weight-sorted layout (see Level::sorted_supers): worth it while a chunk still
-  // makes super-tiles of 8 tiles and more; finer plans keep the default layout's whole super-tiles
-  if (batches > 1 && !c.supers.empty() && s->sorted_learn && !L->chunks.empty()) {
-    uint64_t tiles_in_chunks = 0;
-    std::vector<std::pair<uint32_t, uint32_t>> ranges;
-    for (const auto &ch : L->chunks) { ranges.push_back({ch.t0, ch.t1}); tiles_in_chunks += ch.t1 - ch.t0; }
-    if (tiles_in_chunks / L->chunks.size() >= 8ull * c.sorted_slots) {
-      SortedLayout lay;
-      build_sorted_layout(c, ranges, c.sorted_per_super, c.sorted_slots, false, nth, lay);
-      if (!lay.supers.empty()) {
-        // (launch_tiles looks super-tiles up by their first tile: ascending, like the default layout)
-        std::sort(lay.supers.begin(), lay.supers.end(), [](const SuperTile &a, const SuperTile &b) { return a.tile0 < b.tile0; });
-        L->d_sorted = upload(lay.recs, s->stream, 1);
-        L->d_supers = upload(lay.supers, s->stream);
-        rt::stream_sync(s->stream);   // (the host copies die with this scope)
-        L->sorted_supers.swap(lay.supers);
-      }
-    }
-  }
+  if (s->opts.plan_layouts == 1) ensure_level_layout(s, L.get(), batches);
   const uint32_t nc = (uint32_t)L->chunks.size();
   // beyond this the per-chunk tables cost more than they save: such plans keep the
   // per-record atomics and dynamic counts
@@ -1074,6 +1091,11 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
   const dwx_sampler::Chunk &ch = s->plan_chunks[chunk];
   KernelParams P = s->base;
   P.sweep = s->sweep;
+  // a level that has run this many sweeps is worth a layout of its own (dwx_options.plan_layouts
+  // == 0: the run pays 0.3 s once where it has already spent as much on the default layout)
+  constexpr uint64_t LAYOUT_AFTER_SWEEPS = 2048;
+  if (chunk == 0 && s->plan_level && ++s->plan_level->sweeps == LAYOUT_AFTER_SWEEPS && s->opts.plan_layouts == 0)
+    ensure_level_layout(s, s->plan_level, s->plan_batches);
   const dwx_sampler::Level &L = *s->plan_level;
   const bool split = s->plan_batches > 1;
   // a split sweep without per-chunk tables falls back to per-record atomics and counts

@@ -64,7 +64,7 @@ class GraphInfo(C.Structure):
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("sample_evidence", C.c_int32),
                 ("learn_non_evidence", C.c_int32), ("noise_aware", C.c_int32),
-                ("regularization", C.c_int32), ("reserved", C.c_int32),
+                ("regularization", C.c_int32), ("plan_layouts", C.c_int32),
                 ("reg_param", C.c_double), ("step_cap", C.c_double), ("seed", C.c_uint64),
                 ("var_id_offset", C.c_uint64)]
 
@@ -218,7 +218,7 @@ class GibbsSampler:
 
     def __init__(self, graph: Graph, device=0, sample_evidence=False, learn_non_evidence=False,
                  noise_aware=False, regularization="l2", reg_param=0.01, seed=0x5eed5eed,
-                 step_cap=1.5, var_id_offset=0):
+                 step_cap=1.5, var_id_offset=0, plan_layouts=0):
         self.lib = graph.lib
         self.graph = graph
         o = Options()
@@ -231,6 +231,7 @@ class GibbsSampler:
         o.reg_param = float(reg_param)
         o.seed = int(seed)
         o.step_cap = float(step_cap)
+        o.plan_layouts = int(plan_layouts)
         o.var_id_offset = int(var_id_offset)
         self.opts = o
         h = C.c_void_p()

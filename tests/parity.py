@@ -60,7 +60,7 @@ def learn_sweep_both(s, o, order, seed, sweep, stepsize):
 
 def run_parity(lib, raw, n_learn=3, n_infer=5, stepsize=0.05, decay=0.9, seed=77,
                sample_evidence=False, learn_non_evidence=False, noise_aware=False,
-               regularization="l2", reg_param=0.01, step_cap=1.0, compile_opts=None,
+               regularization="l2", reg_param=0.01, step_cap=1.0, compile_opts=None, plan_layouts=0,
                check_index=True, wtol=1e-12):
     """Returns (sampler, oracle) after asserting exact parity of assignments and tallies
     after every sweep and weights within wtol."""
@@ -74,7 +74,7 @@ def run_parity(lib, raw, n_learn=3, n_infer=5, stepsize=0.05, decay=0.9, seed=77
     order, off = g.schedule()
     assert sorted(order.tolist()) == list(range(raw.num_variables - raw.num_ghost_variables))
     assert o.sched_check_independent(order, off), "a launch is not an independent set"
-    s = dwx.GibbsSampler(g, seed=seed, step_cap=step_cap, **kw)
+    s = dwx.GibbsSampler(g, seed=seed, step_cap=step_cap, plan_layouts=plan_layouts, **kw)
     assert np.array_equal(s.assignments("free"), o.assignments("free"))
     assert np.array_equal(s.assignments("evid"), o.assignments("evid"))
     sweep = 0

@@ -119,7 +119,7 @@ def test_weight_sorted_super_tiles(lib, monkeypatch, min_w):
         # more): the plan level builds a layout cut ALONG its chunks, every chunk is one launch of
         # the sorted kernel and nothing is left to the tile sweep
         raw = synthetic.cfg3(6000, n_weights=1200, seed=6)
-        s, _ = run_parity(lib, raw, n_learn=3, n_infer=2, stepsize=0.5, decay=1.0, step_cap=48.0,
+        s, _ = run_parity(lib, raw, n_learn=3, n_infer=2, stepsize=0.5, decay=1.0, step_cap=48.0, plan_layouts=1,
                           compile_opts=dict(tile_vars=32, super_tiles=6, sorted_slots=2))
         batches, n_chunks, _ = s.sgd_plan(0.5)
         assert batches > 1 and s.graph.info.num_tiles // n_chunks >= 16
@@ -128,6 +128,18 @@ def test_weight_sorted_super_tiles(lib, monkeypatch, min_w):
         _, launches, sweeps = s.kernel_time("learn")
         assert sweeps == 1 and launches == n_chunks, (launches, n_chunks)
         s.kernel_time_reset(False)
+        # ... and so does an un-split sweep whose launch holds query and evidence tiles (one run
+        # per launch instead of the default layout's two): one launch per sweep
+        s, _ = run_parity(lib, raw, n_learn=3, n_infer=2, stepsize=0.01, step_cap=0.0, plan_layouts=1,
+                          compile_opts=dict(tile_vars=32, super_tiles=6, sorted_slots=2))
+        s.kernel_time_reset(True)
+        s.sample_sgd(0.01); s.wait()
+        _, launches, sweeps = s.kernel_time("learn")
+        assert sweeps == 1 and launches == 1, launches
+        s.kernel_time_reset(False)
+        # (plan_layouts = 2: never -- the default layout serves, with the tile sweep at the seams)
+        s, _ = run_parity(lib, raw, n_learn=2, n_infer=1, stepsize=0.5, decay=1.0, step_cap=48.0, plan_layouts=2,
+                          compile_opts=dict(tile_vars=32, super_tiles=6, sorted_slots=2))
     # categorical rows stay with the tile sweep (config 4's shape beside boolean variables)
     raw = random_graph(33, V=600, F=4000, W=1300, max_arity=1, exact_fvals=True, p_cat=0.4)
     s, _ = run_parity(lib, raw, n_learn=3, n_infer=3, compile_opts=dict(tile_vars=32, super_tiles=3))
