@@ -37,7 +37,7 @@ const FlagSpec kFlags[] = {
     {"p", "stepsize", true}, {"d", "diminish", true}, {"b", "reg_param", true},
     {"", "regularization", true}, {"q", "quiet", false}, {"", "sample_evidence", false},
     {"", "learn_non_evidence", false}, {"", "noise_aware", false},
-    {"", "device", true}, {"", "seed", true}, {"", "step_cap", true},
+    {"", "device", true}, {"", "seed", true}, {"", "step_cap", true}, {"", "plan_layouts", true},
     {"", "gpus", true}, {"", "devices", true}, {"", "comm", true},
 };
 
@@ -172,6 +172,7 @@ CmdLine parse_cmdline(int argc, const char *const argv[]) {
     else if (n == "device") { if (need_u()) a.device = (int)u; }
     else if (n == "seed") { if (need_u()) a.seed = u; }
     else if (n == "step_cap") { if (need_d()) a.step_cap = d; }
+    else if (n == "plan_layouts") { if (need_u()) a.plan_layouts = (int)u; }
     else if (n == "gpus") { if (need_u()) a.gpus = (int)u; }
     else if (n == "comm") {
       if (val != "rccl" && val != "host") { ++a.num_errors; err << "PARSE ERROR: Argument: --comm\n             must be rccl or host\n"; }
@@ -614,6 +615,7 @@ int gibbs(const CmdLine &args) {
     o.reg_param = args.reg_param;
     o.seed = args.seed;
     o.step_cap = args.step_cap;
+    o.plan_layouts = args.plan_layouts;
     hip_start.join();
     ok(dwx_sampler_create(graph, &o, &sampler));
     phase("dwx_sampler_create (upload, gradient incidence list, curvature estimate)");

@@ -39,6 +39,7 @@ struct CmdLine {
   int device = 0;
   uint64_t seed = 0x5eed5eedULL;
   double step_cap = 1.5;
+  int plan_layouts = 0;        // dwx_options.plan_layouts (0: after 2048 sweeps, 1: at once, 2: never)
   int gpus = 0;                 // --gpus N: variable-block shards over N GPUs (dw_multi.h)
   std::vector<int> devices;     // --devices a,b,...: the ranks' HIP devices (default 0..N-1)
   std::string comm = "rccl";    // --comm rccl | host (host-staged sums: a test stand-in)

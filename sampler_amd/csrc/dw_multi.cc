@@ -319,6 +319,7 @@ void Rank::setup() {
   o.regularization = args_.regularization_l1 ? 0 : 1;
   o.reg_param = args_.reg_param;
   o.step_cap = args_.step_cap;
+  o.plan_layouts = args_.plan_layouts;
   (void)dwx_device_init(o.device);
   if (sh_.replicas) {
     graph_ = sh_.replica_graph;

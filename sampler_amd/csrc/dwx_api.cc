@@ -1093,7 +1093,8 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
   P.sweep = s->sweep;
   // a level that has run this many sweeps is worth a layout of its own (dwx_options.plan_layouts
   // == 0: the run pays 0.3 s once where it has already spent as much on the default layout)
-  constexpr uint64_t LAYOUT_AFTER_SWEEPS = 2048;
+  uint64_t LAYOUT_AFTER_SWEEPS = 2048;
+  if (const char *e = getenv("DWX_LAYOUT_AFTER_SWEEPS")) LAYOUT_AFTER_SWEEPS = (uint64_t)std::max(1L, atol(e));   // test hook
   if (chunk == 0 && s->plan_level && ++s->plan_level->sweeps == LAYOUT_AFTER_SWEEPS && s->opts.plan_layouts == 0)
     ensure_level_layout(s, s->plan_level, s->plan_batches);
   const dwx_sampler::Level &L = *s->plan_level;

@@ -137,6 +137,16 @@ def test_weight_sorted_super_tiles(lib, monkeypatch, min_w):
         _, launches, sweeps = s.kernel_time("learn")
         assert sweeps == 1 and launches == 1, launches
         s.kernel_time_reset(False)
+        # the default policy builds the level's layout once the level has run 2048 sweeps (here: 3,
+        # test hook) -- in the middle of a run, with the same results before and after the switch
+        monkeypatch.setenv("DWX_LAYOUT_AFTER_SWEEPS", "3")
+        s, _ = run_parity(lib, raw, n_learn=6, n_infer=2, stepsize=0.5, decay=1.0, step_cap=48.0,
+                          compile_opts=dict(tile_vars=32, super_tiles=6, sorted_slots=2))
+        s.kernel_time_reset(True)
+        s.sample_sgd(0.5); s.wait()
+        assert s.kernel_time("learn")[1] == s.sgd_plan(0.5)[1]          # (one launch per chunk: the layout is in)
+        s.kernel_time_reset(False)
+        monkeypatch.delenv("DWX_LAYOUT_AFTER_SWEEPS")
         # (plan_layouts = 2: never -- the default layout serves, with the tile sweep at the seams)
         s, _ = run_parity(lib, raw, n_learn=2, n_infer=1, stepsize=0.5, decay=1.0, step_cap=48.0, plan_layouts=2,
                           compile_opts=dict(tile_vars=32, super_tiles=6, sorted_slots=2))
