@@ -158,6 +158,10 @@ constexpr uint32_t TILE_WIDE = 1u << 6;
 // take the pull gradient of TILE_PULL tiles -- the sweep publishes the variables' ballots, the
 // incidence lists hold those records -- and only the non-unary records scatter atomics
 constexpr uint32_t TILE_PULL_UNARY = 1u << 8;
+// every value row of the tile holds exactly ONE record (config 4's shape: one unary factor per
+// (variable, value)): row r of the tile starts at record e0 + r, the sweeps make the row pointers
+// up instead of loading them (a quarter of config 4's traffic)
+constexpr uint32_t TILE_UNIT_ROWS = 1u << 9;
 constexpr uint32_t TILE_OUTSIDE = TILE_GIANT | TILE_WIDE;
 constexpr uint32_t WIDE_MIN_RECORDS_DEFAULT = 192;
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");

@@ -701,7 +701,9 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
         }
       const bool giant = t.nrows > g.rcap || t.nedges > g.ecap;
       const uint32_t outside = giant ? TILE_GIANT : (tile_wide[i] ? TILE_WIDE : 0u);
-      t.flags = (simple ? TILE_SIMPLE : 0u) | (cat ? TILE_CATEGORICAL : 0u) | outside |
+      bool unit_rows = t.nrows == t.nedges && t.nrows > 0;
+      for (uint32_t r = 0; r < t.nrows && unit_rows; ++r) unit_rows = g.row_ptr[t.r0 + r + 1] - g.row_ptr[t.r0 + r] == 1;
+      t.flags = (simple ? TILE_SIMPLE : 0u) | (cat ? TILE_CATEGORICAL : 0u) | outside | (unit_rows ? TILE_UNIT_ROWS : 0u) |
                 ((simple && !cat && W > LDS_AGG_MAX_W && !outside) ? TILE_PULL : 0u) |
                 ((terms2 && !simple && !cat && t.nv <= 256 && !outside) ? TILE_TERMS2 : 0u) |
                 ((terms3 && !simple && (cat ? cat_terms3 : !terms2) && t.nv <= 256 && !outside) ? TILE_TERMS3 : 0u);

@@ -103,10 +103,15 @@ template <bool LEARN, int K, bool NT = true, class Rec, int RP>
 DWX_DEV void issue_tile_loads(const KernelParams &P, const TileDesc &d, uint32_t t,
                               TilePrefetch<K, Rec, RP> &f, const bool pair = false) {
   issue_record_loads<LEARN, K>(P, d, t, f.rec);
+  if (d.flags & TILE_UNIT_ROWS) {   // workgroup-uniform: one record per row, nothing to load
 #pragma unroll
-  for (uint32_t k = 0; k < (uint32_t)RP; ++k) {
-    const uint32_t *rp = &P.row_ptr[d.r0 + umin(t + k * BLOCK_THREADS, d.nrows)];
-    f.rp[k] = NT ? DWX_NT_LOAD(rp) : *rp;
+    for (uint32_t k = 0; k < (uint32_t)RP; ++k) f.rp[k] = d.e0 + umin(t + k * BLOCK_THREADS, d.nrows);
+  } else {
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)RP; ++k) {
+      const uint32_t *rp = &P.row_ptr[d.r0 + umin(t + k * BLOCK_THREADS, d.nrows)];
+      f.rp[k] = NT ? DWX_NT_LOAD(rp) : *rp;
+    }
   }
   f.pre = load_var_pre<LEARN, NT>(P, d.v0 + umin(pair ? t >> 1 : t, d.nv - 1));
 }
@@ -417,7 +422,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
 #pragma unroll
       for (uint32_t k = 0; k < ROWPTR_UNROLL; ++k) s_rowptr[t + k * BLOCK_THREADS] = f.rp[k];
       for (uint32_t i = t + ROWPTR_UNROLL * BLOCK_THREADS; i <= d.nrows; i += BLOCK_THREADS)
-        s_rowptr[i] = P.row_ptr[d.r0 + i];
+        s_rowptr[i] = (d.flags & TILE_UNIT_ROWS) ? d.e0 + i : P.row_ptr[d.r0 + i];
       __syncthreads();
     }
     // Prefetch, unconditionally and branch-free (a conditional prefetch makes the
@@ -601,7 +606,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
 #pragma unroll
       for (uint32_t k = 0; k < (uint32_t)RP; ++k) s_rowptr[t + k * BLOCK_THREADS] = f.rp[k];
       for (uint32_t i = t + RP * BLOCK_THREADS; i <= d.nrows; i += BLOCK_THREADS)
-        s_rowptr[i] = P.row_ptr[d.r0 + i];
+        s_rowptr[i] = (d.flags & TILE_UNIT_ROWS) ? d.e0 + i : P.row_ptr[d.r0 + i];
       __syncthreads();
     }
     // prefetch, unconditionally and branch-free (see sweep_kernel): the descriptor two tiles
