@@ -365,9 +365,12 @@ void Rank::setup() {
     {
       const uint64_t sh = info_.grad_shift;
       const uint64_t m = sh_.agree->max_u64(rank_, sh ? 64 - sh : 64);          // (64 - min shift; 64: some rank knows nothing)
-      const uint64_t unit = sh_.agree->max_u64(rank_, info_.grad_unit_max);
+      // (the largest contribution in fixed-point units: ranks may know different shifts, the
+      // count bound is taken at the common one)
+      const uint64_t qmax = sh_.agree->max_u64(rank_, info_.grad_unit_max << sh);
       const uint64_t recs = sh_.agree->max_u64(rank_, info_.max_records_per_weight) * (uint64_t)sh_.world;
       narrow_shift_ = (uint32_t)(64 - m);
+      const uint64_t unit = narrow_shift_ > 0 ? qmax >> narrow_shift_ : 0;
       narrow_ = !has_categorical_ && narrow_shift_ > 0 && unit > 0 && recs * unit < (1ull << 31) && sh_.world > 1 &&
                 !getenv("DWX_NO_NARROW_ALLREDUCE");
       if (root() && !args_.should_be_quiet)

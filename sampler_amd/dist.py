@@ -103,12 +103,15 @@ class HipEngine:
         info = self.s.graph.info
         world = dist.get_world_size(group)
         sh = int(info.grad_shift)
-        t = torch.tensor([-sh if sh > 0 else 0, int(info.grad_unit_max)], dtype=torch.int64, device=self.grad.device)
+        # (the largest contribution in fixed-point units, not in units of this rank's own shift:
+        # ranks may know different shifts, the count bound is taken at the common one)
+        t = torch.tensor([-sh if sh > 0 else 0, int(info.grad_unit_max) << sh], dtype=torch.int64, device=self.grad.device)
         u = torch.tensor([int(info.max_records_per_weight)], dtype=torch.int64, device=self.grad.device)
         with torch.cuda.stream(self.stream):
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)      # (MAX of -shift = -MIN shift; 0 if any rank knows nothing)
             dist.all_reduce(u, op=dist.ReduceOp.SUM, group=group)      # (>= the largest record count of a weight over all ranks)
-        shift, unit_max, recs = -int(t[0]), int(t[1]), int(u[0])
+        shift, recs = -int(t[0]), int(u[0])
+        unit_max = (int(t[1]) >> shift) if shift > 0 else 0
         ok = (not self.has_categorical and shift > 0 and unit_max > 0 and recs * unit_max < 2 ** 31
               and world > 1 and not os.environ.get("DWX_NO_NARROW_ALLREDUCE"))
         self._narrow_shift = shift if ok else None
