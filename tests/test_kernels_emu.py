@@ -105,20 +105,20 @@ def test_weight_sorted_super_tiles(lib, monkeypatch, min_w):
         s, _ = run_parity(lib, raw, n_learn=3, n_infer=3, stepsize=0.05, sample_evidence=True,
                           compile_opts=dict(tile_vars=9, tile_edges=48, tile_rows=12, super_tiles=5))
         assert want(s)
-    s, _ = run_parity(lib, synthetic.cfg3(4000, n_weights=3000, seed=4), n_learn=3, n_infer=3)
+    s, _ = run_parity(lib, synthetic.cfg3(3000, n_weights=3000, seed=4), n_learn=2, n_infer=2)
     assert want(s)
     # few weights: inference sorted, learning through the tile sweep's LDS accumulators
     s, _ = run_parity(lib, synthetic.cfg3(3000, n_weights=40, seed=5), n_learn=3, n_infer=3, compile_opts=dict(tile_vars=64))
     assert want(s)
     # a split sweep: chunks cut inside super-tiles
-    s, _ = run_parity(lib, synthetic.cfg3(6000, n_weights=1200, seed=6), n_learn=3, n_infer=2, stepsize=0.5,
+    s, _ = run_parity(lib, synthetic.cfg3(3200, n_weights=1200, seed=6), n_learn=3, n_infer=2, stepsize=0.5,
                       compile_opts=dict(tile_vars=32, super_tiles=6))
     assert want(s) and s.sgd_plan(0.5)[0] > 1
     if min_w == 0:
         # ... and with chunks big enough for super-tiles of their own (8 tiles x sorted_slots and
         # more): the plan level builds a layout cut ALONG its chunks, every chunk is one launch of
         # the sorted kernel and nothing is left to the tile sweep
-        raw = synthetic.cfg3(6000, n_weights=1200, seed=6)
+        raw = synthetic.cfg3(3200, n_weights=1200, seed=6)
         s, _ = run_parity(lib, raw, n_learn=3, n_infer=2, stepsize=0.5, decay=1.0, step_cap=48.0, plan_layouts=1,
                           compile_opts=dict(tile_vars=32, super_tiles=6, sorted_slots=2))
         batches, n_chunks, _ = s.sgd_plan(0.5)
@@ -140,7 +140,7 @@ def test_weight_sorted_super_tiles(lib, monkeypatch, min_w):
         # the default policy builds the level's layout once the level has run 2048 sweeps (here: 3,
         # test hook) -- in the middle of a run, with the same results before and after the switch
         monkeypatch.setenv("DWX_LAYOUT_AFTER_SWEEPS", "3")
-        s, _ = run_parity(lib, raw, n_learn=6, n_infer=2, stepsize=0.5, decay=1.0, step_cap=48.0,
+        s, _ = run_parity(lib, raw, n_learn=5, n_infer=1, stepsize=0.5, decay=1.0, step_cap=48.0,
                           compile_opts=dict(tile_vars=32, super_tiles=6, sorted_slots=2))
         s.kernel_time_reset(True)
         s.sample_sgd(0.5); s.wait()
@@ -159,7 +159,7 @@ def test_weight_sorted_super_tiles(lib, monkeypatch, min_w):
         # atomics: such sweeps stay with the tile sweep (the sorted kernel only publishes ballots),
         # inference sweeps of the same sampler take the sorted one
         monkeypatch.setenv("DWX_PLAN_TABLE_CHUNKS", "1")
-        s, _ = run_parity(lib, synthetic.cfg3(6000, n_weights=1200, seed=7), n_learn=3, n_infer=2, stepsize=0.5,
+        s, _ = run_parity(lib, synthetic.cfg3(3200, n_weights=1200, seed=7), n_learn=3, n_infer=2, stepsize=0.5,
                           compile_opts=dict(tile_vars=32, super_tiles=6))
         assert want(s) and s.sgd_plan(0.5)[0] > 1
         monkeypatch.delenv("DWX_PLAN_TABLE_CHUNKS")
