@@ -1,5 +1,6 @@
 // dw_cli.cc -- see dw_cli.h.  Plain C++17; talks to the sampler only through the C ABI.
 #include "dw_cli.h"
+#include "dw_multi.h"
 
 #include "host_parallel.h"
 
@@ -9,6 +10,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -17,6 +19,7 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 
@@ -471,6 +474,227 @@ void load_factors(const std::vector<std::string> &files, LoadedGraph &g) {
   if (e_base != g.n_edges)
     throw std::runtime_error("edge count " + std::to_string(e_base) + " != meta " + std::to_string(g.n_edges));
   g.fac_edge_offset[g.n_factors] = g.n_edges;
+}
+
+// ------------------------------------------------------------------ sharded loader
+// `dw gibbs --gpus N` (dw_multi.cc): the factor files are decoded ONCE, straight into the
+// ranks' shard graphs -- no whole-graph factor columns in between (config 5's 10^9 factors:
+// 42 GB of file become 8 shards of a ninth each instead of 60 GB of columns + the shards).
+// Same reading of the format as load_factors (src/binary_format.cc:128-190: factor ids in
+// read order, so a shard's factors keep their relative order), same cut into pieces, same
+// errors.  Pass 1 walks every piece, counts per (piece, rank) the factors that touch the
+// rank's block and their edges, and collects the ranks' ghosts; pass 2 walks the pieces again
+// and copies, ids renumbered (owned: id - begin, ghosts behind them in ascending global id).
+namespace {
+struct Cut { std::vector<Piece> pieces; uint64_t n_rec = 0, n_edge = 0; };
+
+// every record has the arity of the first one (to be verified by the walk)?
+bool cut_fixed(const Mapped &m, uint64_t f_base, uint64_t e_base, Cut &c) {
+  const uint64_t kPiece = 1 << 16;
+  c = Cut();
+  const uint64_t a0 = be64(m.p + 2);
+  if (a0 > (m.n - 10) / 16) return false;
+  const size_t rs = 26 + 16 * a0;
+  if (m.n % rs != 0) return false;
+  const uint64_t n = m.n / rs;
+  for (uint64_t r = 0; r < n; r += kPiece) {
+    const uint64_t k = std::min(kPiece, n - r);
+    c.pieces.push_back({(size_t)(r * rs), k, f_base + r, e_base + r * a0, (size_t)((r + k) * rs)});
+  }
+  c.n_rec = n; c.n_edge = n * a0;
+  return true;
+}
+
+// hop from record to record reading only the arity
+void cut_hop(const Mapped &m, const std::string &path, uint64_t f_base, uint64_t e_base, Cut &c) {
+  const uint64_t kPiece = 1 << 16;
+  c = Cut();
+  size_t off = 0;
+  uint64_t f = f_base, e = e_base;
+  Piece cur{0, 0, f, e, 0};
+  while (off < m.n) {
+    if (off + 10 > m.n) throw std::runtime_error(path + ": truncated factor record");
+    const uint64_t arity = be64(m.p + off + 2);
+    if (arity > (m.n - off - 10) / 16 || off + 26 + 16 * arity > m.n)
+      throw std::runtime_error(path + ": truncated factor record");
+    off += 26 + 16 * arity;
+    ++f; e += arity;
+    if (++cur.n_rec == kPiece) { cur.end = off; c.pieces.push_back(cur); cur = Piece{off, 0, f, e, 0}; }
+  }
+  if (cur.n_rec) { cur.end = off; c.pieces.push_back(cur); }
+  c.n_rec = f - f_base; c.n_edge = e - e_base;
+}
+
+// fn(func, arity, pointer to the arity 16-byte entries (the weight id and the feature value
+// follow them)) for every record of a piece; false if the records do not end where the cut said
+template <class Fn>
+bool walk_piece(const Mapped &m, const Piece &pc, Fn &&fn) {
+  size_t off = pc.off;
+  for (uint64_t r = 0; r < pc.n_rec; ++r) {
+    if (off + 10 > m.n) return false;
+    const uint16_t func = be16(m.p + off);
+    const uint64_t arity = be64(m.p + off + 2);
+    off += 10;
+    if (arity > (m.n - off) / 16 || off + 16 * arity + 16 > m.n) return false;
+    fn(func, arity, m.p + off);
+    off += 16 * arity + 16;
+  }
+  return off == pc.end;
+}
+}  // namespace
+
+void load_factors_sharded(const std::vector<std::string> &files, const LoadedGraph &whole, int world,
+                          std::vector<ShardGraph> &shards) {
+  if (world < 1 || world > 64) throw std::runtime_error("load_factors_sharded: 1 to 64 ranks");
+  const uint32_t nth = dwx::host_threads();
+  const uint64_t V = whole.n_variables, per = std::max<uint64_t>(1, (V + world - 1) / world);
+  shards.clear();
+  shards.resize(world);
+  for (int r = 0; r < world; ++r) shard_range(V, r, world, shards[r].begin, shards[r].end);
+  // (the rank that owns v; rank and mask are only used for v < V)
+  auto owner = [&](uint64_t v) { return (int)(v / per); };
+
+  struct File { std::unique_ptr<Mapped> m; std::string path; Cut cut; size_t piece0; };
+  std::vector<File> fs;
+  std::vector<uint64_t> cnt_f, cnt_e;              // [piece * world + rank]
+  std::vector<std::vector<uint64_t>> gh(world);    // ghosts per rank, ascending, unique
+  auto tidy = [](std::vector<uint64_t> &v) {
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+  };
+  uint64_t f_base = 0, e_base = 0;
+  size_t n_pieces = 0;
+  for (const auto &path : files) {
+    File fl;
+    fl.m.reset(new Mapped(path));
+    fl.path = path;
+    const Mapped &m = *fl.m;
+    if (m.n == 0) continue;
+    if (m.n < 10) throw std::runtime_error(path + ": truncated factor record");
+    // pass 1 of this file: counts and ghosts; first on the optimistic cut, then on the hop
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (attempt == 0) {
+        if (!cut_fixed(m, f_base, e_base, fl.cut)) continue;
+      } else {
+        cut_hop(m, path, f_base, e_base, fl.cut);
+      }
+      const Cut &c = fl.cut;
+      // more than the meta file announced: the general path reports which count is off
+      if (f_base > whole.n_factors || c.n_rec > whole.n_factors - f_base)
+        { if (attempt == 0) continue;
+          throw std::runtime_error("factor count " + std::to_string(f_base + c.n_rec) + " != meta " + std::to_string(whole.n_factors)); }
+      if (e_base > whole.n_edges || c.n_edge > whole.n_edges - e_base)
+        { if (attempt == 0) continue;
+          throw std::runtime_error("edge count " + std::to_string(e_base + c.n_edge) + " != meta " + std::to_string(whole.n_edges)); }
+      const size_t np = c.pieces.size();
+      std::vector<uint64_t> cf(np * world, 0), ce(np * world, 0);
+      const uint32_t T = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nth, np));
+      std::vector<std::vector<std::vector<uint64_t>>> part(T, std::vector<std::vector<uint64_t>>(world));
+      std::atomic<bool> ok{true};
+      std::atomic<uint64_t> bad_vid{~0ull};
+      dwx::parallel_parts(np, T, [&](uint32_t t, uint64_t pb, uint64_t pe) {
+        std::vector<size_t> sorted_upto(world, 0);
+        for (uint64_t i = pb; i < pe && ok; ++i) {
+          uint64_t *nf = &cf[i * world], *ne = &ce[i * world];
+          const bool good = walk_piece(m, c.pieces[i], [&](uint16_t, uint64_t arity, const uint8_t *ent) {
+            uint64_t mask = 0;
+            for (uint64_t k = 0; k < arity; ++k) {
+              const uint64_t v = be64(ent + 16 * k);
+              if (v >= V) { bad_vid = v; return; }
+              mask |= 1ull << owner(v);
+            }
+            for (uint64_t mm = mask; mm; mm &= mm - 1) {
+              const int r = __builtin_ctzll(mm);
+              ++nf[r]; ne[r] += arity;
+              if (mask == (1ull << r)) continue;      // nothing remote
+              for (uint64_t k = 0; k < arity; ++k) {
+                const uint64_t v = be64(ent + 16 * k);
+                if (owner(v) != r) part[t][r].push_back(v);
+              }
+            }
+          });
+          if (!good) ok = false;
+          for (int r = 0; r < world; ++r)             // (a ghost is named by every factor that reads it)
+            if (part[t][r].size() - sorted_upto[r] > (1u << 20)) { tidy(part[t][r]); sorted_upto[r] = part[t][r].size(); }
+        }
+        for (int r = 0; r < world; ++r) tidy(part[t][r]);
+      }, 2);
+      if (!ok) {
+        if (attempt == 0) continue;
+        throw std::runtime_error(path + ": inconsistent factor records");
+      }
+      if (bad_vid.load() != ~0ull) throw std::runtime_error("factor references unknown variable");
+      cnt_f.insert(cnt_f.end(), cf.begin(), cf.end());
+      cnt_e.insert(cnt_e.end(), ce.begin(), ce.end());
+      for (uint32_t t = 0; t < T; ++t)
+        for (int r = 0; r < world; ++r) gh[r].insert(gh[r].end(), part[t][r].begin(), part[t][r].end());
+      for (int r = 0; r < world; ++r) tidy(gh[r]);
+      fl.piece0 = n_pieces;
+      n_pieces += np;
+      f_base += c.n_rec; e_base += c.n_edge;
+      fs.push_back(std::move(fl));
+      break;
+    }
+  }
+  if (f_base != whole.n_factors)
+    throw std::runtime_error("factor count " + std::to_string(f_base) + " != meta " + std::to_string(whole.n_factors));
+  if (e_base != whole.n_edges)
+    throw std::runtime_error("edge count " + std::to_string(e_base) + " != meta " + std::to_string(whole.n_edges));
+
+  // exclusive prefix over the pieces, per rank
+  std::vector<uint64_t> off_f((n_pieces + 1) * world, 0), off_e((n_pieces + 1) * world, 0);
+  for (size_t i = 0; i < n_pieces; ++i)
+    for (int r = 0; r < world; ++r) {
+      off_f[(i + 1) * world + r] = off_f[i * world + r] + cnt_f[i * world + r];
+      off_e[(i + 1) * world + r] = off_e[i * world + r] + cnt_e[i * world + r];
+    }
+  for (int r = 0; r < world; ++r) {
+    ShardGraph &sg = shards[r];
+    sg.ghosts.swap(gh[r]);
+    sg.n_ghost = sg.ghosts.size();
+    fill_shard_variables(whole, sg);
+    LoadedGraph &g = sg.g;
+    const uint64_t nf = off_f[n_pieces * world + r], ne = off_e[n_pieces * world + r];
+    g.n_factors = nf; g.n_edges = ne;
+    g.fac_func.reset(nf); g.fac_edge_offset.reset(nf + 1); g.fac_weight_id.reset(nf); g.fac_feature_value.reset(nf);
+    g.edge_vid.reset(ne); g.edge_equal_to.reset(ne);
+    g.fac_edge_offset[nf] = ne;
+  }
+  // pass 2: copy
+  for (const File &fl : fs) {
+    const Mapped &m = *fl.m;
+    dwx::parallel_ranges(fl.cut.pieces.size(), nth, [&](uint64_t pb, uint64_t pe) {
+      std::vector<uint64_t> nf(world), ne(world);
+      for (uint64_t i = pb; i < pe; ++i) {
+        const size_t gi = fl.piece0 + i;
+        for (int r = 0; r < world; ++r) { nf[r] = off_f[gi * world + r]; ne[r] = off_e[gi * world + r]; }
+        walk_piece(m, fl.cut.pieces[i], [&](uint16_t func, uint64_t arity, const uint8_t *ent) {
+          uint64_t mask = 0;
+          for (uint64_t k = 0; k < arity; ++k) mask |= 1ull << owner(be64(ent + 16 * k));
+          const uint64_t wid = be64(ent + 16 * arity);
+          const double fval = bef64(ent + 16 * arity + 8);
+          for (uint64_t mm = mask; mm; mm &= mm - 1) {
+            const int r = __builtin_ctzll(mm);
+            ShardGraph &sg = shards[r];
+            LoadedGraph &g = sg.g;
+            const uint64_t f = nf[r]++;
+            uint64_t o = ne[r];
+            g.fac_func[f] = func;
+            g.fac_edge_offset[f] = o;
+            g.fac_weight_id[f] = wid;
+            g.fac_feature_value[f] = fval;
+            for (uint64_t k = 0; k < arity; ++k, ++o) {
+              const uint64_t v = be64(ent + 16 * k);
+              g.edge_vid[o] = owner(v) == r ? v - sg.begin
+                  : (sg.end - sg.begin) + (uint64_t)(std::lower_bound(sg.ghosts.begin(), sg.ghosts.end(), v) - sg.ghosts.begin());
+              g.edge_equal_to[o] = be64(ent + 16 * k + 8);
+            }
+            ne[r] = o;
+          }
+        });
+      }
+    }, 2);
+  }
 }
 
 dwx_graph_desc LoadedGraph::desc() const {

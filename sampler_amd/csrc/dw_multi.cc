@@ -134,6 +134,42 @@ dwx_graph_desc ShardGraph::desc() const {
   return d;
 }
 
+// the variable side of a shard (out.begin / end / ghosts are set): owned variables first, then
+// the ghosts; the domain blocks of the variables present, renumbered; the weights (global)
+void fill_shard_variables(const LoadedGraph &w, ShardGraph &out) {
+  const uint64_t begin = out.begin, end = out.end, n_owned = end - begin;
+  const std::vector<uint64_t> &gh = out.ghosts;
+  auto owned = [&](uint64_t v) { return v >= begin && v < end; };
+  auto local_id = [&](uint64_t v) -> uint64_t {
+    if (owned(v)) return v - begin;
+    return n_owned + (uint64_t)(std::lower_bound(gh.begin(), gh.end(), v) - gh.begin());
+  };
+  LoadedGraph &g = out.g;
+  const uint64_t nv = n_owned + gh.size();
+  g.n_variables = nv; g.n_weights = w.n_weights;
+  g.var_role.resize(nv); g.var_init_value.resize(nv); g.var_dtype.resize(nv); g.var_cardinality.resize(nv);
+  g.n_evidence = g.n_query = 0;
+  for (uint64_t i = 0; i < nv; ++i) {
+    const uint64_t v = i < n_owned ? begin + i : gh[i - n_owned];
+    g.var_role[i] = w.var_role[v]; g.var_init_value[i] = w.var_init_value[v];
+    g.var_dtype[i] = w.var_dtype[v]; g.var_cardinality[i] = w.var_cardinality[v];
+    if (i < n_owned) (w.var_role[v] >= 1 ? g.n_evidence : g.n_query)++;
+  }
+  g.dom_vid.clear(); g.dom_offset.assign(1, 0); g.dom_value.clear(); g.dom_truthiness.clear();
+  for (size_t b = 0; b < w.dom_vid.size(); ++b) {
+    const uint64_t v = w.dom_vid[b];
+    if (!owned(v) && !std::binary_search(gh.begin(), gh.end(), v)) continue;
+    g.dom_vid.push_back(local_id(v));
+    for (uint64_t i = w.dom_offset[b]; i < w.dom_offset[b + 1]; ++i) {
+      g.dom_value.push_back(w.dom_value[i]);
+      g.dom_truthiness.push_back(w.dom_truthiness[i]);
+    }
+    g.dom_offset.push_back(g.dom_value.size());
+  }
+  g.w_initial_value = w.w_initial_value;
+  g.w_is_fixed = w.w_is_fixed;
+}
+
 void make_shard(const LoadedGraph &w, uint64_t begin, uint64_t end, ShardGraph &out) {
   const uint32_t nth = dwx::host_threads();
   const uint64_t F = w.n_factors, n_owned = end - begin;
@@ -187,29 +223,9 @@ void make_shard(const LoadedGraph &w, uint64_t begin, uint64_t end, ShardGraph &
     if (owned(v)) return v - begin;
     return n_owned + (uint64_t)(std::lower_bound(gh.begin(), gh.end(), v) - gh.begin());
   };
+  fill_shard_variables(w, out);
   LoadedGraph &g = out.g;
-  const uint64_t nv = n_owned + gh.size();
-  g.n_variables = nv; g.n_factors = nf; g.n_edges = ne; g.n_weights = w.n_weights;
-  g.var_role.resize(nv); g.var_init_value.resize(nv); g.var_dtype.resize(nv); g.var_cardinality.resize(nv);
-  g.n_evidence = g.n_query = 0;
-  for (uint64_t i = 0; i < nv; ++i) {
-    const uint64_t v = i < n_owned ? begin + i : gh[i - n_owned];
-    g.var_role[i] = w.var_role[v]; g.var_init_value[i] = w.var_init_value[v];
-    g.var_dtype[i] = w.var_dtype[v]; g.var_cardinality[i] = w.var_cardinality[v];
-    if (i < n_owned) (w.var_role[v] >= 1 ? g.n_evidence : g.n_query)++;
-  }
-  // domain blocks of the variables present, renumbered
-  g.dom_vid.clear(); g.dom_offset.assign(1, 0); g.dom_value.clear(); g.dom_truthiness.clear();
-  for (size_t b = 0; b < w.dom_vid.size(); ++b) {
-    const uint64_t v = w.dom_vid[b];
-    if (!owned(v) && !std::binary_search(gh.begin(), gh.end(), v)) continue;
-    g.dom_vid.push_back(local_id(v));
-    for (uint64_t i = w.dom_offset[b]; i < w.dom_offset[b + 1]; ++i) {
-      g.dom_value.push_back(w.dom_value[i]);
-      g.dom_truthiness.push_back(w.dom_truthiness[i]);
-    }
-    g.dom_offset.push_back(g.dom_value.size());
-  }
+  g.n_factors = nf; g.n_edges = ne;
   g.fac_func.reset(nf); g.fac_edge_offset.reset(nf + 1); g.fac_weight_id.reset(nf); g.fac_feature_value.reset(nf);
   g.edge_vid.reset(ne); g.edge_equal_to.reset(ne);
   dwx::parallel_ranges(nblk, nth, [&](uint64_t bb, uint64_t be) {
@@ -230,15 +246,14 @@ void make_shard(const LoadedGraph &w, uint64_t begin, uint64_t end, ShardGraph &
     }
   }, 2);
   g.fac_edge_offset[nf] = ne;
-  g.w_initial_value = w.w_initial_value;
-  g.w_is_fixed = w.w_is_fixed;
 }
 
 // ------------------------------------------------------------------ the ranks
 namespace {
 struct Shared {          // what the rank threads share (one process)
   const CmdLine *args = nullptr;
-  const LoadedGraph *whole = nullptr;
+  const LoadedGraph *whole = nullptr;      // shards: meta counts, variables, domains, weights only
+  std::vector<ShardGraph> *shards = nullptr;   // [rank], cut while loading (load_factors_sharded)
   int world = 1;
   std::vector<int> devices;
   HostAgree *agree = nullptr;
@@ -334,7 +349,7 @@ void Rank::setup() {
                                " would own no variable (" + std::to_string(whole.n_variables) +
                                " variables in blocks of " + std::to_string((whole.n_variables + sh_.world - 1) / sh_.world) +
                                "): use fewer GPUs");
-    make_shard(whole, b, e, shard_);
+    shard_ = std::move((*sh_.shards)[rank_]);   // cut while loading
     sh_.bounds[rank_] = {b, e};
     sh_.ghosts[rank_] = &shard_.ghosts;
     dwx_graph_desc desc = shard_.desc();
@@ -736,12 +751,58 @@ int gibbs_multi(const CmdLine &args) {
     load_variables(args.variable_file, whole);
     load_weights(args.weight_file, whole);
     load_domains(args.domain_file, whole);
-    load_factors(args.factor_file, whole);
+    // shards: every factor record is decoded once and lands in the shards that own one of its
+    // variables -- the whole graph's factor columns never exist (replicas need them: -c N)
+    std::vector<ShardGraph> shards;
+    if (replicas) {
+      load_factors(args.factor_file, whole);
+    } else {
+      for (int r = 0; r < n; ++r) {
+        uint64_t b, e;
+        shard_range(whole.n_variables, r, n, b, e);
+        if (e <= b)
+          throw std::runtime_error("--gpus " + std::to_string(n) + ": rank " + std::to_string(r) +
+                                   " would own no variable (" + std::to_string(whole.n_variables) +
+                                   " variables in blocks of " + std::to_string((whole.n_variables + n - 1) / n) +
+                                   "): use fewer GPUs");
+      }
+      load_factors_sharded(args.factor_file, whole, n, shards);
+      if (getenv("DWX_DW_VERIFY_SHARDS")) {
+        // (test hook: the sharded loader against load_factors + make_shard, column by column)
+        LoadedGraph all;
+        read_meta(args.fg_file, all);
+        load_variables(args.variable_file, all);
+        load_weights(args.weight_file, all);
+        load_domains(args.domain_file, all);
+        load_factors(args.factor_file, all);
+        for (int r = 0; r < n; ++r) {
+          ShardGraph ref;
+          make_shard(all, shards[r].begin, shards[r].end, ref);
+          const LoadedGraph &a = shards[r].g, &b = ref.g;
+          auto same = [](const auto &x, const auto &y, uint64_t k) {
+            return x.size() >= k && y.size() >= k && std::equal(x.data(), x.data() + k, y.data());
+          };
+          const bool ok = shards[r].ghosts == ref.ghosts && shards[r].n_ghost == ref.n_ghost &&
+              a.n_variables == b.n_variables && a.n_factors == b.n_factors && a.n_edges == b.n_edges &&
+              a.n_weights == b.n_weights && a.n_evidence == b.n_evidence && a.n_query == b.n_query &&
+              a.var_role == b.var_role && a.var_init_value == b.var_init_value && a.var_dtype == b.var_dtype &&
+              a.var_cardinality == b.var_cardinality && a.dom_vid == b.dom_vid && a.dom_offset == b.dom_offset &&
+              a.dom_value == b.dom_value && a.dom_truthiness == b.dom_truthiness &&
+              a.w_initial_value == b.w_initial_value && a.w_is_fixed == b.w_is_fixed &&
+              same(a.fac_func, b.fac_func, a.n_factors) && same(a.fac_edge_offset, b.fac_edge_offset, a.n_factors + 1) &&
+              same(a.fac_weight_id, b.fac_weight_id, a.n_factors) &&
+              std::memcmp(a.fac_feature_value.data(), b.fac_feature_value.data(), 8 * a.n_factors) == 0 &&
+              same(a.edge_vid, b.edge_vid, a.n_edges) && same(a.edge_equal_to, b.edge_equal_to, a.n_edges);
+          if (!ok) throw std::runtime_error("DWX_DW_VERIFY_SHARDS: shard " + std::to_string(r) + " differs from make_shard");
+        }
+        std::cout << "DWX_DW_VERIFY_SHARDS: " << n << " shards equal make_shard" << std::endl;
+      }
+    }
     HostAgree agree(n);
     std::unique_ptr<Comm> comm = args.comm == "host" ? make_host_comm(n, &agree) : make_rccl_comm(devices);
     Shared sh;
     sh.args = &args; sh.whole = &whole; sh.world = n; sh.devices = devices; sh.agree = &agree; sh.comm = comm.get();
-    sh.replicas = replicas;
+    sh.replicas = replicas; sh.shards = &shards;
     sh.ghosts.assign(n, nullptr); sh.bounds.assign(n, {0, 0}); sh.results.resize(n);
     uint64_t num_values = 0;
     for (uint64_t v = 0; v < whole.n_variables; ++v) num_values += whole.var_dtype[v] == 0 ? 1 : whole.var_cardinality[v];

@@ -86,6 +86,13 @@ struct ShardGraph {
   dwx_graph_desc desc() const;
 };
 void make_shard(const LoadedGraph &whole, uint64_t begin, uint64_t end, ShardGraph &out);
+// the variable side of a shard whose begin / end / ghosts are set (variables, domains, weights)
+void fill_shard_variables(const LoadedGraph &whole, ShardGraph &out);
+// The factor files decoded ONCE, straight into the shards of all `world` ranks (dw_cli.cc, next
+// to load_factors: same format, cuts and errors): `whole` holds the meta counts, the variables,
+// domains and weights -- and never the factor columns.  Result == make_shard of every block.
+void load_factors_sharded(const std::vector<std::string> &files, const LoadedGraph &whole, int world,
+                          std::vector<ShardGraph> &shards);
 void shard_range(uint64_t total, int rank, int world, uint64_t &begin, uint64_t &end);
 
 // `dw gibbs --gpus N` / `-c N`: returns the process exit code

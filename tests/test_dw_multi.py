@@ -262,6 +262,118 @@ def test_make_shard_progress_output_names_the_ranks(dw_emu):
         assert r.stdout.count("LEARNING EPOCH") == 2 and "TOTAL INFERENCE TIME" in r.stdout
 
 
+# ------------------------------------------------------------------------ sharded loader
+def _write_graph(tmp, recs, n_vars, n_weights, split=None, n_factors=None, n_edges=None, raw=None):
+    """A boolean graph (every third variable evidence) whose factor file(s) hold `recs`
+    ([(func, [(vid, equal_to), ...], wid, fval)]); returns the `dw gibbs` file arguments."""
+    import struct
+    from test_text2bin import _factor_bytes
+    n_factors = len(recs) if n_factors is None else n_factors
+    n_edges = sum(len(r[1]) for r in recs) if n_edges is None else n_edges
+    open(os.path.join(tmp, "graph.meta"), "w").write("%d,%d,%d,%d" % (n_weights, n_vars, n_factors, n_edges))
+    open(os.path.join(tmp, "graph.variables"), "wb").write(
+        b"".join(struct.pack(">QBQHQ", v, v % 3 == 0, v % 2, 0, 2) for v in range(n_vars)))
+    open(os.path.join(tmp, "graph.weights"), "wb").write(
+        b"".join(struct.pack(">QBd", w, 0, 0.0) for w in range(n_weights)))
+    cmd = ["-m", os.path.join(tmp, "graph.meta"), "-v", os.path.join(tmp, "graph.variables"),
+           "-w", os.path.join(tmp, "graph.weights")]
+    cuts = [0] + (split or []) + [len(recs)]
+    for i in range(len(cuts) - 1):
+        fn = os.path.join(tmp, "graph.factors.%d" % i)
+        open(fn, "wb").write(raw if raw is not None else _factor_bytes(recs[cuts[i]:cuts[i + 1]]))
+        cmd += ["-f", fn]
+    return cmd
+
+
+def _dw_files(binary, files, out, extra, env=None):
+    cmd = [binary, "gibbs"] + files + ["-o", out] + extra
+    return subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+
+
+def test_sharded_loader_equals_make_shard(dw_emu):
+    """`dw gibbs --gpus N` decodes the factor files once, straight into the ranks' shards
+    (load_factors_sharded) -- no whole-graph factor columns.  DWX_DW_VERIFY_SHARDS compares every
+    column of every shard with load_factors + make_shard: fixtures, and a graph of mixed arities
+    (fixed-stride file, hop-cut file, look-alike file, > 64 k records = several pieces) whose
+    pairwise and ternary factors cross the block boundaries."""
+    import random
+    for fx, n in [("biased_coin", 3), ("partial_observation", 2), ("sparse_domains", 3),
+                  ("biased_coin_with_multinomial", 4), ("categorical_noise_aware", 2)]:
+        if fx not in FIXTURES:
+            continue
+        with tempfile.TemporaryDirectory() as out:
+            r = subprocess.run(
+                [dw_emu, "gibbs"] + _fixture_files(fx) + ["-o", out, "-l", "2", "-i", "2", "--gpus", str(n), "--comm", "host"],
+                capture_output=True, text=True, env=dict(os.environ, DWX_DW_VERIFY_SHARDS="1"))
+            assert r.returncode == 0, r.stderr
+            assert "%d shards equal make_shard" % n in r.stdout, fx
+    rnd = random.Random(11)
+    V, W = 3000, 50
+
+    def rec(arity):
+        v0 = rnd.randrange(V)
+        vs = [v0] + [(v0 + rnd.choice([1, 7, 101, V // 3 + 3])) % V for _ in range(arity - 1)]
+        return (rnd.choice([0, 1, 2, 3]) if arity > 1 else 4, [(v, 1) for v in vs], rnd.randrange(W), 1.0)
+
+    recs = ([rec(1) for _ in range(70_000)] + [rec(rnd.randint(1, 3)) for _ in range(3000)] +
+            [rec(1)] + [rec(3), rec(3), rec(3)] * 7 + [rec(1)] * 20 + [rec(2) for _ in range(2000)])
+    split = [70_000, 73_000, 73_000 + 42]
+    for n, exe, env in ((2, dw_emu, {}), (3, dw_emu, {}), (7, dw_emu, {}), (3, dw_emu + "_asan", _asan_env())):
+        with tempfile.TemporaryDirectory() as t:
+            files = _write_graph(t, recs, V, W, split=split)
+            r = _dw_files(exe, files, t, ["-l", "1", "-i", "1", "--gpus", str(n), "--comm", "host"],
+                          env=dict(env, DWX_DW_VERIFY_SHARDS="1", DWX_HOST_THREADS="8"))
+            assert r.returncode == 0, r.stderr[-3000:]
+            assert "%d shards equal make_shard" % n in r.stdout
+
+
+def _asan_env():
+    libasan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+    return {"LD_PRELOAD": libasan, "ASAN_OPTIONS": "detect_leaks=0:abort_on_error=1", "UBSAN_OPTIONS": "halt_on_error=1"}
+
+
+@pytest.mark.parametrize("asan", [False, True])
+def test_sharded_loader_rejects_malformed_files(dw_emu, asan):
+    """The errors of load_factors (tests/test_text2bin.py), through `dw gibbs --gpus 2`; plain and
+    under ASan/UBSan (a rejected file must not have written past a column)."""
+    import random
+    from test_text2bin import _factor_bytes
+    if asan:
+        dw_emu = dw_emu + "_asan"
+    asan_env = dict(_asan_env(), DWX_HOST_THREADS="8") if asan else None
+    rnd = random.Random(6)
+    recs = [(4, [(rnd.randrange(8), 1)], 0, 1.0) for _ in range(100)]
+    blob = _factor_bytes(recs)
+    extra = ["-l", "1", "-i", "1", "-q", "--gpus", "2", "--comm", "host"]
+    with tempfile.TemporaryDirectory() as t:      # cut in the middle of a record
+        r = _dw_files(dw_emu, _write_graph(t, recs, 8, 4, raw=blob[:-5]), t, extra, asan_env)
+        assert r.returncode == 1 and "truncated" in r.stderr
+    with tempfile.TemporaryDirectory() as t:      # fewer records than graph.meta announces
+        r = _dw_files(dw_emu, _write_graph(t, recs, 8, 4, n_factors=101, n_edges=101), t, extra, asan_env)
+        assert r.returncode == 1 and "factor count" in r.stderr
+    with tempfile.TemporaryDirectory() as t:      # more records than graph.meta announces
+        r = _dw_files(dw_emu, _write_graph(t, recs, 8, 4, n_factors=99, n_edges=99), t, extra, asan_env)
+        assert r.returncode == 1 and "count" in r.stderr
+    with tempfile.TemporaryDirectory() as t:      # an arity field pointing far past the file
+        bad = bytearray(blob)
+        bad[42 * 50 + 2:42 * 50 + 10] = (1 << 40).to_bytes(8, "big")
+        r = _dw_files(dw_emu, _write_graph(t, recs, 8, 4, raw=bytes(bad)), t, extra, asan_env)
+        assert r.returncode == 1 and "truncated" in r.stderr
+    with tempfile.TemporaryDirectory() as t:      # a variable id the meta file does not know
+        bad = recs[:50] + [(4, [(8, 1)], 0, 1.0)] + recs[51:]
+        r = _dw_files(dw_emu, _write_graph(t, bad, 8, 4), t, extra, asan_env)
+        assert r.returncode == 1 and "unknown variable" in r.stderr
+
+
+def _fixture_files(fx):
+    d = os.path.join(GOLDEN, fx)
+    cmd = ["-m", os.path.join(d, "graph.meta"), "-w", os.path.join(d, "graph.weights"),
+           "-v", os.path.join(d, "graph.variables"), "-f", os.path.join(d, "graph.factors")]
+    if os.path.exists(os.path.join(d, "graph.domains")):
+        cmd += ["--domains", os.path.join(d, "graph.domains")]
+    return cmd
+
+
 # ------------------------------------------------------------------------ GPU box
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [["--gpus", "2"], ["-c", "2"]], ids=lambda m: "".join(m))
