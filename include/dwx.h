@@ -203,6 +203,14 @@ void dwx_sampler_destroy(dwx_sampler *s);
 
 /* GibbsSampler::sample(i_epoch) (src/gibbs_sampler.cc:20-25): one inference sweep. */
 int dwx_sample_async(dwx_sampler *s);
+/* The inference loop of DimmWitted::inference (src/dimmwitted.cc:131-156: `for i_epoch:
+ * sample(i_epoch); wait()`), n_sweeps of its iterations in one call: state, tallies and sweep
+ * counter afterwards are bit for bit those of n_sweeps calls of dwx_sample_async.  On a graph
+ * whose factors are all unary (no variable reads another, so nothing a sweep reads changes
+ * between sweeps) the sweeps share ONE launch: every record is read once, every variable draws
+ * n_sweeps times with the uniforms its separate sweeps would have used.  Any other graph runs
+ * the n_sweeps sweeps one after the other. */
+int dwx_sample_n_async(dwx_sampler *s, uint32_t n_sweeps);
 /* GibbsSampler::sample_sgd(stepsize) (src/gibbs_sampler.cc:27-33): one learning
  * sweep = dwx_sgd_plan + (accumulate, apply)* + dwx_sgd_finish. */
 int dwx_sample_sgd_async(dwx_sampler *s, double stepsize);

@@ -259,6 +259,7 @@ struct KernelParams {
   uint32_t lds_w_off;         // byte offset of the staged f32 weights (learning kernel)
   uint32_t lds_agg_off;       // byte offset of the per-workgroup gradient accumulators
                               // (int64[2W], learning kernel, only when W <= LDS_AGG_MAX_W), else 0
+  uint32_t n_sweeps;          // MULTI builds of the inference sweep: sweeps [sweep, sweep + n_sweeps) in one launch
 };
 
 }  // namespace dwx

@@ -915,7 +915,10 @@ int gibbs(const CmdLine &args) {
         std::cout << std::setprecision(3) << "" << elapsed << " sec." << "," << V / elapsed << " vars/sec"
                   << std::endl << std::setprecision(6);
       } else {
-        ok(dwx_sample_async(sampler));   // quiet: epochs stay queued on the stream
+        // quiet: nothing is printed per epoch -- all of them in one call (an all-unary graph
+        // runs them in one launch, any other queues them on the stream)
+        ok(dwx_sample_n_async(sampler, (uint32_t)std::min<uint64_t>(args.n_inference_epoch - e, 1u << 20)));
+        e += std::min<uint64_t>(args.n_inference_epoch - e, 1u << 20) - 1;
       }
     }
     ok(dwx_wait(sampler));

@@ -87,6 +87,7 @@ struct TimedSpan {
   uint32_t launches;
   bool has_pull;
   bool new_sweep;   // the span opens a sweep (inference: always; learning: its first chunk)
+  uint32_t n_sweeps = 1;   // ... or several (dwx_sample_n_async on an all-unary graph)
 };
 }  // namespace
 
@@ -248,8 +249,9 @@ struct dwx_halo {
 
 namespace {
 // launch the sweep kernel (+ the oversized-variable kernel) over tiles [t0, t1) of launch l
+// multi (inference of a graph without degree-binned variables): P.n_sweeps sweeps per launch
 template <bool LEARN>
-uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, uint32_t t1) {
+uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, uint32_t t1, const bool multi = false) {
   const CompiledGraph &c = *s->cg;
   if (t1 <= t0) return 0;
   uint32_t launches = 0;
@@ -291,6 +293,19 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   // (all-unary graphs stage 8-byte terms whenever the compute phase needs no record)
   const size_t lds = tab8 ? s->lds_tab : slim ? s->lds_learn_pull : s->lds_bytes[LEARN ? 1 : 0];
   constexpr int RPC = (int)ROWPTR_UNROLL_CAT;
+  if constexpr (!LEARN) {
+    if (multi) {   // (only asked for on compact-record graphs, never on the terms table)
+      constexpr int RP = (int)ROWPTR_UNROLL;
+      if (s->rp_cat) rt::launch(sweep8_kernel<false, 6, false, RPC, true>, grid, BLOCK_THREADS, lds, s->stream, P);
+      else switch (s->stage_k) {
+        case 3: rt::launch(sweep8_kernel<false, 3, false, RP, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+        case 6: rt::launch(sweep8_kernel<false, 6, false, RP, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+        default: rt::launch(sweep8_kernel<false, 12, false, RP, true>, grid, BLOCK_THREADS, lds, s->stream, P); break;
+      }
+      ++launches;
+      return;
+    }
+  }
   if (rec8 && s->rp_cat) {
     if (tab8) rt::launch(sweep8_kernel<false, 6, true, RPC>, grid, BLOCK_THREADS, lds, s->stream, P);
     else rt::launch(sweep8_kernel<LEARN, 6, false, RPC>, grid, BLOCK_THREADS, lds, s->stream, P);
@@ -326,7 +341,7 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   // scatters its gradient or counts updates dynamically -- the kernel only publishes ballots);
   // the tiles before, between and behind them: the tile sweep.
   bool used_sorted = false;
-  if (s->d_supers && !P.edge_terms && (!LEARN || (s->sorted_learn && !(P.flags & (OPT_NO_PULL | OPT_DYNAMIC_T))))) {
+  if (s->d_supers && !P.edge_terms && !multi && (!LEARN || (s->sorted_learn && !(P.flags & (OPT_NO_PULL | OPT_DYNAMIC_T))))) {
     // (a chunk of a split learning sweep: the plan level's own layout, cut along the chunks)
     const dwx_sampler::Level *lv = (LEARN && s->plan_level && s->plan_level->d_supers) ? s->plan_level : nullptr;
     const std::vector<SuperTile> &sv = lv ? lv->sorted_supers : c.supers;
@@ -395,6 +410,43 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
     if (any_wide) { rt::event_record(s->ev_join[1], st_wide); rt::stream_wait_event(s->stream, s->ev_join[1]); }
   }
   return launches;
+}
+
+// n inference sweeps of a graph whose sweeps can share a launch: compact records (all-unary, so
+// no variable reads another and the potentials of a variable are the same in every sweep while
+// the weights rest) and no degree-binned variable (wide / giant tiles run kernels of their own).
+// ONE launch of the gathering tile sweep stages every tile once and draws n times per variable
+// (sweep8_kernel<..., MULTI>, infer_variable_multi): neither the terms table nor the weight-sorted
+// copy is needed -- a record is read once per n sweeps.
+bool multi_sweep_graph(const dwx_sampler *s) {
+  return s->rec8 && s->cgiant_tiles.empty() && s->bgiant_tiles.empty() && s->cg->wide_tiles.empty() &&
+         !getenv("DWX_NO_MULTI_SWEEP");
+}
+
+void enqueue_inference_multi(dwx_sampler *s, uint32_t n) {
+  const CompiledGraph &c = *s->cg;
+  rt::set_device(s->device);
+  KernelParams P = s->base;
+  P.sweep = s->sweep;
+  P.n_sweeps = n;
+  P.edge_terms = nullptr;
+  TimedSpan sp{};
+  if (s->timing) {
+    sp.a = rt::event_create(); sp.b = rt::event_create(); sp.c = rt::event_create(); sp.kind = 0;
+    rt::event_record(sp.a, s->stream);
+  }
+  uint32_t launches = 0;
+  for (size_t l = 0; l + 1 < c.launch_off.size(); ++l) {
+    const uint32_t t1 = s->opts.sample_evidence ? c.launch_tile[l + 1] : c.launch_query_tile_end[l];
+    launches += launch_tiles<false>(s, P, l, c.launch_tile[l], t1, true);
+  }
+  if (s->timing) {
+    rt::event_record(sp.b, s->stream);
+    rt::event_record(sp.c, s->stream);
+    sp.launches = launches; sp.has_pull = false; sp.new_sweep = true; sp.n_sweeps = n;
+    s->spans.push_back(sp);
+  }
+  s->sweep += n;
 }
 
 // one inference sweep (GibbsSampler::sample)
@@ -1196,7 +1248,7 @@ void drain_spans(dwx_sampler *s) {
   for (auto &sp : s->spans) {
     s->t_ms[sp.kind] += rt::event_elapsed_ms(sp.a, sp.b);
     s->t_launches[sp.kind] += sp.launches;
-    s->t_sweeps[sp.kind] += sp.new_sweep ? 1 : 0;   // (a learning sweep is one or more chunks)
+    s->t_sweeps[sp.kind] += sp.new_sweep ? sp.n_sweeps : 0;   // (a learning sweep is one or more chunks)
     if (sp.has_pull) {
       s->t_ms[2] += rt::event_elapsed_ms(sp.b, sp.c);
       s->t_launches[2] += 1;
@@ -1445,6 +1497,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     // same region alternatively holds 32-byte LearnRecs (which carry their weight)
     s->lds_bytes[1] = P.lds_edge_off + slots * (s->wide_learn ? 32 : 20);
     P.lds_agg_off = 0;
+    P.n_sweeps = 1;
     if (c.W > 0 && c.W <= LDS_AGG_MAX_W) {
       P.lds_agg_off = (uint32_t)((s->lds_bytes[1] + 15) & ~(size_t)15);
       s->lds_bytes[1] = P.lds_agg_off + (size_t)c.W * 16;
@@ -1574,6 +1627,18 @@ int dwx_sample_async(dwx_sampler *s) {
   return guarded([&]() {
     enqueue_inference(s);
     ++s->infer_sweeps;
+  });
+}
+
+int dwx_sample_n_async(dwx_sampler *s, uint32_t n_sweeps) {
+  if (!s) return fail(DWX_E_INVALID, "null sampler");
+  return guarded([&]() {
+    if (n_sweeps > 1 && multi_sweep_graph(s)) {
+      enqueue_inference_multi(s, n_sweeps);
+    } else {
+      for (uint32_t k = 0; k < n_sweeps; ++k) enqueue_inference(s);
+    }
+    s->infer_sweeps += n_sweeps;
   });
 }
 

@@ -519,9 +519,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
 #ifndef DWX_S8_LEARN_WG
 #define DWX_S8_LEARN_WG 3
 #endif
-template <bool LEARN, int K, bool TAB = false, int RP = (int)ROWPTR_UNROLL>
+// MULTI (inference, gathering build only): P.n_sweeps sweeps per launch -- the tile is staged once
+// and every variable is drawn n_sweeps times (infer_variable_multi, tile_walk.h).
+template <bool LEARN, int K, bool TAB = false, int RP = (int)ROWPTR_UNROLL, bool MULTI = false>
 __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN_WG : DWX_S8_INFER_WG)) sweep8_kernel(const KernelParams P) {
   static_assert(!(LEARN && TAB), "the terms table serves inference sweeps only");
+  static_assert(!MULTI || (!LEARN && !TAB), "several sweeps per launch: the gathering inference build");
   DWX_DYN_LDS(dyn_lds);
   uint32_t *s_rowptr = (uint32_t *)dyn_lds;
   double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
@@ -556,7 +559,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
         for (int k = 0; k < K; ++k) w[k] = P.w32[f.rec[k].key & REC8_WID_MASK];
       }
       // ... and this lane's uniforms while the gathers are in flight
-      philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
+      if (!MULTI) philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
       if (TAB) {
         // the table's entries go to LDS as they are (8 bytes per record: half the staging
         // area of the 16-byte modes, more workgroups per CU); the row walk decodes them
@@ -621,7 +624,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
     int delta = 0;
     if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
-      if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
+      if (MULTI)
+        infer_variable_multi<W_TERMS, true>(P, T, d.v0 + t, pre);
+      else if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
         delta = process_variable<LEARN, W_TERMS8, true, true>(P, T, d.v0 + t, pre, A, B, true);
       else   // (FIXED: boolean variables of a compact-record graph sum their potentials in fixed point)
         process_variable<LEARN, LEARN ? W_ARRAY : (TAB ? W_TERMS8 : W_TERMS), true, true>(P, T, d.v0 + t, pre, A, B, false);

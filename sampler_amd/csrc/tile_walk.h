@@ -784,6 +784,85 @@ DWX_DEV VarPre load_var_pre(const KernelParams &P, uint32_t p) {
   return v;
 }
 
+// MULTI: P.n_sweeps consecutive inference sweeps of ONE variable of an all-unary tile in one go.
+// No factor of such a graph reads another variable, so a variable's potentials do not change
+// from sweep to sweep (the weights are fixed during inference): they are summed ONCE, exactly as
+// a single sweep sums them, and sweep k draws with its own uniform -- Philox keyed (seed, global
+// id, sweep + k), as n separate launches would.  The draws are the reference's own expressions
+// (src/gibbs_sampler.h:204-214 / :217-246) with their sweep-invariant parts hoisted:
+// r * (1 + exp(pn - pp)) < 1, and r -= exp(pot_d - sum) until r <= 0 -- what bool_draw and
+// cat_draw return by construction (their f32 fast paths only ever shortcut to this verdict).
+// Tallies are added once per value, the assignment is the last sweep's: bit for bit what
+// n_sweeps calls of the single-sweep path leave behind (tests/test_multi_sweep.py).
+template <int WMODE, bool FIXED>
+DWX_DEV void infer_variable_multi(const KernelParams &P, const TileView &T, uint32_t p, const VarPre pre) {
+  const uint32_t meta = pre.meta;
+  if ((meta & VM_EVIDENCE) && !(P.flags & OPT_SAMPLE_EVIDENCE)) return;
+  const uint32_t card = meta >> VM_CARD_SHIFT, row0 = pre.row0, n = P.n_sweeps;
+  const uint64_t vid = P.vid_offset + pre.orig;
+  uint32_t prop = 0;
+  if (!(meta & VM_CATEGORICAL)) {
+    double pp, pn;
+    bool_potentials<WMODE, true, FIXED>(P, T, row0, P.assign_evid, p, pp, pn);
+    const double scale = 1.0 + exp(pn - pp);
+    uint32_t count = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+      double A, B;
+      philox_uniforms(P.seed, vid, P.sweep + k, A, B);
+      prop = (A * scale < 1.0) ? 1u : 0u;
+      count += prop;
+    }
+    if (count) atomicAdd(&P.tally[row0], count);
+  } else if (card <= SMALL_CARD) {
+    double e[SMALL_CARD];
+    uint32_t es = T.rowptr[row0 - T.row_bias];
+#pragma unroll
+    for (uint32_t d = 0; d < SMALL_CARD; ++d) {
+      e[d] = -1e300;
+      if (d < card) {
+        const uint32_t ee = T.rowptr[row0 + d + 1 - T.row_bias];
+        e[d] = range_potential<WMODE, true>(P, T, es, ee, P.assign_evid, p, d);
+        es = ee;
+      }
+    }
+    double sum = -100000.0;
+#pragma unroll
+    for (uint32_t d = 0; d < SMALL_CARD; ++d) if (d < card) sum = logadd(sum, e[d]);
+#pragma unroll
+    for (uint32_t d = 0; d < SMALL_CARD; ++d) e[d] = d < card ? exp(e[d] - sum) : 0.0;
+    uint32_t cnt[SMALL_CARD];
+#pragma unroll
+    for (uint32_t d = 0; d < SMALL_CARD; ++d) cnt[d] = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+      double r, B;
+      philox_uniforms(P.seed, vid, P.sweep + k, r, B);
+      uint32_t res = card - 1;
+      bool found = false;
+#pragma unroll
+      for (uint32_t d = 0; d < SMALL_CARD; ++d) {
+        if (d < card && !found) {
+          r -= e[d];
+          if (r <= 0) { res = d; found = true; }
+        }
+      }
+#pragma unroll
+      for (uint32_t d = 0; d < SMALL_CARD; ++d) cnt[d] += res == d ? 1u : 0u;
+      prop = res;
+    }
+#pragma unroll
+    for (uint32_t d = 0; d < SMALL_CARD; ++d)
+      if (d < card && cnt[d]) atomicAdd(&P.tally[row0 + d], cnt[d]);
+  } else {
+    for (uint32_t k = 0; k < n; ++k) {
+      double A, B;
+      philox_uniforms(P.seed, vid, P.sweep + k, A, B);
+      prop = cat_draw<WMODE, true>(P, T, row0, card, P.assign_evid, p, A);
+      atomicAdd(&P.tally[row0 + prop], 1u);
+    }
+  }
+  DWX_NT_STORE(prop, &P.assign_evid[p]);
+}
+
 // want_delta (learning, TILE_PULL tiles only): instead of scattering gradient atomics,
 // return hit(free) - hit(evid) in {-1,0,+1} for a variable that triggers SGD (0 otherwise).
 template <bool LEARN, int WMODE, bool SIMPLE, bool FIXED = false>

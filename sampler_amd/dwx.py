@@ -24,7 +24,7 @@ SYMBOLS = [
     "dwx_last_error", "dwx_version", "dwx_default_options",
     "dwx_graph_create", "dwx_graph_destroy", "dwx_graph_get_info", "dwx_graph_get_schedule",
     "dwx_graph_get_values", "dwx_graph_get_fixed_point_mask", "dwx_graph_get_positions", "dwx_graph_get_index",
-    "dwx_sampler_create", "dwx_device_init", "dwx_device_count", "dwx_buffer_copy", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_sgd_async",
+    "dwx_sampler_create", "dwx_device_init", "dwx_device_count", "dwx_buffer_copy", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_n_async", "dwx_sample_sgd_async",
     "dwx_wait", "dwx_sgd_plan", "dwx_sgd_curvature", "dwx_sgd_plan_rows", "dwx_sgd_plan_force_dynamic", "dwx_sgd_get_chunks", "dwx_grad_pack32_async", "dwx_grad_unpack32_async", "dwx_sgd_accumulate_async",
     "dwx_sgd_apply_async", "dwx_sgd_finish",
     "dwx_get_weights", "dwx_set_weights", "dwx_average_weights_async",
@@ -98,6 +98,7 @@ class Library:
         L.dwx_buffer_copy.argtypes = [vp, vp, vp, u64, i32]
         L.dwx_sampler_destroy.argtypes = [vp]; L.dwx_sampler_destroy.restype = None
         L.dwx_sample_async.argtypes = [vp]
+        L.dwx_sample_n_async.argtypes = [vp, C.c_uint32]
         L.dwx_sample_sgd_async.argtypes = [vp, dbl]
         L.dwx_wait.argtypes = [vp]
         L.dwx_sgd_plan.argtypes = [vp, dbl, C.c_uint32, vp, vp, vp]
@@ -252,6 +253,10 @@ class GibbsSampler:
     # ---- the reference's interface ----
     def sample(self, i_epoch=0):
         self.lib.check(self.lib.L.dwx_sample_async(self.h))
+
+    def sample_n(self, n_sweeps):
+        """n_sweeps inference sweeps (one launch on an all-unary graph; include/dwx.h)."""
+        self.lib.check(self.lib.L.dwx_sample_n_async(self.h, n_sweeps))
 
     def sample_sgd(self, stepsize):
         self.lib.check(self.lib.L.dwx_sample_sgd_async(self.h, stepsize))
@@ -458,6 +463,6 @@ class DimmWitted:
 
     def inference(self):
         self.sampler.clear_tallies()
-        for e in range(self.n_inference_epoch):
-            self.sampler.sample(e)
+        if self.n_inference_epoch:
+            self.sampler.sample_n(self.n_inference_epoch)
         self.sampler.wait()

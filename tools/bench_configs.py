@@ -52,6 +52,21 @@ def run(name, raw, n_learn, n_infer, stepsize=0.001, **kw):
             s.sample_sgd(stepsize) if kind == "learn" else s.sample()
         s.wait()
         wall[kind] = (time.perf_counter() - t1) / n * 1e3
+    # n inference sweeps in ONE call (dwx_sample_n_async: one launch on an all-unary graph,
+    # n queued sweeps on any other), device time per sweep and wall time per sweep
+    multi = {}
+    for n in (10, 100, 1000):
+        s.sample_n(n); s.wait()
+        s.kernel_time_reset(True)
+        s.sample_n(n); s.wait()
+        ms_m, nl_m, ns_m = s.kernel_time("infer")
+        s.kernel_time_reset(False)
+        t1 = time.perf_counter()
+        s.sample_n(n); s.wait()
+        multi[str(n)] = {"ms_per_sweep": ms_m / n, "wall_ms_per_sweep": (time.perf_counter() - t1) / n * 1e3,
+                         "launches": int(nl_m)}
+        if ms_m > 2000.0:
+            break
     batches, n_chunks, eta = s.sgd_plan(stepsize) if n_learn else (None, None, None)
     V = raw.num_variables
     out = {"config": name, "V": V, "colors": int(g.info.num_colors), "tiles": int(g.info.num_tiles),
@@ -61,6 +76,7 @@ def run(name, raw, n_learn, n_infer, stepsize=0.001, **kw):
            "learn_ms_per_sweep": ms_l / max(ns_l, 1) if ns_l else None,
            "learn_vars_per_s": V / (ms_l / ns_l * 1e-3) if ns_l else None,
            "learn_wall_ms_per_sweep": wall.get("learn"), "infer_wall_ms_per_sweep": wall.get("infer"),
+           "infer_n_in_one_call": multi,
            "sgd_batches": batches, "sgd_chunks": n_chunks, "min_weight_stepsize": eta}
     print(json.dumps(out), flush=True)
     s.close()
