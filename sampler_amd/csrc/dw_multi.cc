@@ -634,7 +634,16 @@ void Rank::inference() {
   const uint64_t per_round = sh_.replicas ? n : 1;
   double t_total = now();
   ok(dwx_clear_tallies(s_));
-  for (uint64_t e = 0; e < rounds; ++e) {
+  // quiet and nothing to exchange between the sweeps (replicas; shards without a ghost anywhere):
+  // all rounds in one call -- one launch on an all-unary graph (dwx_sample_n_async)
+  bool exchange = false;
+  if (!sh_.replicas)
+    for (int k = 0; k < sh_.world; ++k) exchange = exchange || !sh_.ghosts[k]->empty();
+  uint64_t e0 = 0;
+  if (args_.should_be_quiet && !exchange)
+    for (; e0 < rounds; e0 += std::min<uint64_t>(rounds - e0, 1u << 20))
+      ok(dwx_sample_n_async(s_, (uint32_t)std::min<uint64_t>(rounds - e0, 1u << 20)));
+  for (uint64_t e = e0; e < rounds; ++e) {
     if (progress())
       std::cout << std::setprecision(3) << "INFERENCE EPOCH " << e * per_round << "~" << (e + 1) * per_round - 1 << "...." << std::flush;
     const double t0 = now();

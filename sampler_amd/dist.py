@@ -192,6 +192,9 @@ class HipEngine:
     def sample(self):
         self.s.sample()
 
+    def sample_n(self, n_sweeps):
+        self.s.sample_n(n_sweeps)
+
     def wait(self):
         self.s.wait()
 
@@ -472,8 +475,11 @@ class ShardedDimmWitted:
         self.e.wait()
 
     def inference(self):
-        for _ in range(self.n_inference_epoch):
-            self.sample_epoch()
+        if self.halo is None and self.n_inference_epoch and hasattr(self.e, "sample_n"):
+            self.e.sample_n(self.n_inference_epoch)     # (nothing to exchange between the sweeps)
+        else:
+            for _ in range(self.n_inference_epoch):
+                self.sample_epoch()
         self.e.wait()
 
     def sample_epoch(self):
@@ -522,8 +528,11 @@ class ReplicatedDimmWitted:
     def inference(self):
         self.e.clear_tallies()
         self._tallies_summed = False
-        for _ in range(self.n_inference_rounds):
-            self.e.sample()
+        if self.n_inference_rounds and hasattr(self.e, "sample_n"):
+            self.e.sample_n(self.n_inference_rounds)
+        else:
+            for _ in range(self.n_inference_rounds):
+                self.e.sample()
         self.e.wait()
 
     def marginals(self):

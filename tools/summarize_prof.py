@@ -15,6 +15,9 @@ def short(name):
         return "sorted_sweep_kernel<LEARN=true>"
     if "sorted_sweep_kernel<false" in name or "sorted_sweep_kernelILb0" in name:
         return "sorted_sweep_kernel<LEARN=false>"
+    import re
+    if re.search(r"sweep8_kernel<false, \d+, false, \d+, true>", name) or re.search(r"sweep8_kernelILb0ELi\d+ELb0ELi\d+ELb1E", name):
+        return "sweep8_kernel<INFER,MULTI>"
     if "sweep8_kernel<true" in name or "sweep8_kernelILb1" in name:
         return "sweep8_kernel<LEARN=true>"
     if "sweep8_kernel<false" in name or "sweep8_kernelILb0" in name:
