@@ -830,24 +830,35 @@ DWX_DEV void infer_variable_multi(const KernelParams &P, const TileView &T, uint
     for (uint32_t d = 0; d < SMALL_CARD; ++d) if (d < card) sum = logadd(sum, e[d]);
 #pragma unroll
     for (uint32_t d = 0; d < SMALL_CARD; ++d) e[d] = d < card ? exp(e[d] - sum) : 0.0;
+    // The reference stops at the first d with r <= 0.  Every e[d] is >= 0, so the running r
+    // never rises (a rounded subtraction of a non-negative number is monotone): the values
+    // r > 0 form a prefix, and the first d with r <= 0 is the NUMBER of d with r > 0 -- capped
+    // at card - 1 (the reference asserts there; rounding can leave r > 0 after the last value,
+    // and the padding slots d >= card subtract 0).  Same subtractions in the same order, no
+    // early exit to track.  Counts: eight 8-bit counters in one 64-bit word, unpacked every 255
+    // draws.
+    static_assert(SMALL_CARD == 8, "eight 8-bit counters per 64-bit word");
     uint32_t cnt[SMALL_CARD];
 #pragma unroll
     for (uint32_t d = 0; d < SMALL_CARD; ++d) cnt[d] = 0;
-    for (uint32_t k = 0; k < n; ++k) {
-      double r, B;
-      philox_uniforms(P.seed, vid, P.sweep + k, r, B);
-      uint32_t res = card - 1;
-      bool found = false;
+    for (uint32_t k0 = 0; k0 < n; k0 += 255u) {
+      const uint32_t k1 = umin(n, k0 + 255u);
+      unsigned long long packed = 0;
+      for (uint32_t k = k0; k < k1; ++k) {
+        double r, B;
+        philox_uniforms(P.seed, vid, P.sweep + k, r, B);
+        uint32_t res = 0;
 #pragma unroll
-      for (uint32_t d = 0; d < SMALL_CARD; ++d) {
-        if (d < card && !found) {
+        for (uint32_t d = 0; d < SMALL_CARD; ++d) {
           r -= e[d];
-          if (r <= 0) { res = d; found = true; }
+          res += r > 0 ? 1u : 0u;
         }
+        res = umin(res, card - 1);
+        packed += 1ull << (res * 8u);
+        prop = res;
       }
 #pragma unroll
-      for (uint32_t d = 0; d < SMALL_CARD; ++d) cnt[d] += res == d ? 1u : 0u;
-      prop = res;
+      for (uint32_t d = 0; d < SMALL_CARD; ++d) cnt[d] += (uint32_t)(packed >> (d * 8u)) & 255u;
     }
 #pragma unroll
     for (uint32_t d = 0; d < SMALL_CARD; ++d)

@@ -21,7 +21,8 @@ def test_kernels_under_asan_ubsan():
     # execute the same kernel paths as the parity tests many more times: left to the plain build)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "not ks_against and not heavy_tying",
-                        os.path.join(ROOT, "tests", "test_kernels_emu.py")],
+                        os.path.join(ROOT, "tests", "test_kernels_emu.py"),
+                        os.path.join(ROOT, "tests", "test_multi_sweep.py"), "-m", "not gpu"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
     assert "passed" in r.stdout
