@@ -390,6 +390,16 @@ def main():
             engine.sample()
         engine.wait()
         ms_r, nl_r, ns_r = sampler.kernel_time("infer")
+    # ... and what a quiet `dw gibbs -i N` runs on an all-unary graph: the N sweeps in ONE launch
+    # (dwx_sample_n_async); aside too, never part of `value`
+    ms_m = ns_m = 0
+    N_MULTI = 100
+    if not args.no_repeat_infer and halo is None and hasattr(engine, "sample_n"):
+        engine.sample_n(N_MULTI); engine.wait()
+        sampler.kernel_time_reset(True)
+        engine.sample_n(N_MULTI)
+        engine.wait()
+        ms_m, _, ns_m = sampler.kernel_time("infer")
     sampler.kernel_time_reset(False)
     # per block: MAX over ranks; per rank: its own median (reported as the per-rank spread)
     blocks = list(blocks_local)
@@ -524,6 +534,8 @@ def main():
             "pull_grad_kernel_ms": (ms_p / ns_p) if ns_p else None,
             "infer_repeat_kernel_ms": (ms_r / ns_r) if ns_r else None,
             "infer_repeat_vars_per_sec": V * n_gpus / (ms_r / max(ns_r, 1) * 1e-3) if ns_r else None,
+            "infer_100_in_one_launch_ms_per_sweep": (ms_m / ns_m) if ns_m else None,
+            "infer_100_in_one_launch_vars_per_sec": V * n_gpus / (ms_m / max(ns_m, 1) * 1e-3) if ns_m else None,
         }
         if use_dist:
             n_steps_timed = args.steps * repeats

@@ -220,6 +220,9 @@ constexpr uint32_t BP_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t BP_DELTA_SLOTS = 4096, BP_MAX_DELTAS = BP_DELTA_SLOTS - 1;   // (the last slot stays 0: BP_EMPTY decodes to it)
 // one block of ballot pairs + the table of deltas: exactly the 160 KiB of a CU
 constexpr uint32_t BP_LDS_BYTES = BP_TILES * 64 + BP_DELTA_SLOTS * 8;
+// sweep8_kernel<MULTI>: a run of at least this many sweeps over a tile with idle lanes is cut
+// into this many slices per variable
+constexpr uint32_t MULTI_SLICES = 4, MULTI_SLICE_MIN_SWEEPS = 256;
 constexpr uint32_t ROWPTR_UNROLL = 2;                       // row pointers prefetched per lane
 constexpr uint32_t ROWPTR_UNROLL_CAT = 7;                   // ... for categorical all-unary graphs (sweep8_kernel)                       // row pointers prefetched per lane
 

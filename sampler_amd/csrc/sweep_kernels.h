@@ -622,11 +622,26 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
     issue_tile_loads<LEARN, K, !TAB>(P, dl, t, f);
     // the current tile out of LDS
     int delta = 0;
-    if (fits && t < d.nv) {
+    if (MULTI) {
+      // A tile with fewer variables than lanes (eight-value rows: 192 of 256) would leave lanes
+      // idle for thousands of draws: a long run is cut into MULTI_SLICES slices per variable and
+      // the (variable, slice) items are dealt out over all lanes -- the potentials are summed
+      // once per item, the draws of a slice are its own sweeps' (same uniforms, same verdicts),
+      // tallies add up, the slice with the last sweep stores the assignment.
+      if (fits) {
+        TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
+        const uint32_t n = P.n_sweeps;
+        const uint32_t S = (n >= MULTI_SLICE_MIN_SWEEPS && d.nv < BLOCK_THREADS) ? MULTI_SLICES : 1u;   // uniform
+        for (uint32_t item = t; item < S * d.nv; item += BLOCK_THREADS) {
+          const uint32_t sl = item / d.nv, var = item - sl * d.nv;
+          const VarPre vp = var == t ? pre : load_var_pre<false, false>(P, d.v0 + var);
+          const uint32_t k_lo = (uint32_t)((uint64_t)n * sl / S), k_hi = (uint32_t)((uint64_t)n * (sl + 1) / S);
+          infer_variable_multi<W_TERMS, true>(P, T, d.v0 + var, vp, k_lo, k_hi, sl + 1 == S);
+        }
+      }
+    } else if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
-      if (MULTI)
-        infer_variable_multi<W_TERMS, true>(P, T, d.v0 + t, pre);
-      else if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
+      if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
         delta = process_variable<LEARN, W_TERMS8, true, true>(P, T, d.v0 + t, pre, A, B, true);
       else   // (FIXED: boolean variables of a compact-record graph sum their potentials in fixed point)
         process_variable<LEARN, LEARN ? W_ARRAY : (TAB ? W_TERMS8 : W_TERMS), true, true>(P, T, d.v0 + t, pre, A, B, false);

@@ -794,11 +794,15 @@ DWX_DEV VarPre load_var_pre(const KernelParams &P, uint32_t p) {
 // cat_draw return by construction (their f32 fast paths only ever shortcut to this verdict).
 // Tallies are added once per value, the assignment is the last sweep's: bit for bit what
 // n_sweeps calls of the single-sweep path leave behind (tests/test_multi_sweep.py).
+// [k_lo, k_hi): the slice of the launch's sweeps this call draws (a tile with fewer variables
+// than lanes cuts a long run of sweeps into slices, so that every lane draws: sweep8_kernel);
+// the slice that holds the last sweep stores the assignment.
 template <int WMODE, bool FIXED>
-DWX_DEV void infer_variable_multi(const KernelParams &P, const TileView &T, uint32_t p, const VarPre pre) {
+DWX_DEV void infer_variable_multi(const KernelParams &P, const TileView &T, uint32_t p, const VarPre pre,
+                                  const uint32_t k_lo, const uint32_t k_hi, const bool store) {
   const uint32_t meta = pre.meta;
   if ((meta & VM_EVIDENCE) && !(P.flags & OPT_SAMPLE_EVIDENCE)) return;
-  const uint32_t card = meta >> VM_CARD_SHIFT, row0 = pre.row0, n = P.n_sweeps;
+  const uint32_t card = meta >> VM_CARD_SHIFT, row0 = pre.row0;
   const uint64_t vid = P.vid_offset + pre.orig;
   uint32_t prop = 0;
   if (!(meta & VM_CATEGORICAL)) {
@@ -806,7 +810,7 @@ DWX_DEV void infer_variable_multi(const KernelParams &P, const TileView &T, uint
     bool_potentials<WMODE, true, FIXED>(P, T, row0, P.assign_evid, p, pp, pn);
     const double scale = 1.0 + exp(pn - pp);
     uint32_t count = 0;
-    for (uint32_t k = 0; k < n; ++k) {
+    for (uint32_t k = k_lo; k < k_hi; ++k) {
       double A, B;
       philox_uniforms(P.seed, vid, P.sweep + k, A, B);
       prop = (A * scale < 1.0) ? 1u : 0u;
@@ -841,8 +845,8 @@ DWX_DEV void infer_variable_multi(const KernelParams &P, const TileView &T, uint
     uint32_t cnt[SMALL_CARD];
 #pragma unroll
     for (uint32_t d = 0; d < SMALL_CARD; ++d) cnt[d] = 0;
-    for (uint32_t k0 = 0; k0 < n; k0 += 255u) {
-      const uint32_t k1 = umin(n, k0 + 255u);
+    for (uint32_t k0 = k_lo; k0 < k_hi; k0 += 255u) {
+      const uint32_t k1 = umin(k_hi, k0 + 255u);
       unsigned long long packed = 0;
       for (uint32_t k = k0; k < k1; ++k) {
         double r, B;
@@ -864,14 +868,14 @@ DWX_DEV void infer_variable_multi(const KernelParams &P, const TileView &T, uint
     for (uint32_t d = 0; d < SMALL_CARD; ++d)
       if (d < card && cnt[d]) atomicAdd(&P.tally[row0 + d], cnt[d]);
   } else {
-    for (uint32_t k = 0; k < n; ++k) {
+    for (uint32_t k = k_lo; k < k_hi; ++k) {
       double A, B;
       philox_uniforms(P.seed, vid, P.sweep + k, A, B);
       prop = cat_draw<WMODE, true>(P, T, row0, card, P.assign_evid, p, A);
       atomicAdd(&P.tally[row0 + prop], 1u);
     }
   }
-  DWX_NT_STORE(prop, &P.assign_evid[p]);
+  if (store) DWX_NT_STORE(prop, &P.assign_evid[p]);
 }
 
 // want_delta (learning, TILE_PULL tiles only): instead of scattering gradient atomics,

@@ -83,6 +83,15 @@ def test_small_tiles_and_16_byte_records_emulated(emu):
     _both(emu, raw, 5, learn=1, compile_opts=dict(no_compact_records=1))
 
 
+def test_long_runs_are_sliced_over_idle_lanes_emulated(emu):
+    """256 sweeps and more over a tile with fewer variables than lanes: four (variable, slice)
+    items per variable, dealt out over all lanes (sweep8_kernel<MULTI>) -- same contract."""
+    _both(emu, synthetic.cfg4(400, card=8, seed=6, learn=False), 300)                 # 192 variables per tile
+    _both(emu, synthetic.cfg4(150, card=12, seed=8, learn=False), 257)                # LDS-scratch draws
+    _both(emu, synthetic.cfg3(300, n_weights=40, seed=9), 263, learn=1, compile_opts=dict(tile_vars=9, tile_edges=48))
+    _both(emu, synthetic.cfg3(700, n_weights=40, seed=9), 256, sample_evidence=True)  # (a last tile that is not full)
+
+
 def test_graphs_with_pairwise_factors_run_their_sweeps_one_by_one_emulated(emu):
     raw = synthetic.cfg3b(600, n_weights=32, seed=5)
     s = _both(emu, raw, 4, learn=1)
@@ -96,6 +105,10 @@ def test_n_sweeps_in_one_launch_equal_n_sweeps_gpu():
     lib = gpu_library()
     for name, raw, kw, learn in _cases(40):
         _both(lib, raw, 25, learn=learn, **kw)
+    # long runs: sliced over idle lanes
+    _both(lib, synthetic.cfg4(20_000, card=8, seed=6, learn=False), 300)
+    _both(lib, synthetic.cfg4(5_000, card=12, seed=8, learn=False), 257)
+    _both(lib, synthetic.cfg3(30_000, n_weights=400, seed=9), 263, learn=1, compile_opts=dict(tile_vars=100, tile_edges=1100))
 
 
 @pytest.mark.gpu
