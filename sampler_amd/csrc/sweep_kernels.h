@@ -632,7 +632,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
         TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
         const uint32_t n = P.n_sweeps;
         const uint32_t S = (n >= MULTI_SLICE_MIN_SWEEPS && d.nv < BLOCK_THREADS) ? MULTI_SLICES : 1u;   // uniform
-        for (uint32_t item = t; item < S * d.nv; item += BLOCK_THREADS) {
+        if (S == 1u) {   // (its own call: the loop over the sweeps keeps scalar bounds)
+          if (t < d.nv) infer_variable_multi<W_TERMS, true>(P, T, d.v0 + t, pre, 0u, n, true);
+        } else for (uint32_t item = t; item < S * d.nv; item += BLOCK_THREADS) {
           const uint32_t sl = item / d.nv, var = item - sl * d.nv;
           const VarPre vp = var == t ? pre : load_var_pre<false, false>(P, d.v0 + var);
           const uint32_t k_lo = (uint32_t)((uint64_t)n * sl / S), k_hi = (uint32_t)((uint64_t)n * (sl + 1) / S);
