@@ -868,6 +868,8 @@ DWX_DEV void infer_variable_multi(const KernelParams &P, const TileView &T, uint
     for (uint32_t d = 0; d < SMALL_CARD; ++d)
       if (d < card && cnt[d]) atomicAdd(&P.tally[row0 + d], cnt[d]);
   } else {
+    // (bigger domains: cat_draw sums the potentials into the tile's LDS scratch on every call; two
+    // slices of one variable write the same values there)
     for (uint32_t k = k_lo; k < k_hi; ++k) {
       double A, B;
       philox_uniforms(P.seed, vid, P.sweep + k, A, B);
