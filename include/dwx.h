@@ -359,7 +359,11 @@ int dwx_stream(dwx_sampler *s, void **stream);
  * stream around every launch since the last reset: total milliseconds, number of
  * kernel launches and number of sweeps (a learning sweep of several colours or
  * mini-batches is ONE sweep of several launches).  kind: 0 = inference sweep kernels, 1 = learning
- * sweep kernels, 2 = the pull-based gradient kernel of learning sweeps. */
+ * sweep kernels, 2 = the pull-based gradient kernel of learning sweeps, 3 = no time: launches =
+ * sweeps = the split learning sweeps dwx_sample_sgd_async handed over as ONE graph launch since
+ * the sampler was created (DWX_GRAPH=n in the environment: a sweep of >= n mini-batches is
+ * captured and replayed as a hipGraph from the plan level's second sweep on, never while timing
+ * is enabled; off by default -- measured, it buys nothing: DESIGN.md section 3.5). */
 int dwx_kernel_time(dwx_sampler *s, int kind, double *ms, uint64_t *launches, uint64_t *sweeps);
 int dwx_kernel_time_reset(dwx_sampler *s, int enable);
 

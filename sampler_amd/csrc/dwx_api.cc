@@ -193,7 +193,12 @@ struct dwx_sampler {
     SortRec8 *d_sorted = nullptr;
     bool layout_done = false;          // ensure_level_layout ran (whatever it decided)
     uint64_t sweeps = 0;               // learning sweeps run at this level (plan_layouts == 0: the layout comes after 2048)
+    // a split sweep of this level as ONE graph launch (dwx_sample_sgd_async): the instantiated graph,
+    // patched in place every sweep; use_graph < 0: replay failed once, the level stays on plain launches
+    rt::graph_exec_t gexec = nullptr;
+    int use_graph = 0;
     ~Level() {
+      rt::graph_exec_destroy(gexec);
       rt::dfree(d_supers); rt::dfree(d_sorted);
       rt::dfree(d_inc_wid); rt::dfree(d_inc_slot); rt::dfree(d_inc_d); rt::dfree(d_t_static);
       for (auto &t : bp) { rt::dfree(t.d_ell); rt::dfree(t.d_tile0); }
@@ -215,6 +220,7 @@ struct dwx_sampler {
   uint64_t infer_sweeps = 0;  // inference sweeps since the last clear_tallies
   // kernel timing
   bool timing = false;
+  uint64_t graph_launches = 0;        // split learning sweeps handed over as one graph launch
   std::vector<TimedSpan> spans;
   double t_ms[3] = {0, 0, 0};   // [0] inference sweep kernels, [1] learning sweep kernels, [2] pull_grad
   uint64_t t_launches[3] = {0, 0, 0}, t_sweeps[3] = {0, 0, 0};
@@ -1136,6 +1142,12 @@ double plan_min_step(dwx_sampler *s) {
   return st * (L->c_max + r) > 1.0 ? 1.0 / (L->c_max + r) : st;   // batch_step (aux_kernels.h)
 }
 
+uint64_t layout_after_sweeps() {
+  uint64_t n = 2048;
+  if (const char *e = getenv("DWX_LAYOUT_AFTER_SWEEPS")) n = (uint64_t)std::max(1L, atol(e));   // test hook
+  return n;
+}
+
 // accumulate the gradient of one chunk of the plan (sampling both chains on the way)
 void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
   rt::set_device(s->device);
@@ -1145,9 +1157,7 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
   P.sweep = s->sweep;
   // a level that has run this many sweeps is worth a layout of its own (dwx_options.plan_layouts
   // == 0: the run pays 0.3 s once where it has already spent as much on the default layout)
-  uint64_t LAYOUT_AFTER_SWEEPS = 2048;
-  if (const char *e = getenv("DWX_LAYOUT_AFTER_SWEEPS")) LAYOUT_AFTER_SWEEPS = (uint64_t)std::max(1L, atol(e));   // test hook
-  if (chunk == 0 && s->plan_level && ++s->plan_level->sweeps == LAYOUT_AFTER_SWEEPS && s->opts.plan_layouts == 0)
+  if (chunk == 0 && s->plan_level && ++s->plan_level->sweeps == layout_after_sweeps() && s->opts.plan_layouts == 0)
     ensure_level_layout(s, s->plan_level, s->plan_batches);
   const dwx_sampler::Level &L = *s->plan_level;
   const bool split = s->plan_batches > 1;
@@ -1170,37 +1180,22 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
     if (!split) { if (chunk + 1 == s->plan_chunks.size()) { pb = L.inc_begin.front(); pe = L.inc_end.back(); } }
     else { pb = L.inc_begin[chunk]; pe = L.inc_end[chunk]; }
   }
-  // block pull of the same group as the list below: the whole sweep (un-split, after the
-  // last colour launch) or this chunk
+  // block pull of the same group as the list: the whole sweep (un-split, after the last colour
+  // launch) or this chunk; what did not fit the block tables' rows stays on the weight-sorted list
+  // (config 3: 2.8 % of the entries) for pull_grad_kernel.  (The list walked on a side stream
+  // beside pull_ell_kernel, fold_partials_kernel waiting for both: bench step 0.5523 -> 0.5507 ms,
+  // pull 0.1127 -> 0.1108 -- inside the noise, not kept.)
+  const dwx_sampler::Level::BlockTable *bt = nullptr;
   if (fast && !L.bp.empty() && (split || chunk + 1 == s->plan_chunks.size())) {
-    const dwx_sampler::Level::BlockTable &bt = L.bp[split ? chunk : 0];
-    if (bt.blocks) {
-      const unsigned grid = bt.blocks * bt.parts;
-      auto go = [&](auto kernel) {
-        rt::launch(kernel, grid, BP_THREADS, BP_LDS_BYTES, s->stream, (const U32x4 *)bt.d_ell,
-                   (const uint32_t *)bt.d_tile0, bt.parts, (const long long *)L.d_bp_qtab, L.bp_deltas, L.bp_wp,
-                   (const unsigned long long *)s->d_delta, L.d_bp_partial);
-      };
-      const bool uni = L.bp_deltas == 1;
-      if (bt.depth == 2) { if (uni) go(pull_ell_kernel<2, true>); else go(pull_ell_kernel<2, false>); }
-      else { if (uni) go(pull_ell_kernel<1, true>); else go(pull_ell_kernel<1, false>); }
-      const uint32_t W = (uint32_t)s->cg->W;
-      const unsigned fgrid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 4096u);
-      if (uni)
-        rt::launch(fold_partials_kernel<true>, fgrid, BLOCK_THREADS, 0, s->stream, (const long long *)L.d_bp_partial,
-                   bt.blocks, L.bp_wp, W, s->d_grad, (const long long *)L.d_bp_qtab);
-      else
-        rt::launch(fold_partials_kernel<false>, fgrid, BLOCK_THREADS, 0, s->stream, (const long long *)L.d_bp_partial,
-                   bt.blocks, L.bp_wp, W, s->d_grad, (const long long *)L.d_bp_qtab);
-      pulled = true;
-    }
+    bt = &L.bp[split ? chunk : 0];
+    if (!bt->blocks) bt = nullptr;
   }
-  if (pe > pb) {
+  auto launch_list = [&](rt::stream_t st) {
     const uint32_t n = pe - pb;
     const unsigned chunk_sz = BLOCK_THREADS * PULL_RUN;
     const unsigned grid = std::min<unsigned>((n + chunk_sz - 1) / chunk_sz, 256u * DWX_PULL_GRID);
     auto go = [&](auto kernel) {
-      rt::launch(kernel, grid, BLOCK_THREADS, 0, s->stream, (const uint32_t *)(L.d_inc_wid + pb),
+      rt::launch(kernel, grid, BLOCK_THREADS, 0, st, (const uint32_t *)(L.d_inc_wid + pb),
                  (const uint32_t *)(L.d_inc_slot + pb), (const float *)(L.d_inc_d + pb), n,
                  (const unsigned long long *)s->d_delta, s->d_grad);
     };
@@ -1208,7 +1203,28 @@ void enqueue_learn_chunk(dwx_sampler *s, uint32_t chunk) {
     // million weights does not)
     if ((uint64_t)n >= 8 * s->cg->W) go(pull_grad_kernel<true>); else go(pull_grad_kernel<false>);
     pulled = true;
+  };
+  if (bt) {
+    const unsigned grid = bt->blocks * bt->parts;
+    auto go = [&](auto kernel) {
+      rt::launch(kernel, grid, BP_THREADS, BP_LDS_BYTES, s->stream, (const U32x4 *)bt->d_ell,
+                 (const uint32_t *)bt->d_tile0, bt->parts, (const long long *)L.d_bp_qtab, L.bp_deltas, L.bp_wp,
+                 (const unsigned long long *)s->d_delta, L.d_bp_partial);
+    };
+    const bool uni = L.bp_deltas == 1;
+    if (bt->depth == 2) { if (uni) go(pull_ell_kernel<2, true>); else go(pull_ell_kernel<2, false>); }
+    else { if (uni) go(pull_ell_kernel<1, true>); else go(pull_ell_kernel<1, false>); }
+    const uint32_t W = (uint32_t)s->cg->W;
+    const unsigned fgrid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 4096u);
+    if (uni)
+      rt::launch(fold_partials_kernel<true>, fgrid, BLOCK_THREADS, 0, s->stream, (const long long *)L.d_bp_partial,
+                 bt->blocks, L.bp_wp, W, s->d_grad, (const long long *)L.d_bp_qtab);
+    else
+      rt::launch(fold_partials_kernel<false>, fgrid, BLOCK_THREADS, 0, s->stream, (const long long *)L.d_bp_partial,
+                 bt->blocks, L.bp_wp, W, s->d_grad, (const long long *)L.d_bp_qtab);
+    pulled = true;
   }
+  if (pe > pb) launch_list(s->stream);
   if (timing) {
     rt::event_record(sp.c, s->stream);
     sp.launches = launches; sp.has_pull = pulled; sp.new_sweep = chunk == 0;
@@ -1720,10 +1736,59 @@ int dwx_sample_sgd_async(dwx_sampler *s, double stepsize) {
   return guarded([&]() {
     make_plan(s, stepsize, 0);
     const size_t n = s->plan_chunks.size();
-    for (size_t c = 0; c < n; ++c) {
-      s->cur_chunk = (uint32_t)c;
-      enqueue_learn_chunk(s, (uint32_t)c);
-      if (s->plan_batches > 1 || c + 1 == n) enqueue_apply(s);
+    auto enqueue_sweep = [&]() {
+      for (size_t c = 0; c < n; ++c) {
+        s->cur_chunk = (uint32_t)c;
+        enqueue_learn_chunk(s, (uint32_t)c);
+        if (s->plan_batches > 1 || c + 1 == n) enqueue_apply(s);
+      }
+    };
+    // Graph replay (DWX_GRAPH=n in the environment: sweeps of at least n mini-batches; default
+    // off).  A split sweep is a chain of 2-4 short dependent launches per mini-batch; from the
+    // level's second sweep on (the first one has done every lazy allocation) it can be captured,
+    // patched into the level's instantiated graph -- only the sweep counter and the step differ
+    // from sweep to sweep -- and launched as ONE graph.  Measured on config 4's learning sweep
+    // (64 mini-batches, 128 launches): 1.610 -> 1.603 ms, i.e. nothing: the chain is bound by the
+    // latency of the chunk kernels themselves (17.5-22 us each for 3 us of work at full width,
+    // profiles/r03/kernel_stats_cfg4learn.csv), not by the host's launches -- hence off.  Never
+    // while kernels are being timed (the events would land inside the graph), nor on the sweep
+    // that builds the level's own layout (host work and uploads).
+    dwx_sampler::Level *L = s->plan_level;
+    const char *genv = getenv("DWX_GRAPH");
+    const int graph_min_chunks = genv ? atoi(genv) : 0;
+    const bool replay = L && graph_min_chunks > 0 && s->plan_batches > 1 && n >= (size_t)graph_min_chunks &&
+                        !s->timing && L->use_graph >= 0 && L->sweeps >= 1 &&
+                        !(s->opts.plan_layouts == 0 && L->sweeps + 1 == layout_after_sweeps());
+    if (!replay) {
+      enqueue_sweep();
+    } else {
+      rt::set_device(s->device);
+      rt::graph_t g = nullptr;
+      rt::capture_begin(s->stream);
+      try {
+        enqueue_sweep();
+        g = rt::capture_end(s->stream);
+      } catch (...) {
+        rt::capture_abandon(s->stream);
+        L->use_graph = -1;
+        throw;
+      }
+      bool launched = false;
+      try {
+        if (L->gexec && !rt::graph_exec_update(L->gexec, g)) { rt::graph_exec_destroy(L->gexec); L->gexec = nullptr; }
+        if (!L->gexec) L->gexec = rt::graph_instantiate(g);
+        rt::graph_launch(L->gexec, s->stream);
+        launched = true;
+        L->use_graph = 1;
+        ++s->graph_launches;
+      } catch (...) {
+        // nothing of the captured sweep has run: this level goes back to plain launches for good
+        L->use_graph = -1;
+        rt::graph_exec_destroy(L->gexec);
+        L->gexec = nullptr;
+      }
+      rt::graph_destroy(g);
+      if (!launched) { --L->sweeps; enqueue_sweep(); }
     }
     ++s->sweep;
     s->plan_valid = false;
@@ -2007,7 +2072,13 @@ int dwx_kernel_time_reset(dwx_sampler *s, int enable) {
 }
 
 int dwx_kernel_time(dwx_sampler *s, int kind, double *ms, uint64_t *launches, uint64_t *sweeps) {
-  if (!s || kind < 0 || kind > 2) return fail(DWX_E_INVALID, "bad argument");
+  if (!s || kind < 0 || kind > 3) return fail(DWX_E_INVALID, "bad argument");
+  if (kind == 3) {   // graph replays of split learning sweeps since the sampler was created (no device time)
+    if (ms) *ms = 0.0;
+    if (launches) *launches = s->graph_launches;
+    if (sweeps) *sweeps = s->graph_launches;
+    return DWX_OK;
+  }
   return guarded([&]() {
     rt::set_device(s->device);
     drain_spans(s);

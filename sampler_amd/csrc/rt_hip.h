@@ -83,6 +83,42 @@ inline double event_elapsed_ms(event_t a, event_t b) {
   return ms;
 }
 
+// Stream capture + graph replay (a split learning sweep is a chain of dozens of short dependent
+// launches: captured once per plan level, re-captured and patched in place every sweep -- the
+// sweep counter and the step change, the topology does not -- and handed over as ONE launch).
+typedef hipGraph_t graph_t;
+typedef hipGraphExec_t graph_exec_t;
+inline void capture_begin(stream_t s) { DWX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed)); }
+inline graph_t capture_end(stream_t s) {
+  graph_t g = nullptr;
+  DWX_HIP(hipStreamEndCapture(s, &g));
+  return g;
+}
+// (after an error inside a capture: leave the stream usable, keep the first error)
+inline void capture_abandon(stream_t s) {
+  graph_t g = nullptr;
+  (void)hipStreamEndCapture(s, &g);
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+}
+inline graph_exec_t graph_instantiate(graph_t g) {
+  graph_exec_t e = nullptr;
+  DWX_HIP(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
+  return e;
+}
+// patch an instantiated graph with the parameters of a freshly captured one; false: the topology
+// differs (the caller instantiates anew)
+inline bool graph_exec_update(graph_exec_t e, graph_t g) {
+  hipGraphNode_t bad = nullptr;
+  hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
+  const hipError_t rc = hipGraphExecUpdate(e, g, &bad, &res);
+  if (rc != hipSuccess) (void)hipGetLastError();
+  return rc == hipSuccess && res == hipGraphExecUpdateSuccess;
+}
+inline void graph_launch(graph_exec_t e, stream_t s) { DWX_HIP(hipGraphLaunch(e, s)); }
+inline void graph_destroy(graph_t g) { if (g) (void)hipGraphDestroy(g); }
+inline void graph_exec_destroy(graph_exec_t e) { if (e) (void)hipGraphExecDestroy(e); }
+
 template <class K>
 inline void allow_dynamic_lds(K kernel, size_t bytes) {
   if (bytes > 48 * 1024)

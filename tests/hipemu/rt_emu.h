@@ -39,6 +39,19 @@ inline void event_record(event_t e, stream_t) { *e = std::chrono::steady_clock::
 inline double event_elapsed_ms(event_t a, event_t b) {
   return std::chrono::duration<double, std::milli>(*b - *a).count();
 }
+// "capture": launches between begin and end run eagerly (as everywhere in this harness); the
+// graph objects are tokens and a graph launch has nothing left to do
+typedef void *graph_t;
+typedef void *graph_exec_t;
+inline void capture_begin(stream_t) {}
+inline graph_t capture_end(stream_t) { return (graph_t)1; }
+inline void capture_abandon(stream_t) {}
+inline graph_exec_t graph_instantiate(graph_t) { return (graph_exec_t)1; }
+inline bool graph_exec_update(graph_exec_t, graph_t) { return true; }
+inline void graph_launch(graph_exec_t, stream_t) {}
+inline void graph_destroy(graph_t) {}
+inline void graph_exec_destroy(graph_exec_t) {}
+
 template <class K>
 inline void allow_dynamic_lds(K, size_t) {}
 

@@ -64,6 +64,44 @@ def test_synth_exact(lib):
                stepsize=0.001)
 
 
+def test_split_learning_sweep_replayed_as_one_graph(lib, monkeypatch):
+    """DWX_GRAPH=4: dwx_sample_sgd_async hands a split sweep (>= 4 mini-batches: config 4's tied
+    weights) over as ONE hipGraph launch from the plan level's second sweep on -- captured every
+    sweep, patched into the level's instantiated graph (only the Philox sweep counter and the step
+    change).  Exact against the oracle sweep by sweep, identical to the plain launches (the default),
+    and a graph with side streams inside (wave / workgroup bins fork beside the tile sweep) replays
+    as well."""
+    raw = synthetic.cfg4(20_000, card=8, seed=7, learn=True)
+    monkeypatch.setenv("DWX_GRAPH", "4")
+    s, _ = run_parity(lib, raw, n_learn=6, n_infer=2, stepsize=0.001, decay=1.0)
+    batches, n_chunks, _ = s.sgd_plan(0.001)
+    assert batches > 1 and n_chunks >= 4, (batches, n_chunks)
+    assert s.kernel_time("graph")[1] == 5, s.kernel_time("graph")
+    # (timing on: plain launches, the events must not land inside a graph)
+    s.kernel_time_reset(True)
+    s.sample_sgd(0.001); s.wait()
+    assert s.kernel_time("learn")[1] >= n_chunks and s.kernel_time("graph")[1] == 5
+    s.kernel_time_reset(False)
+    monkeypatch.delenv("DWX_GRAPH")
+    s2, _ = run_parity(lib, raw, n_learn=6, n_infer=2, stepsize=0.001, decay=1.0)
+    assert s2.kernel_time("graph")[1] == 0
+    s2.sample_sgd(0.001); s2.wait()
+    assert np.array_equal(s.weights, s2.weights)
+    assert np.array_equal(s.assignments("free"), s2.assignments("free"))
+    assert np.array_equal(s.assignments("evid"), s2.assignments("evid"))
+    monkeypatch.setenv("DWX_GRAPH", "4")
+    # a decaying step walks down the plan levels: every level gets a graph of its own
+    s3, _ = run_parity(lib, raw, n_learn=12, n_infer=1, stepsize=0.002, decay=0.7)
+    assert s3.kernel_time("graph")[1] >= 3, s3.kernel_time("graph")
+    # forks: lanes, waves and workgroups per variable in one split sweep
+    from randgraph import degree_graph_fast
+    s4, _ = run_parity(lib, degree_graph_fast(8, n_low=20_000, n_high=300, max_degree=20_000, W=500),
+                       n_learn=4, n_infer=1, stepsize=0.0005, decay=1.0, check_index=False)
+    assert s4.graph.info.num_wide_tiles > 0 and s4.graph.info.num_giant_tiles > 0
+    if s4.sgd_plan(0.0005)[1] >= 4:
+        assert s4.kernel_time("graph")[1] == 3, s4.kernel_time("graph")
+
+
 def test_small_tiles_and_giant_variable(lib):
     raw = synthetic.cfg3b(300, n_weights=16, seed=8)
     run_parity(lib, raw, n_learn=3, n_infer=3, compile_opts=dict(tile_vars=7, tile_edges=16, tile_rows=7))
