@@ -19,7 +19,14 @@ def test_kernels_under_asan_ubsan():
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     # (the long statistical runs -- KS against the reference's marginals, 30-epoch learning --
     # execute the same kernel paths as the parity tests many more times: left to the plain build)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+    # (the cases are independent: four workers when pytest-xdist is there -- the ASan build runs the
+    # fibers of the emulation several times slower than the plain one)
+    try:
+        import xdist  # noqa: F401
+        workers = ["-n", "4"] if (os.cpu_count() or 1) >= 4 else []
+    except ImportError:
+        workers = []
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", *workers,
                         "-k", "not ks_against and not heavy_tying",
                         os.path.join(ROOT, "tests", "test_kernels_emu.py"),
                         os.path.join(ROOT, "tests", "test_multi_sweep.py"), "-m", "not gpu"],
