@@ -159,6 +159,66 @@ def test_cfg3b_full_size_exact_against_oracle(lib):
     assert s.graph.info.num_colors >= 2
 
 
+def _host_memory_available_gb():
+    """What this process may still allocate: the cgroup's limit minus its use, or MemAvailable."""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            room = int(lim) - int(open("/sys/fs/cgroup/memory.current").read())
+            avail = room if avail is None else min(avail, room)
+    except (OSError, ValueError):
+        pass
+    return (avail or 0) / 1e9
+
+
+def test_config5_whole_graph_on_one_gpu_exact_against_oracle(lib):
+    """BASELINE config 5's WHOLE graph -- 100 M boolean variables x 10 unary factors = 10^9 records,
+    1 M weights tied to 1 000 factors each -- on ONE MI355X (35 GB of its 288): one learning sweep
+    (a split plan: mini-batches, block pull and apply per chunk) and one inference sweep, both
+    chains' assignments and the tallies bit for bit, weights to 1e-12, against the oracle that
+    follows the same chunk boundaries.  (run_parity's body with numpy in place of Python lists.)
+
+    The full size takes 185 GB of host memory and three minutes (graph + compile + the oracle's
+    copy): DWX_BIG_TESTS=1, run once per round through tools/big_parity.sh with its log under
+    profiles/.  By default HALF of it -- 50 M variables, 5 x 10^8 records: the first size whose
+    record streams pass 4 GB, a split plan -- in 65 s and 94 GB, skipped on a box without the room."""
+    from oracle import binding as orc
+    from parity import learn_sweep_both
+    V = int(os.environ.get("DWX_BIG_VARS", "100000000" if os.environ.get("DWX_BIG_TESTS") == "1" else "50000000"))
+    need = 2.0e-6 * V + 20
+    if _host_memory_available_gb() < need:
+        pytest.skip("needs %.0f GB of host memory" % need)
+    raw = synthetic.cfg3(V, n_weights=1_000_000, seed=1234)
+    g = dwx.Graph(raw, lib=lib)
+    o = orc.Oracle(raw)
+    o.set_fixed_point_mask(g.fixed_point_mask())
+    order, off = g.schedule()
+    assert np.array_equal(np.sort(order), np.arange(V, dtype=order.dtype))
+    assert o.sched_check_independent(order, off)
+    s = dwx.GibbsSampler(g, seed=77)
+    assert g.info.num_index_entries == 10 * V and g.info.num_super_tiles > 0
+    batches = learn_sweep_both(s, o, order, 77, 0, 0.001)
+    print("config 5 on one GPU: V = %d, %d mini-batches per learning sweep, device bytes %.1f GB"
+          % (V, batches, g.info.device_bytes / 1e9))
+    assert np.array_equal(s.assignments("free"), o.assignments("free")), "free chain differs"
+    assert np.array_equal(s.assignments("evid"), o.assignments("evid")), "evid chain differs"
+    np.testing.assert_allclose(s.weights, o.weights, rtol=1e-12, atol=1e-12)
+    assert np.abs(s.weights).max() > 0
+    s.clear_tallies(); o.clear_tallies()
+    s.sample(); s.wait()
+    o.sched_sample(order, off, 77, 1)
+    assert np.array_equal(s.assignments("evid"), o.assignments("evid")), "inference chain differs"
+    t, n = s.tallies()
+    assert np.array_equal(t, o.tallies[:len(t)]) and np.array_equal(n, o.nsamples)
+
+
 def test_cfg2_cfg4_full_size_exact_against_oracle(lib):
     """BASELINE configs 2 (1 M boolean x 10 ISTRUE) and 4 (5 M categorical, domain 8) at full
     size, inference only, three sweeps each (gathers, table build, table): bit for bit."""
