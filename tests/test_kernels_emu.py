@@ -65,6 +65,30 @@ def test_synth_cfg4(lib):
                stepsize=0.01)
 
 
+def test_split_sweep_through_the_graph_replay_path(lib, monkeypatch):
+    """DWX_GRAPH=n: dwx_sample_sgd_async captures a split sweep and replays it as one graph launch
+    (the harness's "capture" runs the launches eagerly and its graph launch is a no-op: the host
+    logic -- which sweeps are captured, the per-level graph, the counter -- is what runs here;
+    tests/test_gpu_parity.py has the real thing)."""
+    raw = synthetic.cfg4(700, card=5, seed=7, learn=True)
+    monkeypatch.setenv("DWX_GRAPH", "2")
+    s, _ = run_parity(lib, raw, n_learn=5, n_infer=1, stepsize=0.01, decay=1.0,
+                      compile_opts=dict(tile_vars=16))
+    batches, n_chunks, _ = s.sgd_plan(0.01)
+    assert batches > 1 and n_chunks >= 2, (batches, n_chunks)
+    assert s.kernel_time("graph")[1] == 4, s.kernel_time("graph")       # every sweep but the level's first
+    s.kernel_time_reset(True)                                           # timed sweeps are never captured
+    s.sample_sgd(0.01); s.wait()
+    assert s.kernel_time("graph")[1] == 4
+    s.kernel_time_reset(False)
+    monkeypatch.delenv("DWX_GRAPH")
+    s2, _ = run_parity(lib, raw, n_learn=5, n_infer=1, stepsize=0.01, decay=1.0,
+                       compile_opts=dict(tile_vars=16))
+    assert s2.kernel_time("graph")[1] == 0                              # off by default
+    s2.sample_sgd(0.01); s2.wait()
+    assert np.array_equal(s.weights, s2.weights)
+
+
 @pytest.mark.parametrize("compact", [True, False])
 def test_all_unary_compact_records(lib, compact):
     # all-unary graphs stream 8-byte records (EdgeRec8) by default: every sign class
