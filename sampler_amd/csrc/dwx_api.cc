@@ -688,22 +688,36 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
     RawArray<long long> ts((size_t)nc * 2 * c.W);
     parallel_ranges((uint64_t)nc * 2 * c.W, nth, [&](uint64_t b, uint64_t e) { std::fill(ts.data() + b, ts.data() + e, 0LL); });
     const long long one = (long long)FIX_SCALE;
-    parallel_ranges(nc, std::min(nth, nc), [&](uint64_t kb, uint64_t ke) {
-      for (uint64_t k = kb; k < ke; ++k) {
-        long long *row = ts.data() + k * 2 * c.W, *hrow = row + c.W;
-        const uint32_t p0 = c.tile_v[groups[k].t0], p1 = c.tile_v[groups[k].t1];
-        for (uint32_t p = p0; p < p1; ++p) {
-          const uint32_t m = c.v_meta[p];
-          if (!triggers_sgd(o, m)) continue;
-          for_each_record_bound(c, p, [&](uint32_t e, double bound) {
-            hrow[c.edges[e].wid] += std::llrint(H_SCALE * bound);
-          });
-          if (m & VM_CATEGORICAL) continue;   // (their counts depend on the samples: dynamic)
-          for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p] + 1]; ++e)
-            if (!c.w_fixed[c.edges[e].wid]) row[c.edges[e].wid] += one;
-        }
+    // Few groups (the un-split level has ONE: a single thread used to walk all of config 5's 10^9
+    // records here): the variables of a group are shared out over the threads instead, which add
+    // into the group's rows atomically -- integer sums, the same tables in any order.
+    auto group_rows = [&](uint64_t k, uint32_t pb, uint32_t pe, auto &&add) {
+      long long *row = ts.data() + k * 2 * c.W, *hrow = row + c.W;
+      for (uint32_t p = pb; p < pe; ++p) {
+        const uint32_t m = c.v_meta[p];
+        if (!triggers_sgd(o, m)) continue;
+        for_each_record_bound(c, p, [&](uint32_t e, double bound) {
+          add(&hrow[c.edges[e].wid], (long long)std::llrint(H_SCALE * bound));
+        });
+        if (m & VM_CATEGORICAL) continue;   // (their counts depend on the samples: dynamic)
+        for (uint32_t e = c.row_ptr[c.v_row[p]]; e < c.row_ptr[c.v_row[p] + 1]; ++e)
+          if (!c.w_fixed[c.edges[e].wid]) add(&row[c.edges[e].wid], one);
       }
-    }, 2);
+    };
+    if (nc >= nth || nth <= 1) {
+      parallel_ranges(nc, std::min(nth, nc), [&](uint64_t kb, uint64_t ke) {
+        for (uint64_t k = kb; k < ke; ++k)
+          group_rows(k, c.tile_v[groups[k].t0], c.tile_v[groups[k].t1], [](long long *a, long long v) { *a += v; });
+      }, 2);
+    } else {
+      for (uint64_t k = 0; k < nc; ++k) {
+        const uint32_t p0 = c.tile_v[groups[k].t0], p1 = c.tile_v[groups[k].t1];
+        parallel_ranges(p1 - p0, nth, [&](uint64_t b, uint64_t e) {
+          group_rows(k, p0 + (uint32_t)b, p0 + (uint32_t)e,
+                     [](long long *a, long long v) { __atomic_fetch_add(a, v, __ATOMIC_RELAXED); });
+        });
+      }
+    }
     {
       const uint32_t T = std::max(1u, std::min(nth, 16u));
       std::vector<double> hm(T, 0.0), tm(T, 0.0);
