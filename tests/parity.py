@@ -14,7 +14,7 @@ EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
 
 
 def emu_library(asan=False):
-    subprocess.run(["make", "-s", "-C", EMU_DIR], check=True)
+    subprocess.run(["make", "-s", "-j4", "-C", EMU_DIR], check=True)
     name = "libdwx_emu_asan.so" if asan else "libdwx_emu.so"
     return dwx.Library(os.path.join(EMU_DIR, "build", name))
 

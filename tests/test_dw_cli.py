@@ -18,7 +18,7 @@ DW_EMU = os.path.join(ROOT, "tests", "hipemu", "build", "dw_emu")
 
 @pytest.fixture(scope="module")
 def dw_emu():
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "hipemu")], check=True)
+    subprocess.run(["make", "-s", "-j4", "-C", os.path.join(ROOT, "tests", "hipemu")], check=True)
     return DW_EMU
 
 

@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def dw_emu():
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "hipemu")], check=True)
+    subprocess.run(["make", "-s", "-j4", "-C", os.path.join(ROOT, "tests", "hipemu")], check=True)
     return DW_EMU
 
 
