@@ -41,9 +41,50 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-# algorithmic bytes per variable, SURVEY.md §8(d): (inference, learning)
-ALGO_BYTES = {"cfg3": (340.0, 404.0), "cfg5b": (564.0, 684.0)}
+# SURVEY.md §8(d)'s byte model per variable (inference, learning): a 16-byte factor record + 4-byte
+# index + 4-byte weight per factor.  The layout that ships moves a third of that (8-byte weight-
+# sorted records, weights out of L2), so this model is NOT a lower bound of the traffic any more:
+# it is reported as `frac_survey_model` only.
+SURVEY_BYTES = {"cfg3": (340.0, 404.0), "cfg5b": (564.0, 684.0)}
 RECORDS_PER_VAR = {"cfg3": 10, "cfg5b": 14}
+# the kernel sources whose sha256 stamps profiles/traffic.json (PMC bytes per launch): a kernel
+# change must not silently keep an old counter figure
+KERNEL_SOURCES = ("sweep_kernels.h", "tile_walk.h", "aux_kernels.h", "device_types.h")
+
+
+def kernel_sources_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "sampler_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def layout_bytes_per_var(wl, learn, info, V, Vq, W, sorted_path):
+    """Minimum HBM bytes per visited variable of the layout that ships ('layout
+    byte model'): every datum the dominant sweep kernel must move once -- a LOWER bound of the
+    PMC traffic (no re-fetched weight lines, no partial sectors).
+    cfg3 / sorted_sweep_kernel: 8-byte weight-sorted records (only records with d != 0 exist),
+      the per-variable words (v_meta, v_orig, v_row [+ v_init when learning]: 4 B each), the
+      assignment store(s) (4 B per chain written), learning: two ballot words per wave of 64
+      (0.25 B), inference: the tally read-modify-write (8 B per line-resident u32), and the f32
+      weight table once per XCD L2 (8 x 4 W bytes per launch).
+    cfg3 / sweep8_kernel (no sorted copy): the same with 8-byte variable-major records + 4-byte row pointers.
+    cfg5b / sweep_kernel: 16-byte records (14 per variable), per-variable words, the useful 4 bytes
+      of each neighbour assignment gathered (8 per variable and chain), stores; gradient atomics
+      and ballots are left out (lower bound)."""
+    units = V if learn else Vq
+    if wl == "cfg3":
+        n_rec = float(info.num_sorted_records) / V if (sorted_path and info.num_sorted_records) else float(RECORDS_PER_VAR[wl])
+        b = 8.0 * n_rec + (16.0 if learn else 12.0) + (8.0 if learn else 4.0)
+        b += 0.25 if learn else 8.0
+        if not sorted_path:
+            b += 4.0
+        b += 8.0 * 4.0 * W / max(units, 1)
+        return b
+    n_rec = float(info.num_index_entries) / V
+    chains = 2 if learn else 1
+    return 16.0 * n_rec + (16.0 if learn else 12.0) + 4.0 * chains + 4.0 * 8 * chains + (0.0 if learn else 8.0)
 
 
 def log(*a):
@@ -68,7 +109,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-repeat-infer", action="store_true",
                     help="skip the untimed repeated-inference leg (profiling runs: keeps the kernel stats clean)")
     ap.add_argument("--no-gather-ceiling", action="store_true",
-                    help="skip tools/gather_bench --ceiling (roofline.secondary.peak is then the committed figure)")
+                    help="skip tools/sorted_bench / gather_bench --ceiling (roofline.secondary.reference_loop_rate is then the committed figure)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / JSON plumbing only, over gloo on CPU: no GPU, no sampler")
     ap.add_argument("--weights", type=int, default=0, help="override the weight count (experiments)")
@@ -426,72 +467,92 @@ def main():
         # block (both chains); an inference launch visits the query variables only
         # (evidence is skipped, as in the reference, but still counted in vars/sec)
         Vq = int(graph.info.num_query_variables)
-        B_INFER, B_LEARN = ALGO_BYTES[wl]
+        S_INFER, S_LEARN = SURVEY_BYTES[wl]
         if wl == "cfg3":
             # all-unary: the sweeps run sweep8_kernel (8-byte records) unless --wide-records
             # (8-byte records; weight-sorted super-tiles when the graph has them: sorted_sweep_kernel)
             sorted_path = int(graph.info.num_super_tiles) > 0 and not args.wide_records
             kern = "sweep_kernel" if args.wide_records else ("sorted_sweep_kernel" if sorted_path else "sweep8_kernel")
         else:
+            sorted_path = False
             kern = "sweep_kernel"
+        L_INFER = layout_bytes_per_var(wl, False, graph.info, V, Vq, W, sorted_path)
+        L_LEARN = layout_bytes_per_var(wl, True, graph.info, V, Vq, W, sorted_path)
         # a sweep is one launch per colour: per-launch figures are per colour launch, the
         # roofline is priced per SWEEP (all its colour launches), which is what moves the bytes
         sw_l, sw_i = ms_l / max(ns_l, 1), ms_i / max(ns_i, 1)
         if sw_l >= sw_i:
-            kname, per_sweep_ms, bpv, units, nl, ns = kern + "<LEARN=true>", sw_l, B_LEARN, V, nl_l, ns_l
+            kname, per_sweep_ms, sbpv, lbpv, units, nl, ns = kern + "<LEARN=true>", sw_l, S_LEARN, L_LEARN, V, nl_l, ns_l
         else:
-            kname, per_sweep_ms, bpv, units, nl, ns = kern + "<LEARN=false>", sw_i, B_INFER, Vq, nl_i, ns_i
-        launches_per_sweep = nl / max(ns, 1)
-        achieved = bpv * units / (per_sweep_ms * 1e-3) / 1e9
-        traffic = None
+            kname, per_sweep_ms, sbpv, lbpv, units, nl, ns = kern + "<LEARN=false>", sw_i, S_INFER, L_INFER, Vq, nl_i, ns_i
+        launches_per_sweep = max(nl / max(ns, 1), 1)
+        sweep_s = per_sweep_ms * 1e-3
+        # PMC bytes per launch of exactly this workload, size and KERNEL SOURCES (profiles/traffic.json,
+        # written by tools/summarize_prof.py from separate --pmc passes: 2 x FETCH_SIZE + WRITE_SIZE, the
+        # guide's gfx950 correction): null when the stamp does not match the tree
+        traffic, traffic_note = None, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and V == 10_000_000 and W == 1_000_000 and n_gpus == 1:
-            # (PMC bytes per launch of exactly this workload and size, profiles/r03: per colour launch)
+        if not (V == 10_000_000 and W == 1_000_000 and n_gpus == 1):
+            traffic_note = "no PMC figure for this size"
+        elif not os.path.exists(tp):
+            traffic_note = "profiles/traffic.json missing"
+        else:
             try:
                 tj = json.load(open(tp))
-                traffic = tj.get(wl, {}).get(kname)
-            except Exception:
-                traffic = None
+                stamp = tj.get("_stamp", {}).get("kernel_sources_sha16")
+                if stamp != kernel_sources_sha16():
+                    traffic_note = ("profiles/traffic.json was measured on other kernel sources (stamp %s, tree %s): "
+                                    "re-run tools/profile_gpu.sh" % (stamp, kernel_sources_sha16()))
+                else:
+                    traffic = tj.get(wl, {}).get(kname)
+            except Exception as e:
+                traffic_note = "profiles/traffic.json unreadable: %r" % (e,)
+        layout_gbs = lbpv * units / sweep_s / 1e9
+        survey_gbs = sbpv * units / sweep_s / 1e9
+        if traffic:
+            achieved, source = traffic * launches_per_sweep / sweep_s / 1e9, "pmc"
+        else:
+            achieved, source = layout_gbs, "layout_model"
         roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "algorithmic_bytes_per_var": bpv,
-                    "vars_per_launch": units / max(launches_per_sweep, 1),
-                    "avg_launch_ms": per_sweep_ms / max(launches_per_sweep, 1),
+                    "frac_source": ("PMC bytes per launch (profiles/traffic.json, stamped with the kernel sources' sha) / "
+                                    "the launch time measured in this run" if source == "pmc" else
+                                    "layout byte model (no PMC figure valid for this tree / size): a lower bound of the traffic"),
+                    "traffic": traffic, "traffic_note": traffic_note,
+                    "frac_layout": layout_gbs / HBM_PEAK_GBS, "layout_bytes_per_var": lbpv,
+                    "frac_survey_model": survey_gbs / HBM_PEAK_GBS, "survey_bytes_per_var": sbpv,
+                    "survey_model_note": "SURVEY.md 8(d) prices 32 B per record + weight gathers as HBM bytes; the 8-byte "
+                                         "weight-sorted layout moves a third of that, so this figure is not a fraction of a roofline",
+                    "vars_per_launch": units / launches_per_sweep,
+                    "avg_launch_ms": per_sweep_ms / launches_per_sweep,
                     "launches_per_sweep": launches_per_sweep, "per_gpu": True}
-        if traffic:
-            # the fraction of PHYSICAL HBM bandwidth the kernel draws (PMC bytes, not the
-            # survey's byte model): the layout moves 2.4x fewer bytes than section 8(d) assumed
-            roofline["physical_frac"] = (traffic * max(launches_per_sweep, 1)) / (per_sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        # What actually bounds the all-unary sweeps: one random 4-byte gather out of the 4 MB f32
-        # weight table per record = one 128-byte L2 request each (tools/gather_bench: ~13.7
-        # requests/clk/XCD whatever the occupancy).  Ceiling = the same stream + gather shape
-        # with nothing else, measured on this box right now.
+        # Diagnostics, not ceilings: the same access shape with a trivial draw phase, measured on this
+        # box right now (tools/sorted_bench / tools/gather_bench); the product can run ahead of it
+        # on denser graphs (it read 1.14 at 100 M variables).
         if wl == "cfg3" and kern == "sorted_sweep_kernel":
-            # What bounds the sorted sweep: the CU's vector-memory path -- per 64 records one
-            # coalesced 512-byte stream request and one gather instruction over ~24 lines of the
-            # weight table (tools/sorted_bench: the same loop with a trivial draw phase).
             recs = RECORDS_PER_VAR[wl] * units
             peak = None if args.no_gather_ceiling else sorted_ceiling()
             committed = 3.5e11      # profiles/r03/sorted_bench.jsonl: 16 384 variables, 1024 threads, 1 per CU
-            r_ach = recs / (per_sweep_ms * 1e-3)
+            r_ach = recs / sweep_s
             roofline["secondary"] = {"bound": "cu_vector_memory", "what": "weight-sorted 8-byte record stream + "
                                      "sorted 4-byte weight gathers (about 0.2 L2 requests per record) + one LDS atomic per record",
-                                     "achieved": r_ach / 1e9, "peak": (peak or committed) / 1e9,
-                                     "unit": "Grecord/s", "frac": r_ach / (peak or committed),
-                                     "peak_source": "tools/sorted_bench --ceiling, this run" if peak else
-                                     "profiles/r03/sorted_bench.jsonl (committed)"}
+                                     "achieved": r_ach / 1e9, "reference_loop_rate": (peak or committed) / 1e9,
+                                     "unit": "Grecord/s", "ratio_to_reference_loop": r_ach / (peak or committed),
+                                     "reference_loop_source": "tools/sorted_bench --ceiling, this run" if peak else
+                                     "profiles/r03/sorted_bench.jsonl (committed)",
+                                     "note": "a micro-benchmark of the same loop, a diagnostic and not a bound"}
         elif wl == "cfg3":
             gathers = RECORDS_PER_VAR[wl] * units
             peak = None if args.no_gather_ceiling else gather_ceiling()
             committed = 1.874e11    # profiles/r02/gather_bench.jsonl: stream mode, 4 MB, 3 waves/SIMD
-            g_ach = gathers / (per_sweep_ms * 1e-3)
+            g_ach = gathers / sweep_s
             roofline["secondary"] = {"bound": "l2_req", "what": "random 4-byte weight gathers (one 128-byte L2 "
                                      "request per record) next to the 8-byte record stream",
-                                     "achieved": g_ach / 1e9, "peak": (peak or committed) / 1e9,
-                                     "unit": "Ggather/s", "frac": g_ach / (peak or committed),
-                                     "peak_source": "tools/gather_bench --ceiling, this run" if peak else
+                                     "achieved": g_ach / 1e9, "reference_loop_rate": (peak or committed) / 1e9,
+                                     "unit": "Ggather/s", "ratio_to_reference_loop": g_ach / (peak or committed),
+                                     "reference_loop_source": "tools/gather_bench --ceiling, this run" if peak else
                                      "profiles/r02/gather_bench.jsonl (committed)",
-                                     "pure_gather_peak": 264.0}
+                                     "note": "a micro-benchmark of the same loop, a diagnostic and not a bound"}
         out = {
             "metric": "variables sampled/sec (whole node)",
             "value": total_vars / elapsed,
@@ -525,8 +586,9 @@ def main():
                 "ghost_variables_per_gpu": int(len(ghosts)) if ghosts is not None else 0,
             },
             "roofline": roofline,
-            "infer_roofline_frac": (B_INFER * Vq / (sw_i * 1e-3) / 1e9 / HBM_PEAK_GBS) if ns_i else None,
-            "learn_roofline_frac": (B_LEARN * V / (sw_l * 1e-3) / 1e9 / HBM_PEAK_GBS) if ns_l else None,
+            # (both on the layout byte model: lower bounds of the traffic, so fractions of the HBM peak)
+            "infer_roofline_frac": (L_INFER * Vq / (sw_i * 1e-3) / 1e9 / HBM_PEAK_GBS) if ns_i else None,
+            "learn_roofline_frac": (L_LEARN * V / (sw_l * 1e-3) / 1e9 / HBM_PEAK_GBS) if ns_l else None,
             "sampled_vars_per_sec": (V + Vq) * n_gpus * args.steps / elapsed,
             "infer_vars_per_sec": V * n_gpus / (sw_i * 1e-3) if ns_i else None,
             "learn_vars_per_sec": V * n_gpus / (sw_l * 1e-3) if ns_l else None,

@@ -784,6 +784,31 @@ double l1_flow(double w0, double G, double h, double T, double stepsize, double 
   }
   return w;
 }
+// negligible curvature: the reference's own per-visit recurrence (src/inference_result.h:76-78) over
+// the batch's T visits with the batch's mean gradient per visit, in closed form (l1_visits /
+// l1_update of aux_kernels.h, restated)
+double l1_visits(double w, double G, double T, double stepsize, double reg) {
+  double n = T;
+  const double d = stepsize * G / T, up = reg - d;
+  if (w < 0.0) {
+    if (!(up > 0.0)) return w + n * up;
+    const double k = ceil(-w / up);
+    if (k >= n) return w + n * up;
+    w += k * up; n -= k;
+  }
+  if (!(d > 0.0)) return w - n * d;
+  const double k = floor(w / d) + 1.0;
+  if (k > n) return w - n * d;
+  w -= k * d; n -= k;
+  if (!(up > 0.0)) return w + n * up;
+  if (n * d >= reg) return 0.5 * reg - d;
+  double x = fmod(w + d - n * d, reg);
+  if (x < 0.0) x += reg;
+  return x - d;
+}
+double l1_update(double w0, double G, double h, double T, double stepsize, double reg) {
+  return kCurvMid * h * stepsize <= 0.0625 ? l1_visits(w0, G, T, stepsize, reg) : l1_flow(w0, G, h, T, stepsize, reg);
+}
 }  // namespace
 extern "C" void orc_sched_apply_h(orc_sampler *s, double stepsize, const int64_t *hess) {
   int64_t *G = s->GT.data(), *T = s->GT.data() + s->W, *H = s->GT.data() + 2 * s->W;
@@ -802,7 +827,7 @@ extern "C" void orc_sched_apply_h(orc_sampler *s, double stepsize, const int64_t
     if (s->opts.regularization == 1) {
       x -= step(hh, s->opts.reg_param * Tt) * (Gg + s->opts.reg_param * Tt * x);
     } else {
-      x = l1_flow(x, Gg, hh, Tt, stepsize, s->opts.reg_param);
+      x = l1_update(x, Gg, hh, Tt, stepsize, s->opts.reg_param);
     }
     s->weight_values[w] = x;
   }

@@ -249,6 +249,40 @@ DWX_DEV double l1_flow(double w0, double G, double h, double T, double stepsize,
   }
   return w;
 }
+// Where the batch's curvature is negligible (h stepsize small: weights with few visits per batch --
+// the untied weights of a DeepDive graph) the flow's "the push stops at zero" is NOT what the
+// reference does: a visit's push is a jump of the whole reg_param (w = -0.001, one visit, no
+// gradient: the reference lands on 0.009 and stays).  There the reference's own recurrence
+//   w += reg_param [w < 0];  w -= stepsize g          (src/inference_result.h:76-78)
+// is followed exactly over the batch's n = T visits with the batch's mean gradient per visit, in
+// closed form: rise by reg - d per visit while negative, fall by d per visit while not, and once
+// both have happened w <- w - d + reg [w < 0] is a rotation of x = w + d on [0, reg).  A batch that
+// spans a whole period of that rotation ends at its mean (the visits' own noise decides the phase),
+// a shorter one at the rotation's exact end point.  (T is real: truthiness-weighted.)
+DWX_DEV double l1_visits(double w, double G, double T, double stepsize, double reg_param) {
+  double n = T;
+  const double d = stepsize * G / T, up = reg_param - d;
+  if (w < 0.0) {
+    if (!(up > 0.0)) return w + n * up;          // the gradient outweighs the push: it keeps falling
+    const double k = ceil(-w / up);              // visits until it is >= 0
+    if (k >= n) return w + n * up;
+    w += k * up; n -= k;                         // in [0, up)
+  }
+  if (!(d > 0.0)) return w - n * d;              // nothing pulls it below zero again: no more pushes
+  const double k = floor(w / d) + 1.0;           // visits until it is negative
+  if (k > n) return w - n * d;
+  w -= k * d; n -= k;                            // in [-d, 0)
+  if (!(up > 0.0)) return w + n * up;
+  if (n * d >= reg_param) return 0.5 * reg_param - d;
+  double x = fmod(w + d - n * d, reg_param);
+  if (x < 0.0) x += reg_param;
+  return x - d;
+}
+// (curvature "negligible": the flow's step differs from the plain one by less than 1/32 of itself)
+DWX_DEV double l1_update(double w0, double G, double h, double T, double stepsize, double reg_param) {
+  return DWX_CURV_MID * h * stepsize <= 0.0625 ? l1_visits(w0, G, T, stepsize, reg_param)
+                                               : l1_flow(w0, G, h, T, stepsize, reg_param);
+}
 __global__ void __launch_bounds__(BLOCK_THREADS)
 apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *grad,
              const long long *t_static, const long long *t_hess, uint32_t W, double stepsize,
@@ -265,7 +299,7 @@ apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *gra
     if (l2) {
       x -= batch_step(h, reg_param * Tt, stepsize) * (Gg + reg_param * Tt * x);
     } else {
-      x = l1_flow(x, Gg, h, Tt, stepsize, reg_param);
+      x = l1_update(x, Gg, h, Tt, stepsize, reg_param);
     }
     weights[i] = x;
     w32[i] = (float)x;

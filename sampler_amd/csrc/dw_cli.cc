@@ -203,38 +203,49 @@ CmdLine parse_cmdline(int argc, const char *const argv[]) {
   return a;
 }
 
-namespace {
-std::ostream &operator<<(std::ostream &o, const std::vector<std::string> &v) {
-  if (!v.empty()) {
-    o << '[';
-    for (auto &s : v) o << s << ", ";
-    o << "\b\b]";
-  }
-  return o;
-}
-}  // namespace
-
+// The stdout banner of `dw gibbs` (a drop-in keeps the format scripts grep for: "# label : value"
+// lines between two rules, src/cmd_parser.cc:272-290), driven by a table: label, value printer.
 std::ostream &operator<<(std::ostream &stream, const CmdLine &args) {
-  stream << "#################GIBBS SAMPLING#################" << std::endl;
-  stream << "# fg_file            : " << args.fg_file << std::endl;
-  stream << "# variable_file      : " << args.variable_file << std::endl;
-  stream << "# domain_file        : " << args.domain_file << std::endl;
-  stream << "# weight_file        : " << args.weight_file << std::endl;
-  stream << "# factor_file        : " << args.factor_file << std::endl;
-  stream << "# output_folder      : " << args.output_folder << std::endl;
-  stream << "# n_learning_epoch   : " << args.n_learning_epoch << std::endl;
-  stream << "# n_inference_epoch  : " << args.n_inference_epoch << std::endl;
-  stream << "# stepsize           : " << args.stepsize << std::endl;
-  stream << "# decay              : " << args.decay << std::endl;
-  stream << "# regularization     : " << args.reg_param << std::endl;
-  stream << "# burn_in            : " << args.burn_in << std::endl;
-  stream << "# n_datacopy         : " << args.n_datacopy << std::endl;
-  stream << "# n_threads          : " << args.n_threads << std::endl;
-  stream << "# learn_non_evidence : " << args.should_learn_non_evidence << std::endl;
-  stream << "# is_noise_aware     : " << args.is_noise_aware << std::endl;
-  stream << "# device (HIP)       : " << args.device << std::endl;
-  stream << "# seed               : " << args.seed << std::endl;
-  stream << "################################################" << std::endl;
+  struct Row { const char *label; void (*print)(std::ostream &, const CmdLine &); };
+  // (file lists print as "[a, b]", nothing when empty)
+#define DWX_ROW_LIST(label, field) {label, [](std::ostream &o, const CmdLine &a) { \
+    for (size_t i = 0; i < a.field.size(); ++i) o << (i ? ", " : "[") << a.field[i]; \
+    if (!a.field.empty()) o << ']'; }}
+#define DWX_ROW(label, field) {label, [](std::ostream &o, const CmdLine &a) { o << a.field; }}
+  static const Row rows[] = {
+      DWX_ROW("fg_file", fg_file),
+      DWX_ROW_LIST("variable_file", variable_file),
+      DWX_ROW_LIST("domain_file", domain_file),
+      DWX_ROW_LIST("weight_file", weight_file),
+      DWX_ROW_LIST("factor_file", factor_file),
+      DWX_ROW("output_folder", output_folder),
+      DWX_ROW("n_learning_epoch", n_learning_epoch),
+      DWX_ROW("n_inference_epoch", n_inference_epoch),
+      DWX_ROW("stepsize", stepsize),
+      DWX_ROW("decay", decay),
+      DWX_ROW("regularization", reg_param),
+      DWX_ROW("burn_in", burn_in),
+      DWX_ROW("n_datacopy", n_datacopy),
+      DWX_ROW("n_threads", n_threads),
+      DWX_ROW("learn_non_evidence", should_learn_non_evidence),
+      DWX_ROW("is_noise_aware", is_noise_aware),
+      // additions of this build
+      DWX_ROW("device (HIP)", device),
+      DWX_ROW("seed", seed),
+  };
+#undef DWX_ROW
+#undef DWX_ROW_LIST
+  const std::string rule_fill(48, '#');
+  const std::string title = "GIBBS SAMPLING";
+  stream << std::string(17, '#') << title << std::string(17, '#') << std::endl;
+  for (const Row &r : rows) {
+    std::string label = r.label;
+    label.resize(19, ' ');
+    stream << "# " << label << ": ";
+    r.print(stream, args);
+    stream << std::endl;
+  }
+  stream << rule_fill << std::endl;
   return stream;
 }
 

@@ -455,13 +455,19 @@ void Rank::halo(int chains) {
 // the start of that learning epoch; with "block" every other rank then sits in a call that
 // never returns (what a collective without its dead peer does), so that only the watchdog of
 // gibbs_multi can end the run.
+// Compiled only into the tests' host harness (-DDWX_TEST_HOOKS, tests/hipemu/Makefile): the product
+// binary does not read the variable.
 void Rank::test_fault(uint64_t epoch) {
+#ifdef DWX_TEST_HOOKS
   const char *e = getenv("DWX_DW_TEST_FAULT");
   if (!e) return;
   int r = -1; unsigned long long ep = 0; char mode[16] = {0};
   if (sscanf(e, "%d:%llu:%15s", &r, &ep, mode) < 2 || ep != epoch) return;
   if (r == rank_) throw std::runtime_error("injected fault (DWX_DW_TEST_FAULT)");
   if (!strcmp(mode, "block")) for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+#else
+  (void)epoch;
+#endif
 }
 
 double Rank::global_curvature(uint32_t batches) {

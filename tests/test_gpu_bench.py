@@ -20,7 +20,14 @@ def _check(out, n_gpus):
     for k in KEYS:
         assert k in d, k
     assert d["n_gpus"] == n_gpus and d["value"] > 0 and d["higher_is_better"] is True
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"]
+    rf = d["roofline"]
+    # every fraction of the line IS a fraction: the headline one comes from PMC bytes (or, off the
+    # profiled size, from the layout byte model -- a lower bound of the traffic); SURVEY 8(d)'s
+    # model, which the layout undercuts, is kept aside under its own name
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1.0 and 0 < rf["frac_layout"] <= 1.0
+    assert rf["frac_survey_model"] > 0 and rf["layout_bytes_per_var"] < rf["survey_bytes_per_var"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert (rf["traffic"] is None) == (rf["traffic_note"] is not None)
     assert "workload" in d["config"]
     assert d["repeats"] >= 1 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
     assert d["dtype"].startswith("f64")
@@ -43,8 +50,9 @@ def test_bench_single_process_small():
     # calibrated on this box by tools/sorted_bench
     sec = d["roofline"]["secondary"]
     assert d["roofline"]["kernel"].startswith("sorted_sweep_kernel")
-    assert sec["bound"] == "cu_vector_memory" and sec["peak"] > 0 and 0 < sec["frac"] < 1.5
-    assert "this run" in sec["peak_source"]
+    assert sec["bound"] == "cu_vector_memory" and sec["reference_loop_rate"] > 0 and 0 < sec["ratio_to_reference_loop"] < 1.5
+    assert "this run" in sec["reference_loop_source"] and "peak" not in sec
+    assert d["roofline"]["traffic"] is None      # (not the profiled size: no PMC figure, the layout model speaks)
     # (200k variables: a block of 3 steps takes 0.2 ms, so the repeat cap ends the run, not --min-time)
     assert d["rccl_ranks"] is None and (d["timed_seconds"] >= 0.4 or d["repeats"] == 200)
 

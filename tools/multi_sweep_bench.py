@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """n inference sweeps in one launch (dwx_sample_n_async) on configs 2 / 3 / 4:
 device time per sweep against the single-sweep path, draws per second.  The profiled command of
 tools/profile_cfg.sh multiN (PROFILE_CMD)."""

@@ -5,6 +5,9 @@ guide's gfx950 correction; separate --pmc passes), average launch duration from 
 of the same command, TB/s and the fraction of the 8 TB/s peak.
 
     python tools/physical_table.py NAME=DIR [NAME=DIR ...] > physical.json
+    python tools/physical_table.py --check-bench profiles/r04/bench_final.json [--traffic profiles/traffic.json]
+        recomputes the bench line's roofline.frac from the committed PMC bytes per launch and the
+        line's own avg_launch_ms (exit 1 unless they agree to 3 digits)
 """
 import csv
 import glob
@@ -55,7 +58,28 @@ def load(d):
     return out
 
 
+def check_bench(bench_path, traffic_path):
+    d = json.loads([l for l in open(bench_path).read().splitlines() if l.startswith("{")][-1])
+    rf = d["roofline"]
+    tj = json.load(open(traffic_path))
+    wl = d["config"]["workload"].split(":")[0]
+    t = tj.get(wl, {}).get(rf["kernel"])
+    if t is None or rf.get("traffic") is None:
+        print("no PMC figure in the line or in %s for %s / %s" % (traffic_path, wl, rf["kernel"]))
+        return 1
+    frac = t / (rf["avg_launch_ms"] * 1e-3) / PEAK
+    ok = abs(frac - rf["frac"]) < 5e-4
+    print(json.dumps({"kernel": rf["kernel"], "bytes_per_launch": t, "avg_launch_ms": rf["avg_launch_ms"],
+                      "frac_recomputed": round(frac, 4), "frac_in_line": round(rf["frac"], 4), "agree": ok,
+                      "stamp": tj.get("_stamp")}))
+    return 0 if ok else 1
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--check-bench":
+        tp = sys.argv[sys.argv.index("--traffic") + 1] if "--traffic" in sys.argv else os.path.join(
+            os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+        sys.exit(check_bench(sys.argv[2], tp))
     res = {}
     for a in sys.argv[1:]:
         name, d = a.split("=", 1)

@@ -81,7 +81,17 @@ for pdir, store in (("pmc_FETCH_SIZE", fetch), ("pmc_WRITE_SIZE", write)):
             store[k] = sum(v) / len(v)
 traffic = {k: (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0 for k in fetch if "sweep" in k}
 if traffic:
+    # stamped with the sha of the kernel sources it was measured on: bench.py reports `traffic:
+    # null` when the tree has moved on (tools/update_traffic.py merges it into profiles/traffic.json)
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = ("sweep_kernels.h", "tile_walk.h", "aux_kernels.h", "device_types.h")
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(root, "sampler_amd", "csrc", f), "rb").read())
+    traffic["_stamp"] = {"kernel_sources_sha16": h.hexdigest()[:16], "files": list(files)}
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1, sort_keys=True)
+    del traffic["_stamp"]
     print("== traffic.json (bytes per launch, 2*FETCH_SIZE + WRITE_SIZE)")
     for k, v in traffic.items():
         print("  %-28s %.4g" % (k, v))
