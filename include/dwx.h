@@ -278,6 +278,13 @@ int dwx_sgd_finish(dwx_sampler *s);
  * src/dimmwitted.cc:209-216); dwx_wait fails if a sum was not a multiple of 2^shift or did not fit. */
 int dwx_grad_pack32_async(dwx_sampler *s, uint32_t shift, void **dev32, uint64_t *n);
 int dwx_grad_unpack32_async(dwx_sampler *s, uint32_t shift);
+/* The general form: bits = 32 as above, or bits = 16 -- two counts per 32-bit word, word i =
+ * c[2i] + 65536 c[2i+1] as arithmetic, *n_words = ceil(W / 2): the all-reduce's 32-bit sums of the
+ * words are the packed sums of the counts while every SUMMED count stays inside (-2^15, 2^15), i.e.
+ * while (sum over ranks of max_records_per_weight) x grad_unit_max < 2^15 -- a quarter of the int64
+ * bytes (config 5a: 2 MB per mini-batch at W = 1 M).  RCCL has no 16-bit integer type, hence words. */
+int dwx_grad_pack_async(dwx_sampler *s, uint32_t shift, uint32_t bits, void **dev32, uint64_t *n_words);
+int dwx_grad_unpack_async(dwx_sampler *s, uint32_t shift, uint32_t bits);
 
 /* infrs.weight_values access (src/dimmwitted.cc:209-216 merge/average, :245-258 dump) */
 int dwx_get_weights(dwx_sampler *s, double *out);

@@ -283,6 +283,24 @@ DWX_DEV double l1_update(double w0, double G, double h, double T, double stepsiz
   return DWX_CURV_MID * h * stepsize <= 0.0625 ? l1_visits(w0, G, T, stepsize, reg_param)
                                                : l1_flow(w0, G, h, T, stepsize, reg_param);
 }
+// InferenceResult::update_weight (src/inference_result.h:66-85) for one weight over one batch:
+// G, Td = the batch's fixed-point gradient sum and dynamic update count.
+DWX_DEV void apply_one(double *weights, float *w32, const uint8_t *w_fixed, const long long *t_static,
+                       const long long *t_hess, uint32_t i, long long G, long long Td, double stepsize,
+                       double reg_param, int l2) {
+  const long long Tn = Td + (t_static ? t_static[i] : 0);
+  if (w_fixed[i] || Tn == 0) return;
+  const double Tt = (double)Tn / FIX_SCALE, Gg = (double)G / FIX_SCALE;
+  const double h = t_hess ? (double)t_hess[i] / H_SCALE : 0.0;
+  double x = weights[i];
+  if (l2) {
+    x -= batch_step(h, reg_param * Tt, stepsize) * (Gg + reg_param * Tt * x);
+  } else {
+    x = l1_update(x, Gg, h, Tt, stepsize, reg_param);
+  }
+  weights[i] = x;
+  w32[i] = (float)x;
+}
 __global__ void __launch_bounds__(BLOCK_THREADS)
 apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *grad,
              const long long *t_static, const long long *t_hess, uint32_t W, double stepsize,
@@ -291,19 +309,41 @@ apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *gra
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride) {
     const long long G = grad[i], Td = grad[W + i];
     if (G != 0 || Td != 0) { grad[i] = 0; grad[W + i] = 0; }
-    const long long Tn = Td + (t_static ? t_static[i] : 0);
-    if (w_fixed[i] || Tn == 0) continue;
-    const double Tt = (double)Tn / FIX_SCALE, Gg = (double)G / FIX_SCALE;
-    const double h = t_hess ? (double)t_hess[i] / H_SCALE : 0.0;
-    double x = weights[i];
-    if (l2) {
-      x -= batch_step(h, reg_param * Tt, stepsize) * (Gg + reg_param * Tt * x);
-    } else {
-      x = l1_update(x, Gg, h, Tt, stepsize, reg_param);
-    }
-    weights[i] = x;
-    w32[i] = (float)x;
+    apply_one(weights, w32, w_fixed, t_static, t_hess, i, G, Td, stepsize, reg_param, l2);
   }
+}
+
+// Few weights (W <= AGG_ROWS_MAX_W): the learning launch left one row of 2W sums per workgroup
+// (flush_accumulators, P.agg_rows).  A block takes ROWS_WPB weights: ROWS_LANES lanes per weight walk
+// the rows (a row's 2W sums are contiguous: a group of lanes reads 128 contiguous bytes), an LDS
+// tree adds the lanes' shares, lane 0 of each weight adds what the wave / workgroup bins put into
+// `grad` by atomics, and applies.  apply == 0 (fold_rows): the totals are ADDED INTO grad instead
+// (a multi-GPU driver all-reduces grad before it applies; an un-split sweep of several colour launches).
+constexpr uint32_t ROWS_WPB = 16, ROWS_LANES = BLOCK_THREADS / ROWS_WPB;
+__global__ void __launch_bounds__(BLOCK_THREADS)
+apply_rows_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *grad, const long long *rows,
+                  uint32_t n_rows, const long long *t_static, const long long *t_hess, uint32_t W, double stepsize,
+                  double reg_param, int l2, int apply) {
+  __shared__ long long s_g[ROWS_LANES][ROWS_WPB], s_t[ROWS_LANES][ROWS_WPB];
+  const uint32_t j = threadIdx.x % ROWS_WPB, rl = threadIdx.x / ROWS_WPB;
+  const uint32_t i = blockIdx.x * ROWS_WPB + j;
+  long long g = 0, td = 0;
+  if (i < W)
+    for (uint32_t r = rl; r < n_rows; r += ROWS_LANES) {
+      const long long *row = rows + (size_t)r * 2 * W;
+      g += row[i]; td += row[W + i];
+    }
+  s_g[rl][j] = g; s_t[rl][j] = td;
+  __syncthreads();
+  for (uint32_t half = ROWS_LANES / 2; half >= 1; half >>= 1) {
+    if (rl < half) { s_g[rl][j] += s_g[rl + half][j]; s_t[rl][j] += s_t[rl + half][j]; }
+    __syncthreads();
+  }
+  if (rl != 0 || i >= W) return;
+  const long long G = s_g[0][j] + grad[i], Td = s_t[0][j] + grad[W + i];
+  if (!apply) { grad[i] = G; grad[W + i] = Td; return; }
+  if (grad[i] != 0 || grad[W + i] != 0) { grad[i] = 0; grad[W + i] = 0; }
+  apply_one(weights, w32, w_fixed, t_static, t_hess, i, G, Td, stepsize, reg_param, l2);
 }
 
 // Inference with unchanged weights repeats the same products sweep after sweep: tabulate
@@ -381,6 +421,35 @@ grad_unpack32_kernel(const int *in, long long *grad, uint32_t W, uint32_t shift)
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride)
     grad[i] = (long long)((unsigned long long)(long long)in[i] << shift);
+}
+
+// The same as 16-bit counts, two per 32-bit word (RCCL has no 16-bit integer type): word i =
+// c[2i] + 65536 * c[2i + 1] as ARITHMETIC (a negative low count borrows from the high one), so that
+// the all-reduce's plain 32-bit sums of the words ARE the packed sums of the counts as long as every
+// summed count stays inside (-2^15, 2^15) -- what the ranks agreed on before choosing this form
+// (sum over ranks of max_records_per_weight x grad_unit_max < 2^15).  A quarter of the int64 bytes.
+__global__ void __launch_bounds__(BLOCK_THREADS)
+grad_pack16_kernel(const long long *grad, int *out, uint32_t W, uint32_t shift, uint32_t *bad) {
+  const uint32_t stride = gridDim.x * blockDim.x, words = (W + 1u) / 2u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) {
+    const long long g0 = grad[2 * i], g1 = 2 * i + 1 < W ? grad[2 * i + 1] : 0;
+    const long long v0 = g0 >> shift, v1 = g1 >> shift;
+    if ((long long)((unsigned long long)v0 << shift) != g0 || (long long)((unsigned long long)v1 << shift) != g1 ||
+        v0 <= -32768 || v0 >= 32768 || v1 <= -32768 || v1 >= 32768)
+      atomicAdd(bad, 1u);
+    out[i] = (int)(v0 + v1 * 65536);
+  }
+}
+__global__ void __launch_bounds__(BLOCK_THREADS)
+grad_unpack16_kernel(const int *in, long long *grad, uint32_t W, uint32_t shift) {
+  const uint32_t stride = gridDim.x * blockDim.x, words = (W + 1u) / 2u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) {
+    const int x = in[i];
+    const int lo = (int)(short)(x & 0xFFFF);        // the low count, sign-extended
+    const int hi = (x - lo) >> 16;                  // exact: x - lo is a multiple of 65536
+    grad[2 * i] = (long long)((unsigned long long)(long long)lo << shift);
+    if (2 * i + 1 < W) grad[2 * i + 1] = (long long)((unsigned long long)(long long)hi << shift);
+  }
 }
 
 // f64 master weights -> f32 sampling copy (after dwx_set_weights)

@@ -96,6 +96,8 @@ constexpr uint32_t SORT_TV_SLOTS = 2 * SUPER_TILES_DEFAULT;   // tile starts of 
 #endif
 constexpr uint32_t SORT_THREADS = DWX_SORT_THREADS;   // sorted_sweep_kernel's workgroup
 constexpr int SORT_K = DWX_SORT_K;                    // ... and its records in flight per lane
+// per-workgroup gradient rows instead of a contended atomic flush: graphs with at most this many weights
+constexpr uint32_t AGG_ROWS_MAX_W = 128;
 constexpr uint32_t SORT_MAX_DVALS = 1024;                     // distinct d values (8 KiB in LDS), else no sorted copy
 struct alignas(16) SuperTile {
   uint32_t tile0, ntiles;   // tiles [tile0, tile0 + ntiles)
@@ -248,6 +250,9 @@ struct KernelParams {
   uint32_t *tally;            // [R]
   const float *w32;           // [W] sampling copy of the weights, rounded to f32 (fits L2)
   long long *grad;            // [2W]: G then T (fixed point)
+  long long *agg_rows;        // learning, few weights (LDS accumulators): [grid][2W] -- each persistent workgroup
+                              // stores its sums as a row of its own (apply_rows_kernel / fold_rows_kernel add
+                              // the rows up) instead of grid x 2W atomics onto 2W addresses; null: atomics
   unsigned long long *delta;  // [n_tiles*4*2] per wave: {chains disagree, free < evid} ballots
   // launch
   uint64_t seed, sweep;

@@ -313,8 +313,8 @@ class Rank {
   uint64_t W_ = 0;
   void *d_grad_ = nullptr, *d_weights_ = nullptr, *d_tallies_ = nullptr;
   bool has_categorical_ = false;
-  bool narrow_ = false;           // the gradient all-reduce travels as 32-bit counts
-  uint32_t narrow_shift_ = 0;
+  bool narrow_ = false;           // the gradient all-reduce travels as 32- or 16-bit counts
+  uint32_t narrow_shift_ = 0, narrow_bits_ = 32;
   std::vector<Peer> send_, recv_;
   std::map<uint32_t, double> lam_;
   std::map<uint32_t, uint32_t> level_chunks_;
@@ -386,10 +386,16 @@ void Rank::setup() {
       const uint64_t recs = sh_.agree->max_u64(rank_, info_.max_records_per_weight) * (uint64_t)sh_.world;
       narrow_shift_ = (uint32_t)(64 - m);
       const uint64_t unit = narrow_shift_ > 0 ? qmax >> narrow_shift_ : 0;
-      narrow_ = !has_categorical_ && narrow_shift_ > 0 && unit > 0 && recs * unit < (1ull << 31) && sh_.world > 1 &&
-                !getenv("DWX_NO_NARROW_ALLREDUCE");
+      // (the override is agreed on: ranks that disagreed would put different types through one collective)
+      const bool no_narrow = sh_.agree->max_u64(rank_, getenv("DWX_NO_NARROW_ALLREDUCE") ? 1 : 0) != 0;
+      const bool no_16 = sh_.agree->max_u64(rank_, getenv("DWX_NO_16BIT_ALLREDUCE") ? 1 : 0) != 0;
+      narrow_ = !has_categorical_ && narrow_shift_ > 0 && unit > 0 && recs * unit < (1ull << 31) && sh_.world > 1 && !no_narrow;
+      // ... and as 16-bit counts, two per word, where even the sum over all ranks stays below 2^15
+      // (config 5a: a weight has ~10^3 records over all shards): a quarter of the int64 bytes
+      narrow_bits_ = (narrow_ && recs * unit < (1ull << 15) && !no_16) ? 16u : 32u;
       if (root() && !args_.should_be_quiet)
-        std::cout << "Gradient all-reduce: " << (narrow_ ? "32-bit counts, shift " + std::to_string(narrow_shift_) : std::string("int64 sums"))
+        std::cout << "Gradient all-reduce: "
+                  << (narrow_ ? std::to_string(narrow_bits_) + "-bit counts, shift " + std::to_string(narrow_shift_) : std::string("int64 sums"))
                   << std::endl;
     }
     // each rank counted its own block's boolean updates and curvature bounds: sum [T | h] once
@@ -499,9 +505,10 @@ void Rank::plan(double stepsize, uint32_t &batches, uint32_t &n_chunks, double &
   }
   if (!level_chunks_.count(batches)) {
     // first use of this batch count: agree on the slowest rank's chunk count and share the
-    // static tables -- for this level AND the coarser ones the decaying step will walk through,
-    // so that all one-off work lands in the first learning sweep
-    for (uint32_t b = batches; b >= 1; b /= 2) {
+    // static tables.  (Only this level: every rank derives the same plan for every step, so the
+    // coarser levels the decaying step walks down to are agreed on when -- and if -- they are
+    // first used; building them all in the first epoch cost 24 s at config 5's size.)
+    for (uint32_t b = batches, once = 1; once; once = 0) {
       if (!level_chunks_.count(b)) {
         if (b > 1 && cap > 0) (void)global_curvature(b);
         uint32_t got_b = 0, n_mine = 0;
@@ -557,9 +564,9 @@ void Rank::learn_shards() {
           // (two's complement: the unsigned 32-bit sum of the ranks' signed counts is their signed sum)
           void *d32 = nullptr;
           uint64_t n32 = 0;
-          ok(dwx_grad_pack32_async(s_, narrow_shift_, &d32, &n32));
+          ok(dwx_grad_pack_async(s_, narrow_shift_, narrow_bits_, &d32, &n32));
           sh_.comm->allreduce_sum_u32(rank_, s_, d32, n32);
-          ok(dwx_grad_unpack32_async(s_, narrow_shift_));
+          ok(dwx_grad_unpack_async(s_, narrow_shift_, narrow_bits_));
         } else if (W_) {
           sh_.comm->allreduce_sum_i64(rank_, s_, d_grad_, (has_categorical_ || dynamic_now_) ? 2 * W_ : W_);
         }

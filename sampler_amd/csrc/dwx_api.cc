@@ -147,6 +147,7 @@ struct dwx_sampler {
   uint32_t n_sort_dvals = 0;
   size_t lds_sorted = 0;
   bool sorted_learn = false;            // ... also in learning sweeps (the super-tiles' tiles pull their gradient)
+  bool no_sort_uni = false;             // DWX_NO_SORT_UNI: never the single-d build of sorted_sweep_kernel (A/B)
   double *d_row_truth = nullptr, *d_edge_fval64 = nullptr;
   EdgeRec *d_edges = nullptr;
   VifRec *d_vifs = nullptr;
@@ -211,6 +212,12 @@ struct dwx_sampler {
   uint32_t cur_chunk = 0;             // last chunk handed to dwx_sgd_accumulate_async
   uint8_t *d_w_fixed = nullptr;
   long long *d_grad = nullptr;
+  // few weights (W <= AGG_ROWS_MAX_W, LDS accumulators): one row of 2W gradient sums per workgroup of
+  // the last learning launch instead of a contended atomic flush (flush_accumulators); rows_pending
+  // rows wait to be added up -- by apply_rows_kernel, or folded into d_grad before anything else
+  // reads or overwrites them
+  long long *d_agg_rows = nullptr;
+  uint32_t agg_rows_cap = 0, rows_pending = 0;
   int *d_grad32 = nullptr;              // dwx_grad_pack32_async: the gradient sums as 32-bit counts
   uint32_t *d_pack_bad = nullptr;       // ... and its "not a multiple / does not fit" counter
   bool pack_check_pending = false;
@@ -234,7 +241,7 @@ struct dwx_sampler {
     rt::dfree(d_grad32); rt::dfree(d_pack_bad);
     rt::dfree(d_edges); rt::dfree(d_edges8); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
     rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_terms); rt::dfree(d_delta);
-    rt::dfree(d_w_fixed); rt::dfree(d_grad);
+    rt::dfree(d_w_fixed); rt::dfree(d_grad); rt::dfree(d_agg_rows);
     for (int i = 0; i < 2; ++i) { if (side[i]) rt::stream_destroy(side[i]); if (ev_join[i]) rt::event_destroy(ev_join[i]); }
     if (ev_fork) rt::event_destroy(ev_fork);
     if (stream) rt::stream_destroy(stream);
@@ -254,6 +261,18 @@ struct dwx_halo {
 };
 
 namespace {
+// the pending gradient rows of the last learning launch added into d_grad (few weights; see
+// dwx_sampler::d_agg_rows): before the rows are overwritten by the next launch and before anything
+// but apply reads the sums (a multi-GPU driver's all-reduce of d_grad)
+void fold_pending_rows(dwx_sampler *s) {
+  if (!s->rows_pending) return;
+  const uint32_t W = (uint32_t)s->cg->W;
+  rt::launch(apply_rows_kernel, (W + ROWS_WPB - 1) / ROWS_WPB, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
+             (const uint8_t *)s->d_w_fixed, s->d_grad, (const long long *)s->d_agg_rows, s->rows_pending,
+             (const long long *)nullptr, (const long long *)nullptr, W, 0.0, 0.0, 1, 0);
+  s->rows_pending = 0;
+}
+
 // launch the sweep kernel (+ the oversized-variable kernel) over tiles [t0, t1) of launch l
 // multi (inference of a graph without degree-binned variables): P.n_sweeps sweeps per launch
 template <bool LEARN>
@@ -299,6 +318,13 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   // (all-unary graphs stage 8-byte terms whenever the compute phase needs no record)
   const size_t lds = tab8 ? s->lds_tab : slim ? s->lds_learn_pull : s->lds_bytes[LEARN ? 1 : 0];
   constexpr int RPC = (int)ROWPTR_UNROLL_CAT;
+  P.agg_rows = nullptr;
+  if (LEARN && P.lds_agg_off && s->d_agg_rows && grid <= s->agg_rows_cap) {
+    // few weights: a row of sums per workgroup instead of grid x 2W atomics onto 2W addresses
+    fold_pending_rows(s);            // (the rows of an earlier launch of this batch)
+    P.agg_rows = s->d_agg_rows;
+    s->rows_pending = grid;
+  }
   if constexpr (!LEARN) {
     if (multi) {   // (only asked for on compact-record graphs, never on the terms table)
       constexpr int RP = (int)ROWPTR_UNROLL;
@@ -370,9 +396,15 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
       uint32_t cursor = t0;
       for (const Run &r : runs) {
         launch_lane_tiles(cursor, sv[r.a].tile0);
-        rt::launch(sorted_sweep_kernel<LEARN>, (unsigned)(r.b - r.a), SORT_THREADS, s->lds_sorted, s->stream, P,
-                   (const SuperTile *)(d_sv + r.a), (uint32_t)(r.b - r.a), d_sr,
-                   (const double *)s->d_sort_dvals, s->n_sort_dvals);
+        // (one distinct d: the UNI build keeps it in a scalar register; DWX_NO_SORT_UNI: A/B knob)
+        if (s->n_sort_dvals == 2 && !s->no_sort_uni)
+          rt::launch(sorted_sweep_kernel<LEARN, true>, (unsigned)(r.b - r.a), SORT_THREADS, s->lds_sorted, s->stream, P,
+                     (const SuperTile *)(d_sv + r.a), (uint32_t)(r.b - r.a), d_sr,
+                     (const double *)s->d_sort_dvals, s->n_sort_dvals);
+        else
+          rt::launch(sorted_sweep_kernel<LEARN, false>, (unsigned)(r.b - r.a), SORT_THREADS, s->lds_sorted, s->stream, P,
+                     (const SuperTile *)(d_sv + r.a), (uint32_t)(r.b - r.a), d_sr,
+                     (const double *)s->d_sort_dvals, s->n_sort_dvals);
         ++launches;
         cursor = sv[r.b - 1].tile0 + sv[r.b - 1].ntiles;
       }
@@ -1128,11 +1160,13 @@ void make_plan(dwx_sampler *s, double stepsize, uint32_t force_batches) {
   }
   s->plan_batches = B;
   s->plan_eta = eta;
-  if (B > 1 && !s->levels.count(B)) {
-    // The step decays from sweep to sweep, so a run that starts at B batches will walk down
-    // through B/2, B/4, ...: prepare those levels (curvature estimate, tables) together with
-    // the first one, so that the one-off host work lands in the first learning sweep instead
-    // of interrupting later ones.
+  // The step decays from sweep to sweep, so a run that starts at B batches walks down through
+  // B/2, B/4, ...  Those levels are built when a plan first NEEDS them (round 4: at config 5's size a
+  // level costs seconds of host time, and a `-l 10` run that starts at 4 batches never reaches 2 --
+  // building them all up front was 15 s of its first learning epoch).  A caller that wants the
+  // one-off work out of a timed region plans the coarser counts itself (bench.py: dist.py's
+  // prepare), or sets DWX_EAGER_LEVELS.
+  if (B > 1 && !s->levels.count(B) && getenv("DWX_EAGER_LEVELS")) {
     for (uint32_t b = B / 2; b >= 2; b /= 2) {
       if (cap > 0) (void)row_sum_bound(s, b);
       (void)build_level(s, b);
@@ -1266,6 +1300,15 @@ void enqueue_apply(dwx_sampler *s) {
   } else {
     auto it = s->levels.find(1);
     if (it != s->levels.end() && it->second->d_t_static) hs = it->second->d_t_static + W;
+  }
+  if (s->rows_pending) {
+    // few weights: the batch's sums are the rows of its learning launch (+ what the wave / workgroup
+    // bins added to d_grad): summed and applied in one kernel
+    rt::launch(apply_rows_kernel, (W + ROWS_WPB - 1) / ROWS_WPB, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
+               (const uint8_t *)s->d_w_fixed, s->d_grad, (const long long *)s->d_agg_rows, s->rows_pending, ts, hs, W,
+               s->plan_eta, s->opts.reg_param, (int)(s->opts.regularization == 1), 1);
+    s->rows_pending = 0;
+    return;
   }
   rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
              (const uint8_t *)s->d_w_fixed, s->d_grad, ts, hs, W, s->plan_eta, s->opts.reg_param,
@@ -1461,8 +1504,11 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       s->n_sort_dvals = (uint32_t)c.sort_dvals.size();
       s->lds_sorted = (size_t)SUPER_NV_MAX * 8 + SORT_TV_SLOTS * 4 + (size_t)s->n_sort_dvals * 8;
       s->sorted_learn = c.W > LDS_AGG_MAX_W;     // == their tiles are TILE_PULL
-      rt::allow_dynamic_lds(sorted_sweep_kernel<false>, s->lds_sorted);
-      rt::allow_dynamic_lds(sorted_sweep_kernel<true>, s->lds_sorted);
+      rt::allow_dynamic_lds(sorted_sweep_kernel<false, false>, s->lds_sorted);
+      rt::allow_dynamic_lds(sorted_sweep_kernel<true, false>, s->lds_sorted);
+      rt::allow_dynamic_lds(sorted_sweep_kernel<false, true>, s->lds_sorted);
+      rt::allow_dynamic_lds(sorted_sweep_kernel<true, true>, s->lds_sorted);
+      s->no_sort_uni = getenv("DWX_NO_SORT_UNI") != nullptr;
     }
     {
       // the batched walks load a factor's first entries branch-free (a unary record reads entry
@@ -1579,6 +1625,11 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
         case 6: prepare8(sweep8_kernel<false, 6>, sweep8_kernel<true, 6>); prepare_tab(sweep8_kernel<false, 6, true>); break;
         default: prepare8(sweep8_kernel<false, 12>, sweep8_kernel<true, 12>); prepare_tab(sweep8_kernel<false, 12, true>); break;
       }
+    }
+    if (P.lds_agg_off && c.W <= AGG_ROWS_MAX_W) {
+      // few weights: the learning launches leave a row of 2W sums per workgroup (flush_accumulators)
+      s->agg_rows_cap = std::max(s->persistent_blocks[1], s->rec8 ? s->persistent_blocks8[1] : 0u);
+      s->d_agg_rows = (long long *)rt::dmalloc((size_t)s->agg_rows_cap * 2 * c.W * 8);
     }
     rt::stream_sync(st);
     // the un-split sweep's curvature estimate is needed by the first dwx_sgd_plan: pay
@@ -1729,6 +1780,7 @@ int dwx_sgd_accumulate_async(dwx_sampler *s, uint32_t chunk) {
   return guarded([&]() {
     s->cur_chunk = chunk;
     enqueue_learn_chunk(s, chunk);
+    fold_pending_rows(s);     // (a multi-GPU driver all-reduces DWX_BUF_GRAD between this call and the apply)
   });
 }
 
@@ -1809,36 +1861,52 @@ int dwx_sample_sgd_async(dwx_sampler *s, double stepsize) {
   });
 }
 
-int dwx_grad_pack32_async(dwx_sampler *s, uint32_t shift, void **dev32, uint64_t *n) {
-  if (!s || !dev32 || !n) return fail(DWX_E_INVALID, "null argument");
+int dwx_grad_pack_async(dwx_sampler *s, uint32_t shift, uint32_t bits, void **dev32, uint64_t *n_words) {
+  if (!s || !dev32 || !n_words) return fail(DWX_E_INVALID, "null argument");
   if (shift == 0 || shift > 62) return fail(DWX_E_INVALID, "gradient shift out of range (dwx_graph_info.grad_shift)");
+  if (bits != 32 && bits != 16) return fail(DWX_E_INVALID, "gradient counts travel as 32- or 16-bit integers");
   return guarded([&]() {
     rt::set_device(s->device);
     const uint32_t W = (uint32_t)s->cg->W;
     if (!s->d_grad32) {
-      s->d_grad32 = (int *)rt::dmalloc((size_t)W * 4);
+      s->d_grad32 = (int *)rt::dmalloc((size_t)W * 4 + 4);
       s->d_pack_bad = (uint32_t *)rt::dmalloc(4);
       rt::dmemset(s->d_pack_bad, 0, 4, s->stream);
     }
-    const unsigned grid = std::max(1u, std::min((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 1024u));
-    rt::launch(grad_pack32_kernel, grid, BLOCK_THREADS, 0, s->stream, (const long long *)s->d_grad, s->d_grad32, W, shift,
-               s->d_pack_bad);
+    const uint32_t words = bits == 32 ? W : (W + 1u) / 2u;
+    const unsigned grid = std::max(1u, std::min((words + BLOCK_THREADS - 1) / BLOCK_THREADS, 1024u));
+    if (bits == 32)
+      rt::launch(grad_pack32_kernel, grid, BLOCK_THREADS, 0, s->stream, (const long long *)s->d_grad, s->d_grad32, W, shift,
+                 s->d_pack_bad);
+    else
+      rt::launch(grad_pack16_kernel, grid, BLOCK_THREADS, 0, s->stream, (const long long *)s->d_grad, s->d_grad32, W, shift,
+                 s->d_pack_bad);
     s->pack_check_pending = true;
     *dev32 = s->d_grad32;
-    *n = W;
+    *n_words = words;
   });
 }
 
-int dwx_grad_unpack32_async(dwx_sampler *s, uint32_t shift) {
+int dwx_grad_unpack_async(dwx_sampler *s, uint32_t shift, uint32_t bits) {
   if (!s) return fail(DWX_E_INVALID, "null sampler");
-  if (!s->d_grad32) return fail(DWX_E_INVALID, "dwx_grad_unpack32_async without dwx_grad_pack32_async");
+  if (!s->d_grad32) return fail(DWX_E_INVALID, "dwx_grad_unpack_async without dwx_grad_pack_async");
+  if (bits != 32 && bits != 16) return fail(DWX_E_INVALID, "gradient counts travel as 32- or 16-bit integers");
   return guarded([&]() {
     rt::set_device(s->device);
     const uint32_t W = (uint32_t)s->cg->W;
-    const unsigned grid = std::max(1u, std::min((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 1024u));
-    rt::launch(grad_unpack32_kernel, grid, BLOCK_THREADS, 0, s->stream, (const int *)s->d_grad32, s->d_grad, W, shift);
+    const uint32_t words = bits == 32 ? W : (W + 1u) / 2u;
+    const unsigned grid = std::max(1u, std::min((words + BLOCK_THREADS - 1) / BLOCK_THREADS, 1024u));
+    if (bits == 32)
+      rt::launch(grad_unpack32_kernel, grid, BLOCK_THREADS, 0, s->stream, (const int *)s->d_grad32, s->d_grad, W, shift);
+    else
+      rt::launch(grad_unpack16_kernel, grid, BLOCK_THREADS, 0, s->stream, (const int *)s->d_grad32, s->d_grad, W, shift);
   });
 }
+
+int dwx_grad_pack32_async(dwx_sampler *s, uint32_t shift, void **dev32, uint64_t *n) {
+  return dwx_grad_pack_async(s, shift, 32, dev32, n);
+}
+int dwx_grad_unpack32_async(dwx_sampler *s, uint32_t shift) { return dwx_grad_unpack_async(s, shift, 32); }
 
 int dwx_wait(dwx_sampler *s) {
   if (!s) return fail(DWX_E_INVALID, "null sampler");
@@ -1850,8 +1918,8 @@ int dwx_wait(dwx_sampler *s) {
       rt::d2h(&bad, s->d_pack_bad, 4, s->stream);
       rt::stream_sync(s->stream);
       s->pack_check_pending = false;
-      if (bad) throw std::runtime_error("dwx_grad_pack32_async: " + std::to_string(bad) +
-                                        " gradient sums were not multiples of 2^shift or did not fit 32 bits");
+      if (bad) throw std::runtime_error("dwx_grad_pack_async: " + std::to_string(bad) +
+                                        " gradient sums were not multiples of 2^shift or did not fit the count width");
     }
   });
 }

@@ -170,6 +170,30 @@ DWX_DEV void stage_generic_records(const KernelParams &P, const TileDesc &d, con
   }
 }
 
+// The per-workgroup gradient accumulators of a learning launch on a graph with few weights (LDS:
+// int64[2W], W <= LDS_AGG_MAX_W), flushed once per persistent workgroup.  With a handful of weights
+// the flush used to be the longest thing a chunk of a split sweep did: grid x 2W atomics onto 2W
+// addresses retire at ~0.3 G/s (tools/atomic_bench: 0.25 G/s on 8 addresses) -- config 4's 407
+// workgroups x 16 sums: ~15 of the chunk kernel's 22 us.  P.agg_rows (W <= AGG_ROWS_MAX_W): each
+// workgroup stores its sums as ONE ROW of its own, plain stores, zeros included; apply_rows_kernel
+// (or fold_rows_kernel, where something else reads the sums first) adds the rows up.  Integer sums:
+// the same totals in any order.
+DWX_DEV void flush_accumulators(const KernelParams &P, const long long *s_agg, uint32_t t) {
+  if (!s_agg) return;
+  __syncthreads();
+#ifndef DWX_EXP_NOFLUSH   // (timing experiment: what the flush costs a chunk of a split sweep)
+  if (P.agg_rows) {
+    long long *row = P.agg_rows + (size_t)blockIdx.x * 2 * P.num_weights;
+    for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) row[i] = s_agg[i];
+    return;
+  }
+  for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) {
+    const long long v = s_agg[i];
+    if (v) atomicAdd((unsigned long long *)&P.grad[i], (unsigned long long)v);
+  }
+#endif
+}
+
 // Persistent, software-pipelined sweep: workgroup b handles tiles b, b + gridDim.x, ...
 // of the launch.  While a tile is processed out of LDS, the NEXT tile's edge records,
 // row pointers and per-variable inputs are already in flight into registers, so the
@@ -479,13 +503,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
     dn = scalarise(raw_nn);
     tile = next; next = nn; has_next = has_nn;
   }
-  if (s_agg) {   // one flush per persistent workgroup
-    __syncthreads();
-    for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) {
-      const long long v = s_agg[i];
-      if (v) atomicAdd((unsigned long long *)&P.grad[i], (unsigned long long)v);
-    }
-  }
+  flush_accumulators(P, s_agg, t);
 }
 
 // ---------------------------------------------------------------- all-unary graphs
@@ -661,35 +679,35 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
     dn = scalarise(raw_nn);
     tile = next; next = nn; has_next = has_nn;
   }
-  if (s_agg) {   // one flush per persistent workgroup
-    __syncthreads();
-    for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) {
-      const long long v = s_agg[i];
-      if (v) atomicAdd((unsigned long long *)&P.grad[i], (unsigned long long)v);
-    }
-  }
+  flush_accumulators(P, s_agg, t);
 }
 
 // ---------------------------------------------------------------- weight-sorted super-tiles
 // What bounded sweep8_kernel on a graph with a million weights was one L2 request per record:
-// the weight gathers of a variable-major record stream are random.  Here ONE WORKGROUP takes a
-// super-tile -- up to 8192 consecutive boolean variables of an all-unary graph (32 tiles) -- and
+// the weight gathers of a variable-major record stream are random.  Here ONE WORKGROUP of
+// SORT_THREADS = 1024 lanes -- the CU's whole LDS, one workgroup per CU -- takes a super-tile: up to
+// SUPER_NV_MAX = 16 384 consecutive boolean variables of an all-unary graph (<= 64 tiles), and
 // streams the super-tile's records in the order of their WEIGHT IDS (the second, sorted copy of
-// graph_compile.cc): the 64 lanes of a wave-instruction gather ascending, neighbouring weights,
-// a fraction of a 128-byte line per lane instead of a line each (config 3: 82 k records over a
-// 4 MB table = 0.38 lines per record; tools/sorted_bench.hip: 0.32 ms per 10^8 records against
-// 0.59 ms for the same loop over unsorted records).  A record adds w * d, d = (sign(hit) -
+// graph_compile.cc; SORT_K = 20 coalesced 8-byte loads in flight per lane, the next step's records
+// under this step's gathers): the 64 lanes of a wave-instruction gather ascending, neighbouring
+// weights, a fraction of a 128-byte line per lane instead of a line each (config 3: 164 k records
+// over a 4 MB table = 0.2 L2 requests per record; tools/sorted_bench.hip: 0.285 ms per 10^8 records
+// against 0.609 ms for the same loop over unsorted records).  A record adds w * d, d = (sign(hit) -
 // sign(miss)) * f, to its owner's potential difference pp - pn in LDS -- a 64-bit fixed-point
 // atomic add (pot_fix: integer sums are order-independent, so the result does not depend on
 // the sorting and equals what sweep8_kernel's row walks compute; the oracle restates it).
-// Then the workgroup walks the super-tile's tiles, a lane per variable: the tiles' own
+// Then the workgroup walks the super-tile's tiles, 256 lanes per tile and four tiles per pass,
+// the per-variable words of the next pass in flight under the current one: the tiles' own
 // process_variable (W_FIXSUM: the potential is given) draws, stores, tallies, and -- learning --
 // publishes the wave ballots of the pull gradient exactly where sweep8_kernel puts them.
-// 64 KiB of sums + the table of distinct d values: two workgroups per CU, one streaming while
-// the other draws.  Replaces, for these variables, FactorGraph::potential's loop
-// (src/factor_graph.h:127-145) and draw_sample (src/gibbs_sampler.h:198-215).
+// LDS: 128 KiB of sums + the tile starts + the table of distinct d values (<= 1024; none when UNI).
+// Replaces, for these variables, FactorGraph::potential's loop (src/factor_graph.h:127-145) and
+// draw_sample (src/gibbs_sampler.h:198-215).
 
-template <bool LEARN>
+// UNI: the table of distinct d holds ONE value besides entry 0 (every record the same function and
+// feature value -- config 3: d = 2): it rides in a scalar register, the per-record ds_read_b64 of the
+// table goes away (round 4; the index is still what tells a zero-filled lane past the end: di == 0).
+template <bool LEARN, bool UNI = false>
 __global__ void __launch_bounds__(SORT_THREADS, SORT_WG_PER_CU)
 sorted_sweep_kernel(const KernelParams P, const SuperTile *supers, uint32_t n_supers, const SortRec8 *recs,
                     const double *dvals, uint32_t n_dvals) {
@@ -705,7 +723,8 @@ sorted_sweep_kernel(const KernelParams P, const SuperTile *supers, uint32_t n_su
   const SortRec8 *base = recs + (((uint64_t)S.hi << 32) | S.lo);
   SortRec8 rec[SORT_K];
   DWX_LOAD_SORTED_RECORDS(SORT_K, base, S.nrec, 0u, t, rec);
-  for (uint32_t i = t; i < n_dvals; i += SORT_THREADS) s_d[i] = dvals[i];
+  const double d_uni = UNI ? dvals[1] : 0.0;    // (uniform address: a scalar load)
+  if (!UNI) for (uint32_t i = t; i < n_dvals; i += SORT_THREADS) s_d[i] = dvals[i];
   for (uint32_t i = t; i < S.ntiles; i += SORT_THREADS) s_tv[i] = P.tiles[S.tile0 + i].v0;
   if (t == 0) s_tv[S.ntiles] = S.v0 + S.nv;
   for (uint32_t i = t; i < S.nv; i += SORT_THREADS) s_acc[i] = 0ull;
@@ -723,7 +742,7 @@ sorted_sweep_kernel(const KernelParams P, const SuperTile *supers, uint32_t n_su
 #pragma unroll
     for (int k = 0; k < SORT_K; ++k) {
       const uint32_t di = cur[k].od >> SORT_OWNER_BITS;     // 0: a lane past the end
-      const long long q = pot_fix((double)w[k] * s_d[di]);
+      const long long q = pot_fix((double)w[k] * (UNI ? d_uni : s_d[di]));
       if (di) atomicAdd(&s_acc[cur[k].od & SORT_OWNER_MASK], (unsigned long long)q);
     }
   }

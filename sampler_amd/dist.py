@@ -85,8 +85,8 @@ class HipEngine:
         self._plan_batches, self._dynamic_counts, self._shared_levels = 1, False, set()
         self._level_dynamic = {}      # batches -> agreed "some rank counts dynamically"
         self.comm_timing = None       # CommTiming: device time of the collectives (bench.py)
-        # all-boolean all-unary graphs: the gradient sums travel as 32-bit counts (agree())
-        self._narrow_shift, self._g32, self._g64 = None, None, None
+        # all-boolean all-unary graphs: the gradient sums travel as 32- or 16-bit counts (agree())
+        self._narrow_shift, self._narrow_bits, self._g32 = None, 32, None
 
     def agree(self, group=None):
         """Once after create: what every rank must decide alike.  A shard without categorical
@@ -112,11 +112,18 @@ class HipEngine:
             dist.all_reduce(u, op=dist.ReduceOp.SUM, group=group)      # (>= the largest record count of a weight over all ranks)
         shift, recs = -int(t[0]), int(u[0])
         unit_max = (int(t[1]) >> shift) if shift > 0 else 0
+        # (the overrides are agreed on too: ranks that disagreed would send different types into one collective)
+        ov = torch.tensor([int(bool(os.environ.get("DWX_NO_NARROW_ALLREDUCE"))), int(bool(os.environ.get("DWX_NO_16BIT_ALLREDUCE")))],
+                          dtype=torch.int32, device=self.grad.device)
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(ov, op=dist.ReduceOp.MAX, group=group)
         ok = (not self.has_categorical and shift > 0 and unit_max > 0 and recs * unit_max < 2 ** 31
-              and world > 1 and not os.environ.get("DWX_NO_NARROW_ALLREDUCE"))
+              and world > 1 and not int(ov[0]))
         self._narrow_shift = shift if ok else None
-        self._g32 = torch.empty(self.s.W, dtype=torch.int32, device=self.grad.device) if ok else None
-        self._g64 = torch.empty(self.s.W, dtype=torch.int64, device=self.grad.device) if ok else None   # (scratch: no allocation per call)
+        # 16-bit counts, two per 32-bit word (dwx_grad_pack_async), while even the sum over all ranks
+        # stays below 2^15: a quarter of the int64 bytes (config 5a at W = 1 M: 2 MB per mini-batch)
+        self._narrow_bits = 16 if (ok and recs * unit_max < 2 ** 15 and not int(ov[1])) else 32
+        self._g32 = None      # tensor view of the library's count buffer, made at the first call
 
     def allreduce_static_counts(self, group=None):
         """Once after create: every rank only counted its own shard's boolean updates and
@@ -203,12 +210,13 @@ class HipEngine:
             t = self.grad if self._dynamic_counts else self.grad_reduced
             narrow = self._narrow_shift is not None and not self._dynamic_counts
             if narrow:
-                # (exact: every sum is a multiple of 2^shift by construction; DWX_CHECK_NARROW=1 verifies)
-                g64, sh = t, self._narrow_shift
-                if os.environ.get("DWX_CHECK_NARROW"):
-                    assert bool(torch.equal((g64 >> sh) << sh, g64)), "a gradient sum is not a multiple of 2^%d" % sh
-                torch.bitwise_right_shift(g64, sh, out=self._g64)
-                self._g32.copy_(self._g64)
+                # the library packs (and checks: dwx_wait fails on a sum that is not a multiple of
+                # 2^shift or does not fit) and unpacks; only the all-reduce of its buffer is torch's
+                ptr, n_words = self.s.grad_pack(self._narrow_shift, self._narrow_bits)
+                if self._g32 is None or self._g32_key != (ptr, n_words):
+                    self._g32_holder = _CudaArray(ptr, n_words * 4, "<i4", 4)
+                    self._g32 = torch.as_tensor(self._g32_holder, device=self.grad.device)
+                    self._g32_key = (ptr, n_words)
                 t = self._g32
             if self.comm_timing is not None:
                 self.comm_timing.begin("allreduce", self.stream, t.numel() * t.element_size())
@@ -216,8 +224,7 @@ class HipEngine:
             if self.comm_timing is not None:
                 self.comm_timing.end("allreduce", self.stream)
             if narrow:
-                self._g64.copy_(self._g32)
-                torch.bitwise_left_shift(self._g64, sh, out=g64)
+                self.s.grad_unpack(self._narrow_shift, self._narrow_bits)
 
     # ---- replicas (the reference's n_datacopy) ----
     def sample_sgd(self, stepsize):

@@ -25,7 +25,7 @@ SYMBOLS = [
     "dwx_graph_create", "dwx_graph_destroy", "dwx_graph_get_info", "dwx_graph_get_schedule",
     "dwx_graph_get_values", "dwx_graph_get_fixed_point_mask", "dwx_graph_get_positions", "dwx_graph_get_index",
     "dwx_sampler_create", "dwx_device_init", "dwx_device_count", "dwx_buffer_copy", "dwx_sampler_destroy", "dwx_sample_async", "dwx_sample_n_async", "dwx_sample_sgd_async",
-    "dwx_wait", "dwx_sgd_plan", "dwx_sgd_curvature", "dwx_sgd_plan_rows", "dwx_sgd_plan_force_dynamic", "dwx_sgd_get_chunks", "dwx_grad_pack32_async", "dwx_grad_unpack32_async", "dwx_sgd_accumulate_async",
+    "dwx_wait", "dwx_sgd_plan", "dwx_sgd_curvature", "dwx_sgd_plan_rows", "dwx_sgd_plan_force_dynamic", "dwx_sgd_get_chunks", "dwx_grad_pack32_async", "dwx_grad_unpack32_async", "dwx_grad_pack_async", "dwx_grad_unpack_async", "dwx_sgd_accumulate_async",
     "dwx_sgd_apply_async", "dwx_sgd_finish",
     "dwx_get_weights", "dwx_set_weights", "dwx_average_weights_async",
     "dwx_clear_tallies", "dwx_get_tallies",
@@ -108,6 +108,8 @@ class Library:
         L.dwx_sgd_get_chunks.argtypes = [vp, vp]
         L.dwx_grad_pack32_async.argtypes = [vp, C.c_uint32, vp, vp]
         L.dwx_grad_unpack32_async.argtypes = [vp, C.c_uint32]
+        L.dwx_grad_pack_async.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp]
+        L.dwx_grad_unpack_async.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.dwx_sgd_accumulate_async.argtypes = [vp, C.c_uint32]
         L.dwx_sgd_apply_async.argtypes = [vp]
         L.dwx_sgd_finish.argtypes = [vp]
@@ -282,6 +284,17 @@ class GibbsSampler:
 
     def sgd_plan_force_dynamic(self, on=True):
         self.lib.check(self.lib.L.dwx_sgd_plan_force_dynamic(self.h, int(bool(on))))
+
+    def grad_pack(self, shift, bits=32):
+        """dwx_grad_pack_async: the gradient sums as 32- or 16-bit counts (two per word) in a device
+        buffer of the library -> (device pointer, number of 32-bit words); dwx_wait fails if a sum
+        was not a multiple of 2^shift or did not fit."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        self.lib.check(self.lib.L.dwx_grad_pack_async(self.h, int(shift), int(bits), C.byref(ptr), C.byref(n)))
+        return ptr.value, int(n.value)
+
+    def grad_unpack(self, shift, bits=32):
+        self.lib.check(self.lib.L.dwx_grad_unpack_async(self.h, int(shift), int(bits)))
 
     def sgd_chunks(self, n_chunks):
         """[n_chunks, 2]: chunk c covers positions [r[c, 0], r[c, 1]) of the schedule order."""

@@ -22,7 +22,7 @@ def dw_emu():
     return DW_EMU
 
 
-def run_dw(binary, fx, out, extra=(), args=None):
+def run_dw(binary, fx, out, extra=(), args=None, env=None):
     d = os.path.join(GOLDEN, fx)
     cmd = [binary, "gibbs", "-m", os.path.join(d, "graph.meta"), "-w", os.path.join(d, "graph.weights"),
            "-v", os.path.join(d, "graph.variables"), "-f", os.path.join(d, "graph.factors"), "-o", out]
@@ -30,7 +30,7 @@ def run_dw(binary, fx, out, extra=(), args=None):
         cmd += ["--domains", os.path.join(d, "graph.domains")]
     cmd += (args if args is not None else open(os.path.join(d, "dw-args")).read().split())
     cmd += list(extra)
-    return subprocess.run(cmd, capture_output=True, text=True)
+    return subprocess.run(cmd, capture_output=True, text=True, env=env)
 
 
 def outputs(out):

@@ -134,16 +134,19 @@ def test_a_shard_with_a_single_tile_runs_the_split_plan_of_its_peers(dw_emu):
                 assert np.all(np.isfinite(w)) and np.abs(w).max() < 1.0, w
 
 
-def test_gradient_travels_as_32_bit_counts_where_the_graph_allows_it(dw_emu):
+def test_gradient_travels_as_narrow_counts_where_the_graph_allows_it(dw_emu):
     """All-boolean all-unary blocks (biased_coin: ISTRUE, f = 1: every contribution is +-2^31):
-    the ranks agree on the shift and all-reduce int32 counts (dwx_grad_pack32_async); a graph with
+    the ranks agree on the shift and all-reduce counts -- 16-bit ones packed two per word while the
+    sum over all ranks of a weight's records stays below 2^15, else 32-bit (dwx_grad_pack_async); a graph with
     categorical variables keeps the int64 vector.  Either way the result files are the single
     rank's (test_shards_of_a_unary_graph_reproduce_the_single_rank_run_byte_for_byte)."""
-    for fx, want in (("biased_coin", "32-bit counts, shift 31"), ("biased_coin_with_multinomial", "int64 sums")):
+    for fx, want, env in (("biased_coin", "16-bit counts, shift 31", None),
+                          ("biased_coin", "32-bit counts, shift 31", dict(os.environ, DWX_NO_16BIT_ALLREDUCE="1")),
+                          ("biased_coin_with_multinomial", "int64 sums", None)):
         with tempfile.TemporaryDirectory() as a, tempfile.TemporaryDirectory() as b:
             common = ["--seed", "11", "--step_cap", "0", "-l", "150", "-i", "50"]    # (last value wins)
             r1 = run_dw(dw_emu, fx, a, common + ["--quiet"])
-            r2 = run_dw(dw_emu, fx, b, common + ["--gpus", "2", "--comm", "host"])
+            r2 = run_dw(dw_emu, fx, b, common + ["--gpus", "2", "--comm", "host"], env=env)
             assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr
             assert "Gradient all-reduce: " + want in r2.stdout, r2.stdout[-1500:]
             assert outputs(a) == outputs(b)

@@ -20,13 +20,15 @@ def test_hip_engine_rccl_plumbing_world_size_1():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("stepsize,mixed", [(0.0002, False), (0.05, False), (0.0002, True), (0.02, True)])
-def test_two_ranks_share_one_gpu_over_gloo(stepsize, mixed):
+@pytest.mark.parametrize("stepsize,mixed,bits", [(0.0002, False, 16), (0.05, False, 16), (0.05, False, 32), (0.0002, True, 0), (0.02, True, 0)])
+def test_two_ranks_share_one_gpu_over_gloo(stepsize, mixed, bits):
     """Two ranks of the sharded driver with the product engine (real kernels, raw device
     buffers, per-chunk static count tables shared across ranks, full or split sweeps) on one
     GPU over gloo.  Weights must be bit-identical on both ranks and equal to the CPU oracle
     replaying the same chunk sequence on the union graph; per-variable state must equal the
     oracle's block.  stepsize 0.0002: un-split sweeps; 0.05: starts split and walks down.
+    bits: the gradient sums travel as 16-bit counts packed two per word (the default on a graph
+    this small) or as 32-bit counts (DWX_NO_16BIT_ALLREDUCE); mixed graphs send int64.
     mixed: rank 1's block is all categorical, rank 0's all boolean -- the ranks' own views of
     "has categorical variables" differ, and both must still put the same [G | T] vector
     through every collective (they used to issue W against 2 W elements)."""
@@ -47,6 +49,8 @@ def test_two_ranks_share_one_gpu_over_gloo(stepsize, mixed):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
                        DWX_TEST_MIXED="1" if mixed else "0")
+            if bits == 32:
+                env["DWX_NO_16BIT_ALLREDUCE"] = "1"
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gpu_gloo_worker.py"),
                                            out, str(total), str(W), str(stepsize)], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
