@@ -49,7 +49,7 @@ SURVEY_BYTES = {"cfg3": (340.0, 404.0), "cfg5b": (564.0, 684.0)}
 RECORDS_PER_VAR = {"cfg3": 10, "cfg5b": 14}
 # the kernel sources whose sha256 stamps profiles/traffic.json (PMC bytes per launch): a kernel
 # change must not silently keep an old counter figure
-KERNEL_SOURCES = ("sweep_kernels.h", "tile_walk.h", "aux_kernels.h", "device_types.h")
+KERNEL_SOURCES = ("sweep_kernels.h", "tile_walk.h", "aux_kernels.h", "persist_kernels.h", "device_types.h")
 
 
 def kernel_sources_sha16():

@@ -370,7 +370,11 @@ int dwx_stream(dwx_sampler *s, void **stream);
  * sweeps = the split learning sweeps dwx_sample_sgd_async handed over as ONE graph launch since
  * the sampler was created (DWX_GRAPH=n in the environment: a sweep of >= n mini-batches is
  * captured and replayed as a hipGraph from the plan level's second sweep on, never while timing
- * is enabled; off by default -- measured, it buys nothing: DESIGN.md section 3.5). */
+ * is enabled; off by default -- measured, it buys nothing: DESIGN.md section 3.5); 4 = no time:
+ * launches = sweeps = the split learning sweeps that ran as ONE persistent launch (DWX_PERSIST=1 in the
+ * environment at dwx_sampler_create; all-unary graphs with at most 128 weights, >= 8 mini-batches:
+ * chunk loop, grid barrier and update inside the kernel; off by default -- measured, it is slower
+ * than the launches it replaces: sampler_amd/csrc/persist_kernels.h). */
 int dwx_kernel_time(dwx_sampler *s, int kind, double *ms, uint64_t *launches, uint64_t *sweeps);
 int dwx_kernel_time_reset(dwx_sampler *s, int enable);
 

@@ -284,20 +284,23 @@ DWX_DEV double l1_update(double w0, double G, double h, double T, double stepsiz
                                                : l1_flow(w0, G, h, T, stepsize, reg_param);
 }
 // InferenceResult::update_weight (src/inference_result.h:66-85) for one weight over one batch:
-// G, Td = the batch's fixed-point gradient sum and dynamic update count.
+// G, Td = the batch's fixed-point gradient sum and dynamic update count; returns the new value
+// (x itself for a fixed weight or one nobody visited).
+DWX_DEV double apply_value(double x, bool fixed, const long long *t_static, const long long *t_hess, uint32_t i,
+                           long long G, long long Td, double stepsize, double reg_param, int l2) {
+  const long long Tn = Td + (t_static ? t_static[i] : 0);
+  if (fixed || Tn == 0) return x;
+  const double Tt = (double)Tn / FIX_SCALE, Gg = (double)G / FIX_SCALE;
+  const double h = t_hess ? (double)t_hess[i] / H_SCALE : 0.0;
+  if (l2) return x - batch_step(h, reg_param * Tt, stepsize) * (Gg + reg_param * Tt * x);
+  return l1_update(x, Gg, h, Tt, stepsize, reg_param);
+}
 DWX_DEV void apply_one(double *weights, float *w32, const uint8_t *w_fixed, const long long *t_static,
                        const long long *t_hess, uint32_t i, long long G, long long Td, double stepsize,
                        double reg_param, int l2) {
   const long long Tn = Td + (t_static ? t_static[i] : 0);
   if (w_fixed[i] || Tn == 0) return;
-  const double Tt = (double)Tn / FIX_SCALE, Gg = (double)G / FIX_SCALE;
-  const double h = t_hess ? (double)t_hess[i] / H_SCALE : 0.0;
-  double x = weights[i];
-  if (l2) {
-    x -= batch_step(h, reg_param * Tt, stepsize) * (Gg + reg_param * Tt * x);
-  } else {
-    x = l1_update(x, Gg, h, Tt, stepsize, reg_param);
-  }
+  const double x = apply_value(weights[i], false, t_static, t_hess, i, G, Td, stepsize, reg_param, l2);
   weights[i] = x;
   w32[i] = (float)x;
 }
@@ -311,39 +314,6 @@ apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *gra
     if (G != 0 || Td != 0) { grad[i] = 0; grad[W + i] = 0; }
     apply_one(weights, w32, w_fixed, t_static, t_hess, i, G, Td, stepsize, reg_param, l2);
   }
-}
-
-// Few weights (W <= AGG_ROWS_MAX_W): the learning launch left one row of 2W sums per workgroup
-// (flush_accumulators, P.agg_rows).  A block takes ROWS_WPB weights: ROWS_LANES lanes per weight walk
-// the rows (a row's 2W sums are contiguous: a group of lanes reads 128 contiguous bytes), an LDS
-// tree adds the lanes' shares, lane 0 of each weight adds what the wave / workgroup bins put into
-// `grad` by atomics, and applies.  apply == 0 (fold_rows): the totals are ADDED INTO grad instead
-// (a multi-GPU driver all-reduces grad before it applies; an un-split sweep of several colour launches).
-constexpr uint32_t ROWS_WPB = 16, ROWS_LANES = BLOCK_THREADS / ROWS_WPB;
-__global__ void __launch_bounds__(BLOCK_THREADS)
-apply_rows_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *grad, const long long *rows,
-                  uint32_t n_rows, const long long *t_static, const long long *t_hess, uint32_t W, double stepsize,
-                  double reg_param, int l2, int apply) {
-  __shared__ long long s_g[ROWS_LANES][ROWS_WPB], s_t[ROWS_LANES][ROWS_WPB];
-  const uint32_t j = threadIdx.x % ROWS_WPB, rl = threadIdx.x / ROWS_WPB;
-  const uint32_t i = blockIdx.x * ROWS_WPB + j;
-  long long g = 0, td = 0;
-  if (i < W)
-    for (uint32_t r = rl; r < n_rows; r += ROWS_LANES) {
-      const long long *row = rows + (size_t)r * 2 * W;
-      g += row[i]; td += row[W + i];
-    }
-  s_g[rl][j] = g; s_t[rl][j] = td;
-  __syncthreads();
-  for (uint32_t half = ROWS_LANES / 2; half >= 1; half >>= 1) {
-    if (rl < half) { s_g[rl][j] += s_g[rl + half][j]; s_t[rl][j] += s_t[rl + half][j]; }
-    __syncthreads();
-  }
-  if (rl != 0 || i >= W) return;
-  const long long G = s_g[0][j] + grad[i], Td = s_t[0][j] + grad[W + i];
-  if (!apply) { grad[i] = G; grad[W + i] = Td; return; }
-  if (grad[i] != 0 || grad[W + i] != 0) { grad[i] = 0; grad[W + i] = 0; }
-  apply_one(weights, w32, w_fixed, t_static, t_hess, i, G, Td, stepsize, reg_param, l2);
 }
 
 // Inference with unchanged weights repeats the same products sweep after sweep: tabulate

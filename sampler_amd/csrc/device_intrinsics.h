@@ -35,6 +35,20 @@
 #define DWX_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #endif
 
+// In-launch hand-off between workgroups (persist_learn8_kernel's chunk barrier; the CDNA guide's
+// Guideline 16, recipe R1): payload stored WRITE-THROUGH by agent-scope relaxed atomic stores (global
+// address space: global_store ... sc1), every storing wave drains, ONE lane signals with an agent-scope
+// atomic add; the consumer polls ONE word relaxed, then ONE agent-scope acquire (+ its wait) before
+// the workgroup's barrier and the plain loads.
+#define DWX_GLOBAL_PTR(T, p) ((__attribute__((address_space(1))) T *)(p))
+#define DWX_AGENT_STORE_I64(p, v) __hip_atomic_store(DWX_GLOBAL_PTR(long long, p), (long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define DWX_AGENT_STORE_U32(p, v) __hip_atomic_store(DWX_GLOBAL_PTR(uint32_t, p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define DWX_AGENT_LOAD_U32(p) __hip_atomic_load(DWX_GLOBAL_PTR(uint32_t, p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define DWX_AGENT_ADD_U32(p, v) __hip_atomic_fetch_add(DWX_GLOBAL_PTR(uint32_t, p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define DWX_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define DWX_ACQUIRE_AGENT() do { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#define DWX_SLEEP() __builtin_amdgcn_s_sleep(2)
+
 namespace dwx {
 typedef uint32_t dwx_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t dwx_u32x2 __attribute__((ext_vector_type(2)));

@@ -96,8 +96,8 @@ constexpr uint32_t SORT_TV_SLOTS = 2 * SUPER_TILES_DEFAULT;   // tile starts of 
 #endif
 constexpr uint32_t SORT_THREADS = DWX_SORT_THREADS;   // sorted_sweep_kernel's workgroup
 constexpr int SORT_K = DWX_SORT_K;                    // ... and its records in flight per lane
-// per-workgroup gradient rows instead of a contended atomic flush: graphs with at most this many weights
-constexpr uint32_t AGG_ROWS_MAX_W = 128;
+// persist_learn8_kernel: every workgroup adds up all workgroups' gradient rows itself -- few weights only
+constexpr uint32_t PERSIST_MAX_W = 128;
 constexpr uint32_t SORT_MAX_DVALS = 1024;                     // distinct d values (8 KiB in LDS), else no sorted copy
 struct alignas(16) SuperTile {
   uint32_t tile0, ntiles;   // tiles [tile0, tile0 + ntiles)
@@ -250,9 +250,6 @@ struct KernelParams {
   uint32_t *tally;            // [R]
   const float *w32;           // [W] sampling copy of the weights, rounded to f32 (fits L2)
   long long *grad;            // [2W]: G then T (fixed point)
-  long long *agg_rows;        // learning, few weights (LDS accumulators): [grid][2W] -- each persistent workgroup
-                              // stores its sums as a row of its own (apply_rows_kernel / fold_rows_kernel add
-                              // the rows up) instead of grid x 2W atomics onto 2W addresses; null: atomics
   unsigned long long *delta;  // [n_tiles*4*2] per wave: {chains disagree, free < evid} ballots
   // launch
   uint64_t seed, sweep;
@@ -269,6 +266,26 @@ struct KernelParams {
                               // (int64[2W], learning kernel, only when W <= LDS_AGG_MAX_W), else 0
   uint32_t n_sweeps;          // MULTI builds of the inference sweep: sweeps [sweep, sweep + n_sweeps) in one launch
 };
+
+// A split learning sweep of a few-weights graph as ONE persistent launch (persist_learn8_kernel,
+// sweep_kernels.h): what the chunk loop and the in-launch updates need besides KernelParams.
+struct PersistArgs {
+  const uint32_t *chunk_tiles;   // [2 * n_chunks]: tiles [t0, t1) of chunk c
+  uint32_t n_chunks, grid;       // grid == gridDim.x: every workgroup resident (one per CU at most)
+  long long *rows;               // [2][grid][row_stride]: the workgroups' gradient sums of chunk c, parity c & 1
+  uint32_t row_stride;           // 2W rounded up to whole 128-byte lines (16 entries)
+  uint32_t *bar;                 // [0] arrivals (monotonic over the launch), [1] give-up flag; zeroed before every launch
+  const long long *t_static;     // [n_chunks][T[W] | h[W]]: static update counts and curvature bounds per chunk
+  double *weights;               // [W] master weights: read at the start, written back by workgroup 0 at the end
+  float *w32;
+  const uint8_t *w_fixed;
+  double stepsize, reg_param;
+  int32_t l2;
+  uint32_t spin_limit;           // polls of one barrier before a workgroup gives up (and takes the launch down)
+  uint32_t lds_w64_off;          // dynamic LDS: f64 weights [W], f32 copy [W] right behind
+  uint32_t lds_red_off;          // ... reduction scratch of the in-launch update (BLOCK_THREADS x 8 bytes) + flag
+};
+constexpr uint32_t PERSIST_MIN_CHUNKS = 8;     // fewer mini-batches: plain launches (nothing to win)
 
 }  // namespace dwx
 #endif

@@ -192,6 +192,7 @@ struct dwx_sampler {
     std::vector<SuperTile> sorted_supers;
     SuperTile *d_supers = nullptr;
     SortRec8 *d_sorted = nullptr;
+    uint32_t *d_chunk_tiles = nullptr; // [2 * chunks]: the chunks' tile ranges (persist_learn8_kernel)
     bool layout_done = false;          // ensure_level_layout ran (whatever it decided)
     uint64_t sweeps = 0;               // learning sweeps run at this level (plan_layouts == 0: the layout comes after 2048)
     // a split sweep of this level as ONE graph launch (dwx_sample_sgd_async): the instantiated graph,
@@ -200,7 +201,7 @@ struct dwx_sampler {
     int use_graph = 0;
     ~Level() {
       rt::graph_exec_destroy(gexec);
-      rt::dfree(d_supers); rt::dfree(d_sorted);
+      rt::dfree(d_supers); rt::dfree(d_sorted); rt::dfree(d_chunk_tiles);
       rt::dfree(d_inc_wid); rt::dfree(d_inc_slot); rt::dfree(d_inc_d); rt::dfree(d_t_static);
       for (auto &t : bp) { rt::dfree(t.d_ell); rt::dfree(t.d_tile0); }
       rt::dfree(d_bp_qtab); rt::dfree(d_bp_partial);
@@ -212,12 +213,16 @@ struct dwx_sampler {
   uint32_t cur_chunk = 0;             // last chunk handed to dwx_sgd_accumulate_async
   uint8_t *d_w_fixed = nullptr;
   long long *d_grad = nullptr;
-  // few weights (W <= AGG_ROWS_MAX_W, LDS accumulators): one row of 2W gradient sums per workgroup of
-  // the last learning launch instead of a contended atomic flush (flush_accumulators); rows_pending
-  // rows wait to be added up -- by apply_rows_kernel, or folded into d_grad before anything else
-  // reads or overwrites them
-  long long *d_agg_rows = nullptr;
-  uint32_t agg_rows_cap = 0, rows_pending = 0;
+  // a split learning sweep of an all-unary graph with few weights as ONE persistent launch
+  // (persist_learn8_kernel; opt-in, DWX_PERSIST=1: measured slower than the chunk-by-chunk launches):
+  // grid (<= one workgroup per CU), its rows [2][grid][row_stride], the barrier words, LDS layout
+  uint32_t persist_grid = 0, persist_row_stride = 0;
+  long long *d_persist_rows = nullptr;
+  uint32_t *d_persist_bar = nullptr;
+  size_t lds_persist = 0;
+  uint32_t persist_w64_off = 0, persist_red_off = 0;
+  bool persist_check_pending = false;
+  uint64_t persist_launches = 0;
   int *d_grad32 = nullptr;              // dwx_grad_pack32_async: the gradient sums as 32-bit counts
   uint32_t *d_pack_bad = nullptr;       // ... and its "not a multiple / does not fit" counter
   bool pack_check_pending = false;
@@ -241,7 +246,7 @@ struct dwx_sampler {
     rt::dfree(d_grad32); rt::dfree(d_pack_bad);
     rt::dfree(d_edges); rt::dfree(d_edges8); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
     rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_terms); rt::dfree(d_delta);
-    rt::dfree(d_w_fixed); rt::dfree(d_grad); rt::dfree(d_agg_rows);
+    rt::dfree(d_w_fixed); rt::dfree(d_grad); rt::dfree(d_persist_rows); rt::dfree(d_persist_bar);
     for (int i = 0; i < 2; ++i) { if (side[i]) rt::stream_destroy(side[i]); if (ev_join[i]) rt::event_destroy(ev_join[i]); }
     if (ev_fork) rt::event_destroy(ev_fork);
     if (stream) rt::stream_destroy(stream);
@@ -261,18 +266,6 @@ struct dwx_halo {
 };
 
 namespace {
-// the pending gradient rows of the last learning launch added into d_grad (few weights; see
-// dwx_sampler::d_agg_rows): before the rows are overwritten by the next launch and before anything
-// but apply reads the sums (a multi-GPU driver's all-reduce of d_grad)
-void fold_pending_rows(dwx_sampler *s) {
-  if (!s->rows_pending) return;
-  const uint32_t W = (uint32_t)s->cg->W;
-  rt::launch(apply_rows_kernel, (W + ROWS_WPB - 1) / ROWS_WPB, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
-             (const uint8_t *)s->d_w_fixed, s->d_grad, (const long long *)s->d_agg_rows, s->rows_pending,
-             (const long long *)nullptr, (const long long *)nullptr, W, 0.0, 0.0, 1, 0);
-  s->rows_pending = 0;
-}
-
 // launch the sweep kernel (+ the oversized-variable kernel) over tiles [t0, t1) of launch l
 // multi (inference of a graph without degree-binned variables): P.n_sweeps sweeps per launch
 template <bool LEARN>
@@ -318,13 +311,7 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
   // (all-unary graphs stage 8-byte terms whenever the compute phase needs no record)
   const size_t lds = tab8 ? s->lds_tab : slim ? s->lds_learn_pull : s->lds_bytes[LEARN ? 1 : 0];
   constexpr int RPC = (int)ROWPTR_UNROLL_CAT;
-  P.agg_rows = nullptr;
-  if (LEARN && P.lds_agg_off && s->d_agg_rows && grid <= s->agg_rows_cap) {
-    // few weights: a row of sums per workgroup instead of grid x 2W atomics onto 2W addresses
-    fold_pending_rows(s);            // (the rows of an earlier launch of this batch)
-    P.agg_rows = s->d_agg_rows;
-    s->rows_pending = grid;
-  }
+
   if constexpr (!LEARN) {
     if (multi) {   // (only asked for on compact-record graphs, never on the terms table)
       constexpr int RP = (int)ROWPTR_UNROLL;
@@ -1301,18 +1288,69 @@ void enqueue_apply(dwx_sampler *s) {
     auto it = s->levels.find(1);
     if (it != s->levels.end() && it->second->d_t_static) hs = it->second->d_t_static + W;
   }
-  if (s->rows_pending) {
-    // few weights: the batch's sums are the rows of its learning launch (+ what the wave / workgroup
-    // bins added to d_grad): summed and applied in one kernel
-    rt::launch(apply_rows_kernel, (W + ROWS_WPB - 1) / ROWS_WPB, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
-               (const uint8_t *)s->d_w_fixed, s->d_grad, (const long long *)s->d_agg_rows, s->rows_pending, ts, hs, W,
-               s->plan_eta, s->opts.reg_param, (int)(s->opts.regularization == 1), 1);
-    s->rows_pending = 0;
-    return;
-  }
   rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
              (const uint8_t *)s->d_w_fixed, s->d_grad, ts, hs, W, s->plan_eta, s->opts.reg_param,
              (int)(s->opts.regularization == 1));
+}
+
+// A split learning sweep of a few-weights, all-unary graph as ONE persistent launch
+// (persist_kernels.h): every chunk's draws, gradient rows, the barrier and the update inside it.
+// false: this sweep does not qualify (the caller enqueues it chunk by chunk).
+bool enqueue_persistent_sweep(dwx_sampler *s) {
+  dwx_sampler::Level *L = s->plan_level;
+  const uint32_t n = (uint32_t)s->plan_chunks.size();
+  if (!s->persist_grid || !L || s->plan_batches < 2 || n < PERSIST_MIN_CHUNKS || !L->fast || !L->d_t_static ||
+      L->rows < n || s->plan_force_dynamic)
+    return false;
+  rt::set_device(s->device);
+  uint32_t most = 0;
+  for (const auto &ch : s->plan_chunks) most = std::max(most, ch.t1 - ch.t0);
+  if (!most) return false;
+  if (!L->d_chunk_tiles) {
+    std::vector<uint32_t> ct;
+    for (const auto &ch : L->chunks) { ct.push_back(ch.t0); ct.push_back(ch.t1); }
+    L->d_chunk_tiles = upload(ct, s->stream);
+    rt::stream_sync(s->stream);      // (the host copy dies with this scope)
+  }
+  ++L->sweeps;
+  KernelParams P = s->base;
+  P.sweep = s->sweep;
+  PersistArgs A{};
+  A.chunk_tiles = L->d_chunk_tiles;
+  A.n_chunks = n;
+  A.grid = std::min(most, s->persist_grid);
+  A.rows = s->d_persist_rows;
+  A.row_stride = s->persist_row_stride;
+  A.bar = s->d_persist_bar;
+  A.t_static = L->d_t_static;
+  A.weights = s->d_weights; A.w32 = s->d_w32; A.w_fixed = s->d_w_fixed;
+  A.stepsize = s->plan_eta; A.reg_param = s->opts.reg_param;
+  A.l2 = s->opts.regularization == 1 ? 1 : 0;
+  A.spin_limit = 4u << 20;
+  A.lds_w64_off = s->persist_w64_off; A.lds_red_off = s->persist_red_off;
+  TimedSpan sp{};
+  if (s->timing) {
+    sp.a = rt::event_create(); sp.b = rt::event_create(); sp.c = rt::event_create(); sp.kind = 1;
+    rt::event_record(sp.a, s->stream);
+  }
+  rt::dmemset(s->d_persist_bar, 0, 16, s->stream);
+  if (s->rp_cat) rt::launch(persist_learn8_kernel<6, (int)ROWPTR_UNROLL_CAT>, A.grid, BLOCK_THREADS, s->lds_persist, s->stream, P, A);
+  else switch (s->stage_k) {
+    case 3: rt::launch(persist_learn8_kernel<3, (int)ROWPTR_UNROLL>, A.grid, BLOCK_THREADS, s->lds_persist, s->stream, P, A); break;
+    case 6: rt::launch(persist_learn8_kernel<6, (int)ROWPTR_UNROLL>, A.grid, BLOCK_THREADS, s->lds_persist, s->stream, P, A); break;
+    default: rt::launch(persist_learn8_kernel<12, (int)ROWPTR_UNROLL>, A.grid, BLOCK_THREADS, s->lds_persist, s->stream, P, A); break;
+  }
+  if (s->timing) {
+    rt::event_record(sp.b, s->stream);
+    rt::event_record(sp.c, s->stream);
+    sp.launches = 1; sp.has_pull = false; sp.new_sweep = true;
+    s->spans.push_back(sp);
+  }
+  s->terms_state = 0;               // the weights change
+  s->cur_chunk = n - 1;
+  s->persist_check_pending = true;
+  ++s->persist_launches;
+  return true;
 }
 
 void drain_spans(dwx_sampler *s) {
@@ -1626,10 +1664,24 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
         default: prepare8(sweep8_kernel<false, 12>, sweep8_kernel<true, 12>); prepare_tab(sweep8_kernel<false, 12, true>); break;
       }
     }
-    if (P.lds_agg_off && c.W <= AGG_ROWS_MAX_W) {
-      // few weights: the learning launches leave a row of 2W sums per workgroup (flush_accumulators)
-      s->agg_rows_cap = std::max(s->persistent_blocks[1], s->rec8 ? s->persistent_blocks8[1] : 0u);
-      s->d_agg_rows = (long long *)rt::dmalloc((size_t)s->agg_rows_cap * 2 * c.W * 8);
+    if (P.lds_agg_off && c.W <= PERSIST_MAX_W && s->rec8 && s->cgiant_tiles.empty() && s->bgiant_tiles.empty() &&
+        c.wide_tiles.empty() && getenv("DWX_PERSIST") && !getenv("DWX_NO_PERSIST")) {
+      // a split learning sweep as one persistent launch (opt-in): at most one workgroup per CU, all resident
+      s->persist_grid = rt::grid_barrier_blocks();
+      if (const char *e = getenv("DWX_PERSIST_WG_PER_CU")) s->persist_grid *= (uint32_t)std::max(1L, std::min(3L, atol(e)));   // (experiment)
+      s->persist_row_stride = (uint32_t)((2 * c.W + 15) / 16 * 16);
+      s->d_persist_rows = (long long *)rt::dmalloc((size_t)2 * s->persist_grid * s->persist_row_stride * 8);
+      s->d_persist_bar = (uint32_t *)rt::dmalloc(16);
+      s->persist_w64_off = (uint32_t)((s->lds_bytes[1] + 15) & ~(size_t)15);
+      s->persist_red_off = (uint32_t)((s->persist_w64_off + c.W * 12 + 15) & ~(size_t)15);
+      s->lds_persist = s->persist_red_off + (size_t)BLOCK_THREADS * 8 + 16;
+      if (s->lds_persist > 160 * 1024) s->persist_grid = 0;
+      else if (s->rp_cat) rt::allow_dynamic_lds(persist_learn8_kernel<6, (int)ROWPTR_UNROLL_CAT>, s->lds_persist);
+      else switch (s->stage_k) {
+        case 3: rt::allow_dynamic_lds(persist_learn8_kernel<3, (int)ROWPTR_UNROLL>, s->lds_persist); break;
+        case 6: rt::allow_dynamic_lds(persist_learn8_kernel<6, (int)ROWPTR_UNROLL>, s->lds_persist); break;
+        default: rt::allow_dynamic_lds(persist_learn8_kernel<12, (int)ROWPTR_UNROLL>, s->lds_persist); break;
+      }
     }
     rt::stream_sync(st);
     // the un-split sweep's curvature estimate is needed by the first dwx_sgd_plan: pay
@@ -1780,7 +1832,6 @@ int dwx_sgd_accumulate_async(dwx_sampler *s, uint32_t chunk) {
   return guarded([&]() {
     s->cur_chunk = chunk;
     enqueue_learn_chunk(s, chunk);
-    fold_pending_rows(s);     // (a multi-GPU driver all-reduces DWX_BUF_GRAD between this call and the apply)
   });
 }
 
@@ -1825,7 +1876,9 @@ int dwx_sample_sgd_async(dwx_sampler *s, double stepsize) {
     const bool replay = L && graph_min_chunks > 0 && s->plan_batches > 1 && n >= (size_t)graph_min_chunks &&
                         !s->timing && L->use_graph >= 0 && L->sweeps >= 1 &&
                         !(s->opts.plan_layouts == 0 && L->sweeps + 1 == layout_after_sweeps());
-    if (!replay) {
+    if (enqueue_persistent_sweep(s)) {
+      // (few weights, many mini-batches: the whole split sweep is one persistent launch)
+    } else if (!replay) {
       enqueue_sweep();
     } else {
       rt::set_device(s->device);
@@ -1913,6 +1966,17 @@ int dwx_wait(dwx_sampler *s) {
   return guarded([&]() {
     rt::set_device(s->device);
     rt::stream_sync(s->stream);
+    if (s->persist_check_pending) {   // (a persistent split sweep whose workgroups were not all resident gave up)
+      uint32_t bar[4] = {0, 0, 0, 0};
+      rt::d2h(bar, s->d_persist_bar, 16, s->stream);
+      rt::stream_sync(s->stream);
+      s->persist_check_pending = false;
+      if (bar[1]) {
+        s->persist_grid = 0;          // (never again on this sampler)
+        throw std::runtime_error("a persistent learning sweep gave up at its grid barrier (its workgroups were not all "
+                                 "resident): the weights and chains of that sweep are invalid; DWX_NO_PERSIST=1 disables it");
+      }
+    }
     if (s->pack_check_pending) {      // (the 32-bit gradient counts: exact by construction, verified here)
       uint32_t bad = 0;
       rt::d2h(&bad, s->d_pack_bad, 4, s->stream);
@@ -2154,7 +2218,13 @@ int dwx_kernel_time_reset(dwx_sampler *s, int enable) {
 }
 
 int dwx_kernel_time(dwx_sampler *s, int kind, double *ms, uint64_t *launches, uint64_t *sweeps) {
-  if (!s || kind < 0 || kind > 3) return fail(DWX_E_INVALID, "bad argument");
+  if (!s || kind < 0 || kind > 4) return fail(DWX_E_INVALID, "bad argument");
+  if (kind == 4) {   // split learning sweeps run as ONE persistent launch since the sampler was created (no device time)
+    if (ms) *ms = 0.0;
+    if (launches) *launches = s->persist_launches;
+    if (sweeps) *sweeps = s->persist_launches;
+    return DWX_OK;
+  }
   if (kind == 3) {   // graph replays of split learning sweeps since the sampler was created (no device time)
     if (ms) *ms = 0.0;
     if (launches) *launches = s->graph_launches;

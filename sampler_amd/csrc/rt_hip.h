@@ -144,6 +144,11 @@ inline unsigned cu_count() {
   return (unsigned)std::max(1, cus);
 }
 
+// workgroups a kernel with a hand-rolled grid barrier may be launched with: one per CU -- all of them
+// resident together whatever else the sampler has queued (the barrier's price list and the sc1
+// hand-off forms of the CDNA guide are measured at one workgroup per CU)
+inline unsigned grid_barrier_blocks() { return cu_count(); }
+
 template <class K, class... A>
 inline void launch(K kernel, unsigned grid, unsigned block, size_t lds, stream_t s, A... args) {
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, args...);

@@ -171,22 +171,14 @@ DWX_DEV void stage_generic_records(const KernelParams &P, const TileDesc &d, con
 }
 
 // The per-workgroup gradient accumulators of a learning launch on a graph with few weights (LDS:
-// int64[2W], W <= LDS_AGG_MAX_W), flushed once per persistent workgroup.  With a handful of weights
-// the flush used to be the longest thing a chunk of a split sweep did: grid x 2W atomics onto 2W
-// addresses retire at ~0.3 G/s (tools/atomic_bench: 0.25 G/s on 8 addresses) -- config 4's 407
-// workgroups x 16 sums: ~15 of the chunk kernel's 22 us.  P.agg_rows (W <= AGG_ROWS_MAX_W): each
-// workgroup stores its sums as ONE ROW of its own, plain stores, zeros included; apply_rows_kernel
-// (or fold_rows_kernel, where something else reads the sums first) adds the rows up.  Integer sums:
-// the same totals in any order.
+// int64[2W], W <= LDS_AGG_MAX_W), flushed once per persistent workgroup with atomics that skip
+// zero sums.  (Round 4 measured what that flush costs a chunk of config 4's split sweep -- 407
+// workgroups x 16 sums onto 16 addresses: 1.2 us of 18, compiled out; a row of sums per workgroup
+// + a summing update kernel instead was 3 us per chunk SLOWER in wall time: not kept.)
 DWX_DEV void flush_accumulators(const KernelParams &P, const long long *s_agg, uint32_t t) {
   if (!s_agg) return;
   __syncthreads();
-#ifndef DWX_EXP_NOFLUSH   // (timing experiment: what the flush costs a chunk of a split sweep)
-  if (P.agg_rows) {
-    long long *row = P.agg_rows + (size_t)blockIdx.x * 2 * P.num_weights;
-    for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) row[i] = s_agg[i];
-    return;
-  }
+#ifndef DWX_EXP_NOFLUSH   // (timing experiment)
   for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) {
     const long long v = s_agg[i];
     if (v) atomicAdd((unsigned long long *)&P.grad[i], (unsigned long long)v);
@@ -920,5 +912,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS) wide_kernel(const KernelParams 
 }  // namespace dwx
 
 #include "aux_kernels.h"
+#include "persist_kernels.h"
 
 #endif  // DWX_SWEEP_KERNELS_H_

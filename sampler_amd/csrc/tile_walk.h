@@ -543,7 +543,12 @@ DWX_DEV void bool_potentials_both(const KernelParams &P, const TileView &T, uint
   }
 }
 
-constexpr double DRAW_GUARD = 1e-4;   // >> every f32 error bound below
+#ifndef DWX_DRAW_GUARD
+#define DWX_DRAW_GUARD 1e-4
+#endif
+// (tests/hipemu builds one library with DWX_DRAW_GUARD = 2: the f32 tier then never decides and every
+// categorical draw of a small domain goes through the second, linear-space tier -- parity over it)
+constexpr double DRAW_GUARD = DWX_DRAW_GUARD;   // >> every f32 error bound below
 constexpr uint32_t SMALL_CARD = 8;    // domains up to this size are drawn out of registers
 
 // src/gibbs_sampler.h:204-214: proposal 1 iff r * (1 + exp(pn - pp)) < 1.
@@ -610,6 +615,54 @@ DWX_DEV uint32_t cat_draw(const KernelParams &P, const TileView &T, uint32_t row
       }
     }
     if (decided) return pick;
+#ifdef DWX_EXP_NOSLOW      // (timing experiment, results invalid: what the exact f64 sequence costs a chunk's critical path)
+    return pick;
+#endif
+    // Second tier (round 4).  The exact sequence below is sixteen DEPENDENT f64 transcendentals
+    // (eight logadds = exp + log1p each, eight exps): ~5 us for the whole wave whenever ONE of its
+    // lanes is within DRAW_GUARD of a boundary -- one wave in ten; measured on config 4: a third of
+    // the inference sweep and 5 us on the critical path of every mini-batch of a split learning sweep.
+    // The same sequence in LINEAR space needs eight INDEPENDENT f64 exps: with e_d = exp(pot_d - m),
+    // the reference's sum = logadd(... logadd(-100000, pot_0) ..., pot_{card-1}) is log(L) + m where
+    // L follows  L <- hi + lo,  or  L <- hi  when lo / hi < exp(-18.42)  (the cut-off of logadd,
+    // src/common.h:118-132; lo, hi = min, max of (L, e_d); the start value -100000 is dropped the
+    // same way), and r -= exp(pot_d - sum) is r -= e_d / L: the first d with e_0 + .. + e_d >= r L.
+    // Every quantity here carries ~1e-15 relative error like the reference's own; the verdict is
+    // taken only 1e-11 L away from both cumulative boundaries and with every cut-off decision 1e-9
+    // clear of its threshold -- otherwise (one draw in 10^10) the exact sequence still decides.
+    // (|m| < 1000: the reference's sum lives in log space, its rounding error grows with its magnitude
+    // -- 8 ulp(1000) ~ 1e-12 is what the 1e-11 guard covers; larger potentials take the exact path.)
+    if (m > -1000.0 && m < 1000.0) {
+      constexpr double CUT = 1.0006809757111146e-08;    // exp(-18.42)
+      double e[SMALL_CARD];
+#pragma unroll
+      for (uint32_t d = 0; d < SMALL_CARD; ++d) e[d] = d < card ? exp(pot[d] - m) : 0.0;
+      double L = 0.0;
+      bool clear = true;
+#pragma unroll
+      for (uint32_t d = 0; d < SMALL_CARD; ++d) {
+        if (d < card) {
+          const double lo = L < e[d] ? L : e[d], hi = L < e[d] ? e[d] : L;
+          const double thr = hi * CUT, gap = lo - thr;
+          if ((gap < 0.0 ? -gap : gap) <= 1e-9 * thr && hi > 0.0) clear = false;
+          L = gap < 0.0 ? hi : hi + lo;
+        }
+      }
+      const double target2 = r * L, g2 = 1e-11 * L;
+      double cum = 0.0;
+      bool done2 = false, near2 = false;
+      uint32_t pick2 = card - 1;
+#pragma unroll
+      for (uint32_t d = 0; d < SMALL_CARD; ++d) {
+        const double lo2 = cum;
+        cum += e[d];
+        if (!done2 && !near2 && d < card && cum >= target2) {
+          if (target2 - lo2 > g2 && cum - target2 > g2) { done2 = true; pick2 = d; }
+          else near2 = true;
+        }
+      }
+      if (clear && done2) return pick2;
+    }
     // exact: the reference's sequence
     double sum = -100000.0;
 #pragma unroll

@@ -62,6 +62,16 @@ void run_grid(unsigned grid, unsigned block, size_t lds_bytes, const std::functi
 #define DWX_LOAD_ROW_NT(p) (*(p))
 #define DWX_NT_STORE(v, p) (*(p) = (v))
 
+// in-launch hand-off words (the harness runs a grid's blocks one after another: a kernel with a grid
+// barrier is launched with ONE block here, rt::grid_barrier_blocks())
+#define DWX_AGENT_STORE_I64(p, v) (*(p) = (long long)(v))
+#define DWX_AGENT_STORE_U32(p, v) (*(p) = (uint32_t)(v))
+#define DWX_AGENT_LOAD_U32(p) (*(p))
+#define DWX_AGENT_ADD_U32(p, v) (atomicAdd((unsigned *)(p), (unsigned)(v)))
+#define DWX_DRAIN_VMEM() ((void)0)
+#define DWX_ACQUIRE_AGENT() ((void)0)
+#define DWX_SLEEP() ((void)0)
+
 inline void __syncthreads() { ::emu::syncthreads(); }
 
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {

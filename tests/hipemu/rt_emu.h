@@ -60,6 +60,10 @@ template <class K>
 inline unsigned resident_blocks(K, unsigned, size_t) { return 3; }
 
 inline unsigned cu_count() { return 5; }
+// workgroups a kernel with a grid barrier may be launched with: the harness runs blocks one after
+// another, so ONE (its barrier then passes trivially; the chunk loop, the rows and the in-launch
+// update run as on the device)
+inline unsigned grid_barrier_blocks() { return 1; }
 
 template <class K, class... A>
 inline void launch(K kernel, unsigned grid, unsigned block, size_t lds, stream_t, A... args) {

@@ -64,6 +64,29 @@ def test_synth_exact(lib):
                stepsize=0.001)
 
 
+def test_split_learning_sweep_as_one_persistent_launch(lib, monkeypatch):
+    """DWX_PERSIST=1 (opt-in: built, exact, measured slower than the plain launches -- persist_kernels.h).
+    Config 4 with learning (8 weights tied to 10^5 evidence factors each: 64 mini-batches per sweep)
+    and a boolean graph with 20 weights: every split sweep is ONE launch of persist_learn8_kernel --
+    up to one workgroup per CU, a gradient row per workgroup and chunk, a grid barrier between the
+    chunks, the update applied by every workgroup to its LDS copy of the weights.  Exact against the
+    oracle stepped chunk by chunk; bit for bit the chunk-by-chunk launches (DWX_NO_PERSIST)."""
+    for raw, kw in ((synthetic.cfg4(200_000, card=8, seed=7, learn=True), dict(stepsize=0.001, decay=0.9)),
+                    (synthetic.cfg3(300_000, n_weights=20, seed=4), dict(stepsize=0.002, decay=0.8, regularization="l1",
+                                                                        reg_param=0.002))):
+        monkeypatch.setenv("DWX_PERSIST", "1")
+        s, _ = run_parity(lib, raw, n_learn=4, n_infer=2, **kw)
+        batches, n_chunks, _ = s.sgd_plan(kw["stepsize"])
+        assert batches >= 8 and n_chunks >= 8, (batches, n_chunks)
+        assert s.kernel_time("persist")[1] >= 3, s.kernel_time("persist")
+        monkeypatch.delenv("DWX_PERSIST")
+        s2, _ = run_parity(lib, raw, n_learn=4, n_infer=2, **kw)
+        assert s2.kernel_time("persist")[1] == 0
+        assert np.array_equal(s.weights, s2.weights)
+        assert np.array_equal(s.assignments("free"), s2.assignments("free"))
+        assert np.array_equal(s.assignments("evid"), s2.assignments("evid"))
+
+
 def test_split_learning_sweep_replayed_as_one_graph(lib, monkeypatch):
     """DWX_GRAPH=4: dwx_sample_sgd_async hands a split sweep (>= 4 mini-batches: config 4's tied
     weights) over as ONE hipGraph launch from the plan level's second sweep on -- captured every

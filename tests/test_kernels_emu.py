@@ -65,6 +65,53 @@ def test_synth_cfg4(lib):
                stepsize=0.01)
 
 
+def test_categorical_draws_through_the_second_tier():
+    """cat_draw's second tier (the reference's logadd sequence restated in linear space: eight
+    independent f64 exps instead of sixteen dependent transcendentals) must return the exact
+    sequence's verdict.  libdwx_emu_tier2.so is built with DWX_DRAW_GUARD = 2: the f32 tier never
+    decides, EVERY small-domain categorical draw goes through the second tier -- half a million of
+    them here, against the oracle's reference sequence, including potentials spread over the logadd
+    cut-off (terms dropped below exp(-18.42) of the running sum, src/common.h:118-132)."""
+    import subprocess
+    from parity import EMU_DIR
+    subprocess.run(["make", "-s", "-C", EMU_DIR, "build/libdwx_emu_tier2.so"], check=True)
+    lib2 = dwx.Library(os.path.join(EMU_DIR, "build", "libdwx_emu_tier2.so"))
+    run_parity(lib2, synthetic.cfg4(20_000, card=8, seed=6, learn=False), n_learn=0, n_infer=20, check_index=False)
+    raw = synthetic.cfg4(6000, card=8, seed=8, learn=False)
+    raw.w_initial_value[:] = [0.0, -18.3, -18.5, -30.0, 5.0, -13.4199, 2.0, -18.42]
+    run_parity(lib2, raw, n_learn=0, n_infer=10, check_index=False)
+    raw.w_initial_value[:] = [-40.0, -58.41, -58.43, -40.0 - 18.42, -77.0, -40.0, -41.0, -900.0]
+    run_parity(lib2, raw, n_learn=0, n_infer=10, check_index=False)
+    run_parity(lib2, synthetic.cfg4(4000, card=5, seed=7, learn=True), n_learn=6, n_infer=6, stepsize=0.01)
+    run_parity(lib2, synthetic.cfg4(3000, card=3, seed=9, learn=True), n_learn=4, n_infer=6, stepsize=0.02)
+    for fx in ("biased_coin_with_multinomial", "sparse_multinomial2", "sparse_domains"):
+        run_parity(lib2, binary_format.read_graph_dir(os.path.join(GOLDEN, fx)), n_learn=20, n_infer=40, stepsize=0.01)
+
+
+def test_split_sweep_as_one_persistent_launch(lib, monkeypatch):
+    """DWX_PERSIST=1 (opt-in: measured slower than the plain launches, persist_kernels.h): a split
+    learning sweep of an all-unary graph with few weights (>= 8 mini-batches) runs as ONE
+    launch of persist_learn8_kernel: chunk loop, a gradient row per workgroup, grid barrier, the update
+    by every workgroup on its LDS copy of the weights (here with one workgroup: the harness runs a
+    grid's blocks one after another; tests/test_gpu_parity.py has the full grid) -- exact against the
+    oracle stepped chunk by chunk, categorical (config 4's shape) and boolean, L2 and L1."""
+    monkeypatch.setenv("DWX_PERSIST", "1")
+    raw = synthetic.cfg4(700, card=5, seed=7, learn=True)
+    s, _ = run_parity(lib, raw, n_learn=5, n_infer=1, stepsize=0.01, decay=1.0, compile_opts=dict(tile_vars=16))
+    batches, n_chunks, _ = s.sgd_plan(0.01)
+    assert batches >= 8 and n_chunks >= 8, (batches, n_chunks)
+    assert s.kernel_time("persist")[1] == 5, s.kernel_time("persist")
+    raw = synthetic.cfg3(3000, n_weights=20, seed=4)
+    s, _ = run_parity(lib, raw, n_learn=4, n_infer=2, stepsize=0.01, decay=0.9, compile_opts=dict(tile_vars=32),
+                      regularization="l1", reg_param=0.002)
+    assert s.kernel_time("persist")[1] >= 3, s.kernel_time("persist")
+    # timing on: the sweep is still one launch, counted as such
+    s.kernel_time_reset(True)
+    s.sample_sgd(0.005); s.wait()
+    assert s.kernel_time("learn")[1:] == (1, 1), s.kernel_time("learn")
+    s.kernel_time_reset(False)
+
+
 def test_split_sweep_through_the_graph_replay_path(lib, monkeypatch):
     """DWX_GRAPH=n: dwx_sample_sgd_async captures a split sweep and replays it as one graph launch
     (the harness's "capture" runs the launches eagerly and its graph launch is a no-op: the host

@@ -85,7 +85,7 @@ if traffic:
     # null` when the tree has moved on (tools/update_traffic.py merges it into profiles/traffic.json)
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = ("sweep_kernels.h", "tile_walk.h", "aux_kernels.h", "device_types.h")
+    files = ("sweep_kernels.h", "tile_walk.h", "aux_kernels.h", "persist_kernels.h", "device_types.h")
     h = hashlib.sha256()
     for f in files:
         h.update(open(os.path.join(root, "sampler_amd", "csrc", f), "rb").read())
