@@ -96,9 +96,15 @@ typedef struct dwx_compile_opts {
   uint32_t no_sorted_records;  /* 1: no weight-sorted second copy of the records of boolean all-unary
                                   tiles (default 0: compact-record graphs with >= 4096 weights get
                                   one, and their sweeps gather weights in sorted order)        */
-  uint32_t super_tiles;        /* tiles per weight-sorted super-tile, at most (default 32 = 8192 variables) */
-  uint32_t sorted_slots;       /* workgroups of sorted_sweep_kernel resident at once (default 512: two per
-                                  CU of an MI355X); runs of tiles are cut into multiples of it          */
+  uint32_t super_tiles;        /* tiles per weight-sorted super-tile, at most (default 64 = 16 384 variables:
+                                  128 KiB of fixed-point sums, the CU's LDS)                            */
+  uint32_t sorted_slots;       /* workgroups of sorted_sweep_kernel resident at once (default 256: one
+                                  1024-thread workgroup per CU of an MI355X); runs of tiles are cut into
+                                  multiples of it                                                       */
+  uint32_t defer_sorted_records; /* set by dwx_graph_create itself where the library can build on the device
+                                  (always in the product; DWX_HOST_BUILD=1 in the environment keeps the host
+                                  builder): the weight-sorted copy is only PLANNED here and every sampler
+                                  builds its records on its own device (device_build.hip)               */
 } dwx_compile_opts;
 
 typedef struct dwx_graph_info {
@@ -322,12 +328,16 @@ enum {
                                (fixed point 2^-30), then the curvature bounds h[W] of
                                all variables (fixed point 2^-10); static; a multi-GPU
                                driver sums it across shards once after create      */
-  DWX_BUF_TSTATIC_PLAN = 6  /* int64[rows][2W]: the same pair per chunk of the current
+  DWX_BUF_TSTATIC_PLAN = 6, /* int64[rows][2W]: the same pair per chunk of the current
                                SPLIT plan (valid between dwx_sgd_plan and dwx_sgd_finish;
                                null / 0 bytes when the plan counts dynamically).  A
                                multi-GPU driver calls dwx_sgd_plan_rows(n_chunks of the
                                slowest rank) and sums the table across shards ONCE per
                                batch count (the library caches it per batch count)   */
+  DWX_BUF_SORTED_RECORDS = 7,      /* test hooks: the weight-sorted record copy of the graph's default  */
+  DWX_BUF_SORTED_RECORDS_PLAN = 8  /* layout / of the current plan level's own (8 bytes per record;
+                                      null / 0 bytes when there is none): the device build
+                                      (device_build.hip) is checked against the host builder's bytes  */
 };
 int dwx_device_buffer(dwx_sampler *s, int which, void **dev_ptr, uint64_t *nbytes);
 /* Copy between host memory and a device pointer obtained from dwx_device_buffer /

@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "device_build.h"
 #include "graph_compile.h"
 #include "host_parallel.h"
 
@@ -636,12 +637,24 @@ void ensure_level_layout(dwx_sampler *s, dwx_sampler::Level *L, uint32_t batches
   if (tiles_in_chunks / L->chunks.size() < 8ull * c.sorted_slots) return;
   rt::set_device(s->device);
   SortedLayout lay;
-  build_sorted_layout(c, ranges, c.sorted_per_super, c.sorted_slots, batches == 1, host_threads(), lay);
+  const bool on_device = devb::available() && !getenv("DWX_HOST_BUILD");
+  build_sorted_layout(c, ranges, c.sorted_per_super, c.sorted_slots, batches == 1, host_threads(), lay, on_device);
   if (lay.supers.empty()) return;
+  SortRec8 *d_sorted = nullptr;
+  SuperTile *d_supers = nullptr;
+  if (on_device) {
+    // (the records sit at their super-tiles' planned offsets whatever the order of the descriptors)
+    d_supers = upload(lay.supers, s->stream);
+    d_sorted = (SortRec8 *)rt::dmalloc((lay.n + 1) * sizeof(SortRec8));
+    rt::dmemset(d_sorted + lay.n, 0, sizeof(SortRec8), s->stream);
+    devb::build_sorted_records(s->d_tiles, s->d_edges, s->d_edges8, d_supers, (uint32_t)lay.supers.size(),
+                               c.sort_dbits.data(), (uint32_t)c.sort_dbits.size(), lay.n, d_sorted, (void *)s->stream);
+    rt::dfree(d_supers);
+  }
   // (launch_tiles looks super-tiles up by their first tile: ascending, like the default layout)
   std::sort(lay.supers.begin(), lay.supers.end(), [](const SuperTile &a, const SuperTile &b) { return a.tile0 < b.tile0; });
-  SortRec8 *d_sorted = upload(lay.recs, s->stream, 1);
-  SuperTile *d_supers = upload(lay.supers, s->stream);
+  if (!on_device) d_sorted = upload(lay.recs, s->stream, 1);
+  d_supers = upload(lay.supers, s->stream);
   rt::stream_sync(s->stream);   // (the host copies die with this scope; the sweeps queued so far used the default layout)
   L->sorted_supers.swap(lay.supers);
   L->d_sorted = d_sorted;
@@ -704,6 +717,19 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
     // update counts T of boolean variables and the curvature bounds h of all variables
     // (apply_kernel's saturating step); row k = [T[W] | h[W]]
     L->rows = nc;
+    const bool tables_on_device = devb::available() && !getenv("DWX_HOST_BUILD");
+    if (tables_on_device) {
+      // (a) on the device: a lane per variable over the uploaded records, integer atomics (device_build.hip)
+      std::vector<uint32_t> group_of(c.tiles.size(), 0xFFFFFFFFu);
+      for (uint32_t k = 0; k < nc; ++k)
+        for (uint32_t t = groups[k].t0; t < groups[k].t1; ++t) group_of[t] = k;
+      L->d_t_static = (long long *)rt::dmalloc((size_t)nc * 2 * c.W * 8);
+      long long tm = 0, hm = 0;
+      devb::build_static_tables(s->d_tiles, (uint32_t)c.tiles.size(), group_of.data(), s->d_v_meta, s->d_v_row, s->d_row_ptr,
+                                s->d_edges, s->d_edge_fval64, (const uint8_t *)s->d_w_fixed, (uint32_t)c.W, nc,
+                                o.learn_non_evidence != 0, o.noise_aware != 0, L->d_t_static, &tm, &hm, (void *)s->stream);
+      L->c_max = (double)hm / H_SCALE; L->t_max = (double)tm / FIX_SCALE;
+    } else {
     RawArray<long long> ts((size_t)nc * 2 * c.W);
     parallel_ranges((uint64_t)nc * 2 * c.W, nth, [&](uint64_t b, uint64_t e) { std::fill(ts.data() + b, ts.data() + e, 0LL); });
     const long long one = (long long)FIX_SCALE;
@@ -752,6 +778,8 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
       for (uint32_t t = 0; t < T; ++t) { L->c_max = std::max(L->c_max, hm[t]); L->t_max = std::max(L->t_max, tm[t]); }
     }
     L->d_t_static = upload_raw(ts.data(), (size_t)nc * 2 * c.W, s->stream);
+    rt::stream_sync(s->stream);      // (ts dies with this scope)
+    }
     // (b) incidence list
     struct Inc { uint32_t wid, slot; float d; uint32_t chunk; };
     RawArray<Inc> by_w, by_c;
@@ -1389,6 +1417,9 @@ int dwx_graph_create(const dwx_graph_desc *desc, const dwx_compile_opts *opts, d
   if (!desc || !out) return fail(DWX_E_INVALID, "null argument");
   dwx_compile_opts o{};
   if (opts) o = *opts;
+  // the weight-sorted copy of the records is built on the sampler's device where the library can
+  // (device_build.hip; DWX_HOST_BUILD=1: the host builder, which is also its checker)
+  o.defer_sorted_records = devb::available() && !getenv("DWX_HOST_BUILD");
   bool limit = false;
   try {
     auto cg = std::make_shared<CompiledGraph>();
@@ -1536,8 +1567,16 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     s->rec8 = c.edges8.size() != 0;
     if (s->rec8) s->d_edges8 = upload(c.edges8, st, 1);
     if (!c.supers.empty()) {
-      s->d_sorted = upload(c.sorted_recs, st, 1);
       s->d_supers = upload(c.supers, st);
+      if (c.sorted_deferred) {
+        // planned on the host, built here: emit + radix sort by (super-tile, weight id) on the device
+        s->d_sorted = (SortRec8 *)rt::dmalloc((c.n_sorted + 1) * sizeof(SortRec8));
+        rt::dmemset(s->d_sorted + c.n_sorted, 0, sizeof(SortRec8), st);
+        devb::build_sorted_records(s->d_tiles, s->d_edges, s->d_edges8, s->d_supers, (uint32_t)c.supers.size(),
+                                   c.sort_dbits.data(), (uint32_t)c.sort_dbits.size(), c.n_sorted, s->d_sorted, (void *)st);
+      } else {
+        s->d_sorted = upload(c.sorted_recs, st, 1);
+      }
       s->d_sort_dvals = upload(c.sort_dvals, st);
       s->n_sort_dvals = (uint32_t)c.sort_dvals.size();
       s->lds_sorted = (size_t)SUPER_NV_MAX * 8 + SORT_TV_SLOTS * 4 + (size_t)s->n_sort_dvals * 8;
@@ -2121,6 +2160,18 @@ int dwx_device_buffer(dwx_sampler *s, int which, void **dev_ptr, uint64_t *nbyte
         const bool tables = s->plan_level->fast && !(s->plan_batches > 1 && s->plan_force_dynamic);
         *dev_ptr = tables ? s->plan_level->d_t_static : nullptr;
         *nbytes = tables ? (uint64_t)s->plan_level->rows * c.W * 16 : 0;
+      }
+      break;
+    case DWX_BUF_SORTED_RECORDS:     // (test hook: the device-built copy against the host builder's)
+      *dev_ptr = s->d_sorted; *nbytes = s->d_sorted ? c.n_sorted * sizeof(SortRec8) : 0;
+      break;
+    case DWX_BUF_SORTED_RECORDS_PLAN:
+      if (!s->plan_level) return fail(DWX_E_INVALID, "no plan: call dwx_sgd_plan first");
+      *dev_ptr = s->plan_level->d_sorted;
+      {
+        uint64_t n = 0;
+        for (const SuperTile &st : s->plan_level->sorted_supers) n += st.nrec;
+        *nbytes = s->plan_level->d_sorted ? n * sizeof(SortRec8) : 0;
       }
       break;
     default: return fail(DWX_E_INVALID, "unknown buffer id");

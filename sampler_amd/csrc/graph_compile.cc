@@ -70,7 +70,8 @@ float sorted_rec_d(const EdgeRec8 &c) {
 // sweep 0.36 -> 0.40 ms).  Otherwise (the layout of a split plan, one range per mini-batch chunk):
 // `slots` equal super-tiles per run, so that every chunk's launch is as wide as the chip.
 void build_sorted_layout(const CompiledGraph &g, const std::vector<std::pair<uint32_t, uint32_t>> &ranges,
-                         uint32_t per_super, uint32_t slots, bool full_rounds, uint32_t nth, SortedLayout &out) {
+                         uint32_t per_super, uint32_t slots, bool full_rounds, uint32_t nth, SortedLayout &out,
+                         bool plan_only) {
   out.supers.clear(); out.recs.clear(); out.n = 0;
   if (g.edges8.size() == 0 || g.sort_dvals.empty()) return;
   per_super = std::max(1u, std::min(per_super, SORT_TV_SLOTS - 1));
@@ -116,6 +117,14 @@ void build_sorted_layout(const CompiledGraph &g, const std::vector<std::pair<uin
   }, 1);
   for (size_t i = 0; i < ns; ++i) count[i + 1] += count[i];
   out.n = count[ns];
+  if (plan_only) {
+    // (the records themselves are built on the device: device_build.hip)
+    for (size_t si = 0; si < ns; ++si) {
+      SuperTile &st = out.supers[si];
+      st.lo = (uint32_t)count[si]; st.hi = (uint32_t)(count[si] >> 32); st.nrec = (uint32_t)(count[si + 1] - count[si]);
+    }
+    return;
+  }
   // the records, super-tile by super-tile, sorted by (weight id, owner)
   out.recs.reset(out.n + 1);
   out.recs[out.n] = SortRec8{0u, 0u};
@@ -896,10 +905,11 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
             ranges.push_back({g.launch_query_tile_end[l], g.launch_tile[l + 1]});
           }
           SortedLayout lay;
-          build_sorted_layout(g, ranges, per_super, slots, true, nth, lay);
+          build_sorted_layout(g, ranges, per_super, slots, true, nth, lay, o.defer_sorted_records != 0);
           g.supers.swap(lay.supers);
           g.sorted_recs = std::move(lay.recs);
           g.n_sorted = lay.n;
+          g.sorted_deferred = o.defer_sorted_records != 0 && !g.supers.empty();
           if (g.supers.empty()) { g.sort_dvals.clear(); g.sort_dbits.clear(); }
         }
       }

@@ -57,6 +57,8 @@ struct CompiledGraph {
   std::vector<uint32_t> sort_dbits; // ... their f32 bit patterns, ascending (entry i <-> sort_dvals[i + 1])
   uint64_t n_sorted = 0;
   uint32_t sorted_per_super = 0, sorted_slots = 0;   // the layout's parameters (0: no sorted copy)
+  bool sorted_deferred = false;     // supers are planned (lo / hi / nrec set), sorted_recs is EMPTY: every sampler
+                                    // builds the records on its device (device_build.hip)
   // All-boolean compact-record graphs: every gradient contribution is +-round(2^30 * d_r),
   // d_r = (sign(hit) - sign(miss)) * f -- a multiple of 2^grad_shift, at most grad_unit_max of
   // those units, and no weight has more than max_records_per_weight records (a multi-GPU driver
@@ -91,8 +93,10 @@ struct SortedLayout {
   RawArray<SortRec8> recs;
   uint64_t n = 0;
 };
+// plan_only: the super-tiles with their record ranges (lo / hi / nrec) and out.n, no records
 void build_sorted_layout(const CompiledGraph &g, const std::vector<std::pair<uint32_t, uint32_t>> &ranges,
-                         uint32_t per_super, uint32_t slots, bool full_rounds, uint32_t n_threads, SortedLayout &out);
+                         uint32_t per_super, uint32_t slots, bool full_rounds, uint32_t n_threads, SortedLayout &out,
+                         bool plan_only = false);
 
 // Throws std::runtime_error (message for dwx_last_error) on malformed input;
 // `limit` is set when the failure is a 32-bit layout limit.

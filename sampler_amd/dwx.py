@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DWX_LIB") or os.path.join(HERE, "csrc", "libdwx.so")
 
 DWX_OK, DWX_E_INVALID, DWX_E_LIMIT, DWX_E_DEVICE, DWX_E_NOMEM = 0, -1, -2, -3, -4
-BUF_WEIGHTS, BUF_GRAD, BUF_ASSIGN_FREE, BUF_ASSIGN_EVID, BUF_TALLIES, BUF_TSTATIC, BUF_TSTATIC_PLAN = range(7)
+BUF_WEIGHTS, BUF_GRAD, BUF_ASSIGN_FREE, BUF_ASSIGN_EVID, BUF_TALLIES, BUF_TSTATIC, BUF_TSTATIC_PLAN, BUF_SORTED_RECORDS, BUF_SORTED_RECORDS_PLAN = range(9)
 
 # every symbol include/dwx.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -48,7 +48,7 @@ class CompileOpts(C.Structure):
                 ("no_compact_records", C.c_uint32), ("no_weight_order", C.c_uint32),
                 ("wide_min_records", C.c_uint32), ("no_record_vifs", C.c_uint32),
                 ("no_pull_unary", C.c_uint32), ("no_sorted_records", C.c_uint32),
-                ("super_tiles", C.c_uint32), ("sorted_slots", C.c_uint32)]
+                ("super_tiles", C.c_uint32), ("sorted_slots", C.c_uint32), ("defer_sorted_records", C.c_uint32)]
 
 
 class GraphInfo(C.Structure):
@@ -362,6 +362,14 @@ class GibbsSampler:
         p, n = C.c_void_p(), C.c_uint64()
         self.lib.check(self.lib.L.dwx_device_buffer(self.h, which, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def read_buffer(self, which, dtype=np.uint8):
+        """Host copy of a device buffer (dwx_device_buffer + dwx_buffer_copy); empty when there is none."""
+        p, n = self.device_buffer(which)
+        out = np.zeros(n // np.dtype(dtype).itemsize, dtype)
+        if p and n:
+            self.lib.check(self.lib.L.dwx_buffer_copy(self.h, out.ctypes.data, p, n, 0))
+        return out
 
     def stream(self):
         p = C.c_void_p()

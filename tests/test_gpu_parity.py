@@ -64,6 +64,76 @@ def test_synth_exact(lib):
                stepsize=0.001)
 
 
+def test_device_built_sorted_records_equal_the_host_builder(lib, monkeypatch):
+    """The weight-sorted copy of the records is built on the device (device_build.hip: ordered emit +
+    radix sort by (super-tile, weight id)) from the uploaded columns; the host builder
+    (graph_compile.cc: build_sorted_layout, DWX_HOST_BUILD=1) is its checker: the same bytes, for the
+    graph's default layout and for a split plan level's own layout (several feature values and sign
+    classes, fixed weights, query and evidence parts; 12 M records -- a level builds a layout of its
+    own only while a chunk still holds 2048 tiles)."""
+    raw = synthetic.cfg3(1_200_000, n_weights=150_000, seed=21)
+    rng = np.random.default_rng(5)
+    raw.fac_feature_value[:] = rng.choice([1.0, 0.5, 2.0, -1.0, 0.25], size=raw.num_factors)
+    raw.edge_equal_to[:] = rng.integers(0, 2, size=raw.num_edges)          # ISTRUE on "== 0" too: other sign classes
+    raw.w_is_fixed[:] = rng.random(raw.num_weights) < 0.1
+    got = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("DWX_HOST_BUILD", "1")
+        g = dwx.Graph(raw, lib=lib)
+        assert g.info.num_super_tiles > 0 and g.info.num_sorted_records > 0
+        s = dwx.GibbsSampler(g, seed=3, plan_layouts=1)
+        base = s.read_buffer(dwx.BUF_SORTED_RECORDS, np.uint64)
+        assert len(base) == g.info.num_sorted_records
+        s.sgd_plan(0.01, 1)                    # the un-split level: one run per launch (query + evidence tiles)
+        lvl1 = s.read_buffer(dwx.BUF_SORTED_RECORDS_PLAN, np.uint64)
+        s.sgd_plan(0.01, 2)                    # a split plan: super-tiles cut along its chunks
+        lvl2 = s.read_buffer(dwx.BUF_SORTED_RECORDS_PLAN, np.uint64)
+        s.sample_sgd(0.01); s.sample(); s.wait()
+        got[mode] = (base, lvl1, lvl2, s.weights.copy(), s.assignments("evid").copy())
+        s.close()
+    monkeypatch.delenv("DWX_HOST_BUILD")
+    assert len(got["device"][1]) > 0 and len(got["device"][2]) > 0, "a plan level built no layout of its own"
+    for k, what in enumerate(("default layout", "un-split level layout", "split level layout", "weights", "chain")):
+        assert np.array_equal(got["device"][k], got["host"][k]), what
+
+
+def test_device_built_static_tables_equal_the_host_builder(lib, monkeypatch):
+    """A plan level's static update counts T and curvature bounds h per chunk, built on the device
+    (device_build.hip: a lane per variable, integer atomics) against the host builder
+    (DWX_HOST_BUILD=1; dwx_api.cc build_level): the same tables bit for bit -- unary and pairwise
+    and ternary factors, boolean and categorical variables, fixed weights, several feature values,
+    un-split and split levels."""
+    rng = np.random.default_rng(9)
+    graphs = []
+    raw = synthetic.cfg3(120_000, n_weights=9000, seed=21)
+    raw.fac_feature_value[:] = rng.choice([1.0, 0.5, 2.0, -1.0, 0.3], size=raw.num_factors)   # (0.3: not f32-exact -> f64 side array)
+    raw.w_is_fixed[:] = rng.random(raw.num_weights) < 0.1
+    graphs.append(raw)
+    graphs.append(synthetic.cfg3b(60_000, n_weights=5000, seed=5))
+    graphs.append(synthetic.cfg3c(30_000, n_weights=3000, seed=6))
+    graphs.append(synthetic.cfg4(40_000, card=8, seed=7, learn=True))
+    graphs.append(synthetic.cfg4b(20_000, card=8, n_weights=2000, seed=8))
+    for gi, raw in enumerate(graphs):
+        got = {}
+        for mode in ("device", "host"):
+            if mode == "host":
+                monkeypatch.setenv("DWX_HOST_BUILD", "1")
+            g = dwx.Graph(raw, lib=lib)
+            s = dwx.GibbsSampler(g, seed=3)
+            t1 = s.read_buffer(dwx.BUF_TSTATIC, np.int64)
+            _, n_chunks, min_step1 = s.sgd_plan(0.01, 1)
+            b, n_chunks, min_step = s.sgd_plan(0.01, 4)
+            t4 = s.read_buffer(dwx.BUF_TSTATIC_PLAN, np.int64)
+            got[mode] = (t1, t4, np.array([min_step1, min_step, n_chunks], np.float64))
+            s.close()
+            if mode == "host":
+                monkeypatch.delenv("DWX_HOST_BUILD")
+        assert len(got["device"][0]) == 2 * raw.num_weights and np.abs(got["device"][0]).max() > 0
+        for k, what in enumerate(("un-split tables", "split tables", "smallest steps")):
+            assert np.array_equal(got["device"][k], got["host"][k]), (gi, what)
+
+
 def test_split_learning_sweep_as_one_persistent_launch(lib, monkeypatch):
     """DWX_PERSIST=1 (opt-in: built, exact, measured slower than the plain launches -- persist_kernels.h).
     Config 4 with learning (8 weights tied to 10^5 evidence factors each: 64 mini-batches per sweep)

@@ -9,6 +9,7 @@ mkdir -p variants
   "$@" -x hip -c -o variants/$name.o dwx_api.cc
 # (the graph compiler shares device_types.h with the kernels: same flags)
 g++ -O2 -std=c++17 -fPIC -Wall -Wextra -pthread "$@" -c -o variants/$name.gc.o graph_compile.cc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/$name.so variants/$name.o variants/$name.gc.o -pthread
+make -s device_build.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/$name.so variants/$name.o variants/$name.gc.o device_build.o -pthread
 rm -f variants/$name.o variants/$name.gc.o
 echo "built sampler_amd/csrc/variants/$name.so"
