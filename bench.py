@@ -345,10 +345,10 @@ def main():
         raw, ghosts = synthetic.cfg5b_shard(V * n_gpus, bounds[rank][0], bounds[rank][1], W, seed=1234)
     graph = dwx.Graph(raw, tile_vars=args.tile_vars, tile_edges=args.tile_edges,
                       no_compact_records=1 if args.wide_records else 0)
-    # plan_layouts = 1: the learning sweeps' own weight-sorted layouts are built with their plan level
-    # (the bench measures steady-state throughput; a run gets them by itself after 2048 sweeps)
+    # (default options: the learning sweeps' own weight-sorted layouts are built with their plan level,
+    # on the device -- what a `dw gibbs` run gets too)
     sampler = dwx.GibbsSampler(graph, device=local_rank, reg_param=reg, seed=20260103,
-                               var_id_offset=rank * V, plan_layouts=1)
+                               var_id_offset=rank * V)
     if rank == 0:
         log("setup: %s V/GPU=%d W=%d tiles=%d colours=%d ghosts=%d device_bytes=%.2f GB (%.1f s)"
             % (wl, V, W, graph.info.num_tiles, graph.info.num_colors, raw.num_ghost_variables,
@@ -581,7 +581,7 @@ def main():
                                                  if halo is not None else "")) if n_gpus > 1 else "single GPU",
                 "stepsize": stepsize, "diminish": decay, "reg_param": reg,
                 "sgd_batches_per_sweep": plan_batches, "min_weight_stepsize": plan_min_step,
-                "plan_layouts": "built with the plan level (dwx_options.plan_layouts = 1: steady state; default: after 2048 sweeps)",
+                "plan_layouts": "default (dwx_options.plan_layouts = 0: the learning sweeps' own weight-sorted layouts are built with their plan level, on the device)",
                 "colours": int(graph.info.num_colors),
                 "ghost_variables_per_gpu": int(len(ghosts)) if ghosts is not None else 0,
             },

@@ -145,10 +145,11 @@ typedef struct dwx_options {
   int32_t plan_layouts;        /* weight-sorted layouts of the LEARNING sweeps' own (cut along a
                                   split plan's mini-batches, or -- un-split -- over whole launches
                                   instead of their query / evidence parts: a few % per sweep for
-                                  0.3 s of host time and a second copy of the records each):
-                                  0 = built once a plan level has run 2048 sweeps (what a run
-                                  that long gets back), 1 = built with the level (steady-state
-                                  throughput: bench.py), 2 = never                         */
+                                  a second copy of the records each):
+                                  0 = default: built with the plan level (the records are sorted on the
+                                  device in milliseconds; a DWX_HOST_BUILD=1 run builds them on the host
+                                  -- 0.3 s per level -- once the level has run 2048 sweeps),
+                                  1 = always with the level, 2 = never                      */
   double reg_param;            /* -b / --reg_param                                     */
   double step_cap;             /* bound on stepsize x R of one SGD mini-batch (see
                                   dwx_sgd_plan); <= 0: never split a sweep; default 1.5

@@ -87,6 +87,8 @@ void dump_marginals_in_text(std::ostream &o, const LoadedGraph &g, bool sample_e
                             const std::vector<uint64_t> &nsamples,
                             uint64_t id_offset = 0, uint64_t n_vars = ~0ull);   // (a shard: local ids + offset, owned only)
 
+// flush and leave the process with exit_code unless DWX_FULL_TEARDOWN is set (dw_cli.cc)
+void quick_exit_if_done(int exit_code);
 // the `dw gibbs` mode (src/dimmwitted.cc:37-95); returns the process exit code
 int gibbs(const CmdLine &args);
 // the same over several GPUs (dw_multi.cc): --gpus N shards, -c N replicas

@@ -912,6 +912,7 @@ int gibbs_multi(const CmdLine &args) {
                                res.nsamples, res.id_offset, res.n_owned);
       }
     }
+    quick_exit_if_done(0);     // (the result files are written: see dw_cli.cc)
     ranks.clear();   // samplers and shard graphs go before the shared replica graph
   } catch (const std::exception &e) {
     std::cerr << "dw: " << e.what() << std::endl;

@@ -129,6 +129,7 @@ struct dwx_sampler {
   std::vector<uint64_t> sgd_work;             // [tiles + 1] prefix sums of SGD-visited records
   uint64_t sgd_work_max_launch = 0;           // ... of the colour launch with the most
   bool wide_learn = false;   // the graph has TILE_TERMS2 tiles: 32-byte staged records when learning
+  bool tv_pair = false;      // every lane tile is pre-signed unary and / or inline arity-2: sweep_kernel<.., TV_PAIR>
   unsigned persistent_blocks[2] = {1, 1};
   bool rec8 = false;                    // the graph streams 8-byte records (CompiledGraph::edges8)
   bool rp_cat = false;                  // ... with every row pointer of a categorical tile prefetched (K = 6 builds)
@@ -341,6 +342,9 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
       case 6: rt::launch(sweep8_kernel<LEARN, 6>, grid, BLOCK_THREADS, lds, s->stream, P); break;
       default: rt::launch(sweep8_kernel<LEARN, 12>, grid, BLOCK_THREADS, lds, s->stream, P); break;
     }
+  } else if (s->tv_pair) {
+    // every tile pre-signed unary and / or inline arity-2 records (config 3b / 5b): the small build
+    rt::launch(sweep_kernel<LEARN, 6, LEARN, TV_PAIR>, grid, BLOCK_THREADS, lds, s->stream, P);
   } else if (LEARN && s->wide_learn) {
     switch (s->stage_k) {
       case 3: rt::launch(sweep_kernel<LEARN, 3, LEARN>, grid, BLOCK_THREADS, lds, s->stream, P); break;
@@ -694,7 +698,10 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
     std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &a, const Piece &b) { return a.at < b.at; });
     for (const Piece &pc : pieces) L->chunks.push_back(pc.ch);
   }
-  if (s->opts.plan_layouts == 1) ensure_level_layout(s, L.get(), batches);
+  // (plan_layouts 0, the default: with the level wherever the records are sorted on the device -- it
+  // costs milliseconds there; a host build pays 0.3 s per level and waits for 2048 sweeps)
+  if (s->opts.plan_layouts == 1 || (s->opts.plan_layouts == 0 && devb::available() && !getenv("DWX_HOST_BUILD")))
+    ensure_level_layout(s, L.get(), batches);
   const uint32_t nc = (uint32_t)L->chunks.size();
   // beyond this the per-chunk tables cost more than they save: such plans keep the
   // per-record atomics and dynamic counts
@@ -1662,7 +1669,22 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       s->persistent_blocks[0] = rt::resident_blocks(infer, BLOCK_THREADS, s->lds_bytes[0]);
       s->persistent_blocks[1] = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_bytes[1]);
     };
-    if (s->wide_learn) {
+    {
+      // the tile classes this graph holds: sweep_kernel's smallest build that contains them
+      uint32_t tv = 0;
+      for (const TileDesc &td : c.tiles) {
+        if (td.flags & TILE_OUTSIDE) continue;
+        if (td.flags & TILE_CATEGORICAL) tv |= TV_CATEGORICAL;
+        if (td.flags & TILE_TERMS3) tv |= TV_TERMS3;
+        else if (td.flags & TILE_TERMS2) tv |= (td.flags & TILE_INLINE2) ? TV_TERMS2_INLINE : TV_TERMS2_VIFS;
+        else if (td.flags & TILE_SIMPLE) tv |= TV_SIMPLE;
+        else tv |= TV_GENERIC;
+      }
+      s->tv_pair = s->wide_learn && s->stage_k == 6 && (tv & TV_TERMS2_INLINE) && !(tv & ~TV_PAIR) && !getenv("DWX_NO_TILE_VARIANTS");
+    }
+    if (s->tv_pair) {
+      prepare(sweep_kernel<false, 6, false, TV_PAIR>, sweep_kernel<true, 6, true, TV_PAIR>);
+    } else if (s->wide_learn) {
       switch (s->stage_k) {
         case 3: prepare(sweep_kernel<false, 3>, sweep_kernel<true, 3, true>); break;
         case 6: prepare(sweep_kernel<false, 6>, sweep_kernel<true, 6, true>); break;

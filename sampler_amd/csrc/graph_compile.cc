@@ -830,18 +830,26 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     // What a multi-GPU driver may assume about the gradient sums (graph_compile.h: grad_shift)
     g.grad_shift = 0; g.grad_unit_max = 0; g.max_records_per_weight = 0;
     if (g.edges8.size() && !g.has_categorical && W > 0) {
-      const uint32_t T = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nth, g.NIdx / 65536 + 1));
+      // (records per weight: a private histogram per thread where that fits -- 10^8 relaxed atomic
+      // increments on one shared table were 0.2 s of config 3's compile -- else the shared table)
+      uint32_t T = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nth, g.NIdx / 65536 + 1));
+      const bool private_hist = (uint64_t)W * 4 * std::min(T, 16u) <= (512ull << 20);
+      if (private_hist) T = std::min(T, 16u);
       std::vector<uint64_t> all_or(T, 0), qmax(T, 0);
-      std::vector<uint32_t> per_w(W, 0);
+      std::vector<std::vector<uint32_t>> hist(private_hist ? T : 1);
+      if (!private_hist) hist[0].assign(W, 0);
       parallel_parts(g.NIdx, T, [&](uint32_t t, uint64_t eb, uint64_t ee) {
         uint64_t o = 0, m = 0;
+        if (private_hist) hist[t].assign(W, 0);
+        uint32_t *per_w = hist[private_hist ? t : 0].data();
         for (uint64_t e = eb; e < ee; ++e) {
           const EdgeRec8 &c = g.edges8[e];
           const double dv = std::fabs((double)sorted_rec_d(c));
           if (dv == 0.0 || (c.key & REC8_FIXED)) continue;
           const uint64_t q = (uint64_t)std::llrint(FIX_SCALE * dv);
           o |= q; m = std::max(m, q);
-          __atomic_fetch_add(&per_w[c.key & REC8_WID_MASK], 1u, __ATOMIC_RELAXED);
+          if (private_hist) ++per_w[c.key & REC8_WID_MASK];
+          else __atomic_fetch_add(&per_w[c.key & REC8_WID_MASK], 1u, __ATOMIC_RELAXED);
         }
         all_or[t] = o; qmax[t] = m;
       }, 0);
@@ -850,7 +858,17 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
       if (o) {
         g.grad_shift = (uint32_t)__builtin_ctzll(o);      // (the lowest set bit of any contribution)
         g.grad_unit_max = m >> g.grad_shift;
-        g.max_records_per_weight = *std::max_element(per_w.begin(), per_w.end());
+        std::vector<uint32_t> wmax(T, 0);
+        parallel_parts(W, T, [&](uint32_t t, uint64_t wb, uint64_t we) {
+          uint32_t mx = 0;
+          for (uint64_t w = wb; w < we; ++w) {
+            uint32_t n = 0;
+            for (const auto &h : hist) if (!h.empty()) n += h[w];
+            mx = std::max(mx, n);
+          }
+          wmax[t] = mx;
+        }, 0);
+        g.max_records_per_weight = *std::max_element(wmax.begin(), wmax.end());
       }
     }
     // Weight-sorted super-tiles over the boolean lane-bin tiles of a compact-record graph.

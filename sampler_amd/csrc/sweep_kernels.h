@@ -196,7 +196,17 @@ DWX_DEV void flush_accumulators(const KernelParams &P, const long long *s_agg, u
 // WIDE (learning only): the graph has TILE_TERMS2 / TILE_TERMS3 tiles; their records are staged as
 // 32-byte LearnRec (the LDS region doubles: 48 KiB per workgroup at K = 6, three workgroups per CU
 // -- measured against two and four: 2.33 / 2.75 / 4.8 ms on config 3b).
-template <bool LEARN, int K, bool WIDE = false>
+// TV: the tile variants this instantiation contains (round 4).  One body with workgroup-uniform
+// branches over EVERY variant was 384 KB of machine code at <LEARN, 6, WIDE> -- the generic
+// factor walk, the arity <= 3 staging through the general sign functions, the vif-pair loads -- and
+// the register allocation of the one path a graph runs paid for all of them (34 VGPRs and 268 SGPRs
+// spilled on config 3b's path, which needs none of those).  The host picks the smallest build that
+// holds the graph's tile classes (dwx_api.cc: tile_variants): TV_PAIR for all-boolean graphs whose tiles
+// are all pre-signed unary and/or inline arity-2 records (config 3b / 5b), TV_ALL otherwise.
+constexpr uint32_t TV_SIMPLE = 1u, TV_TERMS2_INLINE = 2u, TV_TERMS2_VIFS = 4u, TV_TERMS3 = 8u, TV_GENERIC = 16u;
+constexpr uint32_t TV_CATEGORICAL = 32u;      // some lane tile holds categorical variables
+constexpr uint32_t TV_ALL = 63u, TV_PAIR = TV_SIMPLE | TV_TERMS2_INLINE;
+template <bool LEARN, int K, bool WIDE = false, uint32_t TV = TV_ALL>
 // (the learning kernel's LDS footprint admits 2 workgroups per CU at K = 12: give the
 // register allocator the matching budget instead of spilling at the 3-per-CU limit)
 __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEARN ? (K <= 6 ? 3 : 2) : 3)) sweep_kernel(const KernelParams P) {
@@ -248,7 +258,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
       // it and are never read
       // (TILE_TERMS2 staging keeps two vif records and the neighbour values per staged
       // record live: only instantiated for K <= 6; the host clears the flag for K = 12)
-      if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS3)) {
+      if ((TV & TV_TERMS3) && K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS3)) {
         // arity <= 3: the four sign * feature value products of every record (free / evidence
         // chain x proposal 1 / 0) through the general sign functions on batched loads
         LearnRec *s_lrec = (LearnRec *)s_edges;
@@ -265,10 +275,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
           s_lrec[t + k * BLOCK_THREADS] = lr;
         };
         stage_generic_records<K, 4, 2, 0>(P, d, rec, chains, chain, prop, hit, put);
-      } else if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
+      } else if ((TV & (TV_TERMS2_INLINE | TV_TERMS2_VIFS)) && K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
         LearnRec *s_lrec = (LearnRec *)s_edges;
         VifRec va[K], vb[K];
-        if (d.flags & TILE_INLINE2) {   // workgroup-uniform
+        if (!(TV & TV_TERMS2_VIFS) || (d.flags & TILE_INLINE2)) {   // workgroup-uniform
 #pragma unroll
           for (int k = 0; k < K; ++k) decode_inline2(rec[k], d.v0 + edge_owner_lane(rec[k]), va[k], vb[k]);
         } else {
@@ -311,7 +321,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
           }
           s_lrec[t + k * BLOCK_THREADS] = lr;
         }
-      } else if (K <= 6 && !LEARN && (d.flags & TILE_TERMS3)) {
+      } else if ((TV & TV_TERMS3) && K <= 6 && !LEARN && (d.flags & TILE_TERMS3)) {
         // inference, arity <= 3: both proposals' terms of every record, edge-parallel
         EdgeTerms *s_terms = (EdgeTerms *)s_edges;
         const uint32_t *const chains[1] = {P.assign_evid};
@@ -326,7 +336,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
           tt.t0 = wv * term[1];
           s_terms[t + k * BLOCK_THREADS] = tt;
         });
-      } else if (K <= 6 && !LEARN && (d.flags & TILE_TERMS2)) {
+      } else if ((TV & (TV_TERMS2_INLINE | TV_TERMS2_VIFS)) && K <= 6 && !LEARN && (d.flags & TILE_TERMS2)) {
         // inference, boolean tile with pre-signed and arity-2 records: evaluate every
         // record here.  Three batched phases so that a lane's K vif-pair loads, then its K
         // neighbour-assignment gathers, are all in flight together (inside the per-variable
@@ -363,7 +373,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
           }
         } else {
         VifRec va[K], vb[K];
-        if (d.flags & TILE_INLINE2) {   // workgroup-uniform
+        if (!(TV & TV_TERMS2_VIFS) || (d.flags & TILE_INLINE2)) {   // workgroup-uniform
 #pragma unroll
           for (int k = 0; k < K; ++k) decode_inline2(rec[k], d.v0 + edge_owner_lane(rec[k]), va[k], vb[k]);
         } else {
@@ -405,7 +415,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
           s_terms[t + k * BLOCK_THREADS] = tt;
         }
         }
-      } else if (LEARN ? pull : (bool)(d.flags & TILE_SIMPLE)) {
+      } else if ((TV & TV_SIMPLE) && (LEARN ? pull : (bool)(d.flags & TILE_SIMPLE))) {
         // inference, all-unary tile: do the per-record arithmetic here, edge-parallel
         // and straight-line, and stage the two potential terms instead of the record:
         // t1 = w * (sign(hit) * f), t0 = w * (sign(miss) * f), the sign already folded
@@ -455,21 +465,23 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
     issue_tile_loads<LEARN, K>(P, dl, t, f, has_next && chain_pair_tile<LEARN, K, WIDE>(dl));
     // process the current tile out of LDS
     int delta = 0;
-    if (fits && chain_pair_tile<LEARN, K, WIDE>(d)) {
+    if ((TV & (TV_TERMS2_INLINE | TV_TERMS2_VIFS | TV_TERMS3)) && fits && chain_pair_tile<LEARN, K, WIDE>(d)) {
       if (t < 2u * d.nv)
         delta = learn_variable_terms2_pair(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + (t >> 1), pre, A, B,
                                            t & 1u, pull_unary);
     } else if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
-      if (K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS3) && (d.flags & TILE_CATEGORICAL))
+      constexpr uint32_t TV_T23 = TV_TERMS2_INLINE | TV_TERMS2_VIFS | TV_TERMS3;
+      constexpr bool NOCAT = !(TV & TV_CATEGORICAL);
+      if ((TV & TV_TERMS3) && K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS3) && (d.flags & TILE_CATEGORICAL))
         process_variable<LEARN, W_LREC, false>(P, T, d.v0 + t, pre, A, B);
-      else if (K <= 6 && LEARN && WIDE && (d.flags & (TILE_TERMS2 | TILE_TERMS3)))
+      else if ((TV & TV_T23) && K <= 6 && LEARN && WIDE && (d.flags & (TILE_TERMS2 | TILE_TERMS3)))
         delta = learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B, pull_unary);
-      else if (LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
-        delta = process_variable<LEARN, W_TERMS, true>(P, T, d.v0 + t, pre, A, B, true);
-      else if ((d.flags & TILE_SIMPLE) || (K <= 6 && !LEARN && (d.flags & (TILE_TERMS2 | TILE_TERMS3))))
-        delta = process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true>(P, T, d.v0 + t, pre, A, B, false);
-      else
+      else if ((TV & TV_SIMPLE) && LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
+        delta = process_variable<LEARN, W_TERMS, true, false, NOCAT>(P, T, d.v0 + t, pre, A, B, true);
+      else if (((TV & TV_SIMPLE) && (d.flags & TILE_SIMPLE)) || ((TV & TV_T23) && K <= 6 && !LEARN && (d.flags & (TILE_TERMS2 | TILE_TERMS3))))
+        delta = process_variable<LEARN, LEARN ? W_ARRAY : W_TERMS, true, false, NOCAT>(P, T, d.v0 + t, pre, A, B, false);
+      else if (TV & TV_GENERIC)
         process_variable<LEARN, WMODE, false>(P, T, d.v0 + t, pre, A, B);
     }
     if (pull || pull_unary) {

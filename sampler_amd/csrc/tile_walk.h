@@ -935,11 +935,13 @@ DWX_DEV void infer_variable_multi(const KernelParams &P, const TileView &T, uint
 
 // want_delta (learning, TILE_PULL tiles only): instead of scattering gradient atomics,
 // return hit(free) - hit(evid) in {-1,0,+1} for a variable that triggers SGD (0 otherwise).
-template <bool LEARN, int WMODE, bool SIMPLE, bool FIXED = false>
+// NOCAT: the caller's graph has no categorical lane tile (sweep_kernel's TV_PAIR build): every
+// categorical branch -- cat_draw, the noise-aware rows -- compiles out.
+template <bool LEARN, int WMODE, bool SIMPLE, bool FIXED = false, bool NOCAT = false>
 DWX_DEV int process_variable(const KernelParams &P, const TileView &T, uint32_t p,
                              const VarPre pre, double A, double B, const bool want_delta = false) {
   const uint32_t meta = pre.meta;
-  const bool is_cat = meta & VM_CATEGORICAL;
+  const bool is_cat = !NOCAT && (meta & VM_CATEGORICAL);
   const bool is_evid = meta & VM_EVIDENCE;
   const uint32_t card = meta >> VM_CARD_SHIFT;
   const uint32_t row0 = pre.row0;

@@ -279,14 +279,17 @@ def test_config5_whole_graph_on_one_gpu_exact_against_oracle(lib):
     follows the same chunk boundaries.  (run_parity's body with numpy in place of Python lists.)
 
     The full size takes 185 GB of host memory and three minutes (graph + compile + the oracle's
-    copy): DWX_BIG_TESTS=1, run once per round through tools/big_parity.sh with its log under
-    profiles/.  By default HALF of it -- 50 M variables, 5 x 10^8 records: the first size whose
-    record streams pass 4 GB, a split plan -- in 65 s and 94 GB, skipped on a box without the room."""
+    copy): it runs wherever the box has 220 GB to spare (or DWX_BIG_TESTS=1); else HALF of it --
+    50 M variables, 5 x 10^8 records: the first size whose record streams pass 4 GB, a split plan --
+    in 65 s and 94 GB, skipped on a box without the room."""
     from oracle import binding as orc
     from parity import learn_sweep_both
-    V = int(os.environ.get("DWX_BIG_VARS", "100000000" if os.environ.get("DWX_BIG_TESTS") == "1" else "50000000"))
+    # the full 10^9-record graph where the box has the room for it (220 GB: graph + compile + the
+    # oracle's copy take 185), else the half that still passes 4 GB of records
+    have = _host_memory_available_gb()
+    V = int(os.environ.get("DWX_BIG_VARS", "100000000" if (os.environ.get("DWX_BIG_TESTS") == "1" or have >= 220) else "50000000"))
     need = 2.0e-6 * V + 20
-    if _host_memory_available_gb() < need:
+    if have < need:
         pytest.skip("needs %.0f GB of host memory" % need)
     raw = synthetic.cfg3(V, n_weights=1_000_000, seed=1234)
     g = dwx.Graph(raw, lib=lib)
