@@ -87,6 +87,8 @@ void dump_marginals_in_text(std::ostream &o, const LoadedGraph &g, bool sample_e
                             const std::vector<uint64_t> &nsamples,
                             uint64_t id_offset = 0, uint64_t n_vars = ~0ull);   // (a shard: local ids + offset, owned only)
 
+// graph-compile options of a run (dw_cli.cc: the weight order of the variables only for long runs)
+dwx_compile_opts compile_opts_for(const CmdLine &args);
 // flush and leave the process with exit_code unless DWX_FULL_TEARDOWN is set (dw_cli.cc)
 void quick_exit_if_done(int exit_code);
 // the `dw gibbs` mode (src/dimmwitted.cc:37-95); returns the process exit code

@@ -353,8 +353,7 @@ void Rank::setup() {
     sh_.bounds[rank_] = {b, e};
     sh_.ghosts[rank_] = &shard_.ghosts;
     dwx_graph_desc desc = shard_.desc();
-    dwx_compile_opts co;
-    std::memset(&co, 0, sizeof co);
+    dwx_compile_opts co = compile_opts_for(args_);
     co.n_threads = std::max(1u, dwx::host_threads() / (uint32_t)sh_.world);   // the ranks compile side by side
     ok(dwx_graph_create(&desc, &co, &graph_));
     o.seed = args_.seed;                         // one Philox key: counters use global ids
@@ -831,7 +830,8 @@ int gibbs_multi(const CmdLine &args) {
     if (replicas) {
       dwx_graph_desc desc = whole.desc();
       Check ok;
-      ok(dwx_graph_create(&desc, nullptr, &replica_graph));
+      dwx_compile_opts co = compile_opts_for(args);
+      ok(dwx_graph_create(&desc, &co, &replica_graph));
       sh.replica_graph = replica_graph;
     }
     auto print_size = [&](const char *what) {

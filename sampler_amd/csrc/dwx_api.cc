@@ -1059,28 +1059,55 @@ double row_sum_bound(dwx_sampler *s, uint32_t batches) {
       // y = H x, three times: x0 = 1 (y = row sums), then two normalised power steps
       double lam = 0.0, dmax = 0.0;
       if ((uint64_t)(p1 - p0) * 8 >= c.W && p1 - p0 >= 65536) {
-        // a batch that touches a good part of the weight table: variable ranges in
-        // parallel, one private y (and diagonal) per thread, dense passes over the table
-        const uint32_t T = std::min(host_threads(), 16u);
-        std::vector<std::vector<double>> ys(T), ds(T);
+        // a batch that touches a good part of the weight table: variable ranges in parallel on ALL host
+        // threads, ONE shared y (and diagonal) in 64-bit FIXED POINT -- integer atomic adds: the sums
+        // do not depend on the order, lambda is reproducible -- and dense passes over the table.
+        // (Round 4: this was one private f64 vector per thread, hence 16 threads at most and a merge
+        // pass over 16 W doubles per iteration: 6 s of config 5's sampler create at W = 10 M.)
+        const uint32_t T = host_threads();
+        // bound of one term kappa d dot (x <= 1 entrywise: dot <= the variable's sum of deltas) and of
+        // a weight's number of terms, for the scale
+        std::vector<double> umax(T, 0.0), dmx(T, 0.0);
+        std::vector<uint64_t> nrec(T, 0);
+        parallel_parts(p1 - p0, T, [&](uint32_t t, uint64_t b, uint64_t e) {
+          double u = 0.0, dm = 0.0;
+          uint64_t n = 0;
+          for (uint32_t p = p0 + (uint32_t)b; p < p0 + (uint32_t)e; ++p) {
+            const uint32_t m = c.v_meta[p];
+            if (!triggers(m)) continue;
+            const bool cat = (m & VM_CATEGORICAL) != 0;
+            const uint32_t e0 = c.row_ptr[c.v_row[p]], e1 = c.row_ptr[c.v_row[p + 1]];
+            double S = 0.0, dv = 0.0;
+            for (uint32_t k = e0; k < e1; ++k) { const double d = rec_d(k, cat); S += d; dv = std::max(dv, d); }
+            u = std::max(u, (cat ? 0.5 : 0.25) * dv * S);
+            dm = std::max(dm, (cat ? 0.5 : 0.25) * dv * dv);
+            n += e1 - e0;
+          }
+          umax[t] = u; dmx[t] = dm; nrec[t] = n;
+        }, 0);
+        double U = 0.0, D2 = 0.0;
+        uint64_t R = 0;
+        for (uint32_t t = 0; t < T; ++t) { U = std::max(U, umax[t]); D2 = std::max(D2, dmx[t]); R += nrec[t]; }
+        if (U > 0.0 && R > 0) {
+        const double scale = std::ldexp(1.0, 62) / ((double)R * U), dscale = std::ldexp(1.0, 62) / ((double)R * D2);
+        RawArray<long long> yfix(c.W), dfix(c.W);
+        parallel_ranges(c.W, T, [&](uint64_t b, uint64_t e) { for (uint64_t w = b; w < e; ++w) { yfix[w] = 0; dfix[w] = 0; } });
         std::fill(x.begin(), x.end(), 1.0);
         for (int iter = 0; iter < 3; ++iter) {
-          parallel_parts(p1 - p0, T, [&](uint32_t t, uint64_t b, uint64_t e) {
-            std::vector<double> &yt = ys[t], &dt = ds[t];
-            yt.assign(c.W, 0.0);
-            if (iter == 0) dt.assign(c.W, 0.0);
+          parallel_parts(p1 - p0, T, [&](uint32_t, uint64_t b, uint64_t e) {
             for (uint32_t p = p0 + (uint32_t)b; p < p0 + (uint32_t)e; ++p) {
               const uint32_t m = c.v_meta[p];
               if (!triggers(m)) continue;
               const uint32_t e0 = c.row_ptr[c.v_row[p]], e1 = c.row_ptr[c.v_row[p + 1]];
-              const double kappa = (m & VM_CATEGORICAL) ? 0.5 : 0.25;
+              const bool cat = (m & VM_CATEGORICAL) != 0;
+              const double kappa = cat ? 0.5 : 0.25;
               double dot = 0.0;
-              for (uint32_t e = e0; e < e1; ++e) dot += rec_d(e, (m & VM_CATEGORICAL) != 0) * x[c.edges[e].wid];
-              for (uint32_t e = e0; e < e1; ++e) {
-                const double d = rec_d(e, (m & VM_CATEGORICAL) != 0);
+              for (uint32_t k = e0; k < e1; ++k) dot += rec_d(k, cat) * x[c.edges[k].wid];
+              for (uint32_t k = e0; k < e1; ++k) {
+                const double d = rec_d(k, cat);
                 if (d == 0.0) continue;
-                yt[c.edges[e].wid] += kappa * d * dot;
-                if (iter == 0) dt[c.edges[e].wid] += kappa * d * d;
+                __atomic_fetch_add(&yfix[c.edges[k].wid], (long long)std::llrint(scale * (kappa * d * dot)), __ATOMIC_RELAXED);
+                if (iter == 0) __atomic_fetch_add(&dfix[c.edges[k].wid], (long long)std::llrint(dscale * (kappa * d * d)), __ATOMIC_RELAXED);
               }
             }
           }, 0);
@@ -1088,8 +1115,7 @@ double row_sum_bound(dwx_sampler *s, uint32_t batches) {
           parallel_parts(c.W, T, [&](uint32_t t, uint64_t b, uint64_t e) {
             double xy = 0.0, xx = 0.0, yy = 0.0;
             for (uint64_t w = b; w < e; ++w) {
-              double yw = 0.0;
-              for (uint32_t k = 0; k < T; ++k) if (!ys[k].empty()) yw += ys[k][w];
+              const double yw = (double)yfix[w] / scale;
               y[w] = yw;
               xy += x[w] * yw; xx += x[w] * x[w]; yy += yw * yw;
             }
@@ -1099,13 +1125,17 @@ double row_sum_bound(dwx_sampler *s, uint32_t batches) {
           for (uint32_t t = 0; t < T; ++t) { xy += part[3 * t]; xx += part[3 * t + 1]; yy += part[3 * t + 2]; }
           if (xx > 0) lam = std::max(lam, xy / xx);
           const double norm = yy > 0 ? 1.0 / std::sqrt(yy) : 0.0;
-          for (uint64_t w = 0; w < c.W; ++w) { x[w] = y[w] * norm; y[w] = 0.0; }
+          parallel_ranges(c.W, T, [&](uint64_t b, uint64_t e) { for (uint64_t w = b; w < e; ++w) { x[w] = y[w] * norm; y[w] = 0.0; yfix[w] = 0; } });
         }
-        for (uint64_t w = 0; w < c.W; ++w) {
-          double dw = 0.0;
-          for (uint32_t k = 0; k < T; ++k) if (!ds[k].empty()) dw += ds[k][w];
-          dmax = std::max(dmax, dw);
-          x[w] = 0.0;
+        std::vector<double> dpart(T, 0.0);
+        parallel_parts(c.W, T, [&](uint32_t t, uint64_t b, uint64_t e) {
+          long long mx = 0;
+          for (uint64_t w = b; w < e; ++w) { mx = std::max(mx, dfix[w]); x[w] = 0.0; }
+          dpart[t] = (double)mx / dscale;
+        }, 0);
+        for (uint32_t t = 0; t < T; ++t) dmax = std::max(dmax, dpart[t]);
+        } else {
+          std::fill(x.begin(), x.end(), 0.0);
         }
       } else {
       for (int iter = 0; iter < 3; ++iter) {

@@ -4,7 +4,7 @@
 # the all-config timing table, the calibration tools, the kernel resource table.  Everything lands
 # under gpurun_out/; tools/physical_table.py turns the profile directories into physical.json.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$REPO"
 mkdir -p gpurun_out/$TAG
@@ -21,7 +21,11 @@ echo "configs done"
 python bench.py --workload cfg5b --no-cpu-baseline > gpurun_out/$TAG/bench_cfg5b_1gpu.json 2> gpurun_out/$TAG/bench_cfg5b_1gpu.err
 ./tools/sorted_bench > gpurun_out/$TAG/sorted_bench.jsonl 2> gpurun_out/$TAG/sorted_bench.err
 DWX_TIMING=1 python tools/e2e_walltime.py --vars 10000000 --skip-ref > gpurun_out/$TAG/e2e.json 2> gpurun_out/$TAG/e2e.err
-python tools/kernel_resources.py > gpurun_out/$TAG/kernel_resources.txt 2>&1
+# (tools/kernel_resources.py recompiles the library: run it in the build container, not on the GPU box)
 python tools/physical_table.py bench=gpurun_out/prof_$TAG cfg5b=gpurun_out/prof_${TAG}_cfg5b cfg2=gpurun_out/prof_cfg2_$TAG \
   cfg3b=gpurun_out/prof_cfg3b_$TAG cfg4=gpurun_out/prof_cfg4_$TAG > gpurun_out/$TAG/physical.json
+python tools/update_traffic.py cfg3=gpurun_out/prof_$TAG cfg5b=gpurun_out/prof_${TAG}_cfg5b > gpurun_out/$TAG/traffic.json 2> gpurun_out/$TAG/traffic.err
+cp profiles/traffic.json gpurun_out/$TAG/traffic_stamped.json
+python bench.py --no-cpu-baseline > gpurun_out/$TAG/bench_with_traffic.json 2> gpurun_out/$TAG/bench_with_traffic.err
+python tools/physical_table.py --check-bench gpurun_out/$TAG/bench_with_traffic.json > gpurun_out/$TAG/check_bench.json 2>&1
 echo "all done"

@@ -84,13 +84,66 @@ __global__ void __launch_bounds__(THREADS) sorted_kernel(const u32x2 *__restrict
   if (sink == 0x1234567) out[0] = 7;
 }
 
+// --rec6 (round 4): the same loop over 6-BYTE records {weight id: 24 bits, owner slot: 14,
+// index of d: 10} -- a quarter less of the stream.  A lane takes two consecutive records per 12-byte
+// load (buffer_load_dwordx3), K / 2 loads in flight; everything else as sorted_kernel.
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) sorted6_kernel(const uint32_t *__restrict__ recs, const float *__restrict__ w32,
+                                                          uint32_t nv, uint32_t n_super, uint32_t *__restrict__ out) {
+  extern __shared__ unsigned long long acc[];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = nv * PER_VAR;                 // records per super-tile (even)
+  constexpr int L = K / 2;                           // 12-byte loads per lane and step
+  for (uint32_t st = blockIdx.x; st < n_super; st += gridDim.x) {
+    for (uint32_t i = t; i < nv; i += THREADS) acc[i] = 0;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((const char *)recs + (size_t)st * per * 6u), 0, (int)(per * 6u), 0x00020000);
+    u32x3 rec[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) rec[k] = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(t * 12u), (int)(k * THREADS * 12), 2);
+    const uint32_t steps = (per + K * THREADS - 1) / (K * THREADS);
+    for (uint32_t it = 0; it < steps; ++it) {
+      float w[K];
+      uint32_t own[K];
+#pragma unroll
+      for (int k = 0; k < L; ++k) {
+        const u32x3 v = rec[k];
+        const uint32_t b_lo = (v.y >> 16) | (v.z << 16);
+        w[2 * k] = w32[v.x & 0xFFFFFFu];
+        w[2 * k + 1] = w32[b_lo & 0xFFFFFFu];
+        own[2 * k] = (v.x >> 24) | ((v.y & 0x3Fu) << 8);
+        own[2 * k + 1] = (b_lo >> 24) | (((v.z >> 16) & 0x3Fu) << 8);
+      }
+      const uint32_t nxt = (it + 1) * (K * THREADS * 6u);
+#pragma unroll
+      for (int k = 0; k < L; ++k) rec[k] = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(t * 12u), (int)(nxt + k * THREADS * 12), 2);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const long long q = fix32((double)w[k] * 2.0);
+        atomicAdd(&acc[own[k] < nv ? own[k] : 0], (unsigned long long)q);
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < nv; i += THREADS) {
+      const double x = (double)(long long)acc[i] * (1.0 / 4294967296.0);
+      const float q = 0.37f * (1.0f + __expf((float)-x));
+      out[(size_t)st * nv + i] = q < 1.0f ? 1u : 0u;
+    }
+    __syncthreads();
+  }
+}
+
 struct Cfg { uint32_t nv; int threads, wg_per_cu; bool sorted, atomics; };
 
 int main(int argc, char **argv) {
   uint64_t nrec = 100ull * 1000 * 1000;
   uint32_t W = 1u << 20;
   bool ceiling_only = false;    // one line: the product kernel's shape (16 384 variables, 1024 threads, 1 per CU)
+  bool rec6 = false;            // the product's shape over 8-byte and over 6-byte records, side by side
   for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--rec6")) rec6 = true;
     if (!strcmp(argv[i], "--ceiling")) { ceiling_only = true; nrec = 42ull * 1000 * 1000; }
     if (i + 1 < argc && !strcmp(argv[i], "--records")) nrec = strtoull(argv[i + 1], nullptr, 10);
     if (i + 1 < argc && !strcmp(argv[i], "--weights")) W = (uint32_t)strtoul(argv[i + 1], nullptr, 10);
@@ -119,7 +172,7 @@ int main(int argc, char **argv) {
   };
   std::vector<u32x2> h(nrec);
   for (const Cfg &c : cfgs) {
-    if (ceiling_only && !(c.nv == 16384 && c.threads == 1024 && c.sorted && c.atomics)) continue;
+    if ((ceiling_only || rec6) && !(c.nv == 16384 && c.threads == 1024 && c.sorted && c.atomics)) continue;
     const uint32_t per = c.nv * PER_VAR;
     const uint32_t n_super = (uint32_t)(nrec / per);
     // super-tile contents: random weight ids (sorted or not), owners = a random permutation of the
@@ -166,6 +219,38 @@ int main(int argc, char **argv) {
              n / (best * 1e-3), n * 8 / (best * 1e-3) / 1e9);
       fflush(stdout);
     };
+    if (rec6) {
+      // the same super-tiles as 6-byte records (d index 1), two per 12 bytes
+      std::vector<uint8_t> h6((size_t)n_super * per * 6 + 16);
+      for (size_t i = 0; i < (size_t)n_super * per; ++i) {
+        const uint64_t v = (uint64_t)(h[i].x & 0xFFFFFFu) | ((uint64_t)(h[i].y & 0x3FFFu) << 24) | (1ull << 38);
+        memcpy(h6.data() + i * 6, &v, 6);
+      }
+      uint32_t *recs6 = nullptr;
+      CK(hipMalloc(&recs6, h6.size()));
+      CK(hipMemcpy(recs6, h6.data(), h6.size(), hipMemcpyHostToDevice));
+      launch(sorted_kernel<1024, true>);
+      auto kern = sorted6_kernel<1024>;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipEvent_t a, b;
+      CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+      float best = 1e30f;
+      for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL(kern, dim3(cus), dim3(1024), lds, 0, (const uint32_t *)recs6, w32, c.nv, n_super, out);
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, a, b));
+        if (rep) best = std::min(best, ms);
+      }
+      CK(hipGetLastError());
+      const double n = (double)n_super * per;
+      printf("{\"nv\": %u, \"threads\": 1024, \"wg_per_cu\": 1, \"record_bytes\": 6, \"records\": %.0f, \"ms\": %.4f, "
+             "\"records_per_s\": %.4g, \"stream_GBps\": %.1f}\n", c.nv, n, best, n / (best * 1e-3), n * 6 / (best * 1e-3) / 1e9);
+      CK(hipFree(recs6));
+      continue;
+    }
     if (c.threads == 256) { if (c.atomics) launch(sorted_kernel<256, true>); else launch(sorted_kernel<256, false>); }
     if (c.threads == 512) { if (c.atomics) launch(sorted_kernel<512, true>); else launch(sorted_kernel<512, false>); }
     if (c.threads == 1024) { if (c.atomics) launch(sorted_kernel<1024, true>); else launch(sorted_kernel<1024, false>); }
