@@ -105,6 +105,10 @@ typedef struct dwx_compile_opts {
                                   (always in the product; DWX_HOST_BUILD=1 in the environment keeps the host
                                   builder): the weight-sorted copy is only PLANNED here and every sampler
                                   builds its records on its own device (device_build.hip)               */
+  uint32_t no_narrow_info;     /* 1: do not scan the records for dwx_graph_info.grad_shift / grad_unit_max /
+                                  max_records_per_weight (they read 0: "nothing is known, send int64") -- a
+                                  pass over every record with a histogram per weight that only multi-GPU
+                                  drivers need; `dw gibbs` on one GPU sets it (2 s at config 5's size)      */
 } dwx_compile_opts;
 
 typedef struct dwx_graph_info {

@@ -7,6 +7,8 @@
 
 #include <stdint.h>
 
+#include <vector>
+
 #include "device_types.h"
 
 namespace dwx {
@@ -31,6 +33,44 @@ void build_static_tables(const TileDesc *d_tiles, uint32_t n_tiles, const uint32
                          const uint32_t *d_v_row, const uint32_t *d_row_ptr, const EdgeRec *d_edges, const double *d_fval64,
                          const uint8_t *d_w_fixed, uint32_t W, uint32_t n_groups, bool learn_non_evidence, bool noise_aware,
                          long long *d_table, long long *t_max, long long *h_max, void *stream);
+
+// A plan level's pull-gradient structures (build_level (b) of dwx_api.cc), built on the device: the
+// incidence list of every (SGD-triggering boolean variable, non-fixed record with a non-zero delta)
+// pair of the pull tiles, sorted by (group, weight), and -- graphs with >= block_pull_min_w weights and
+// few distinct deltas -- per group the block-pull table (rows of BP_ROW x depth entries per (variable
+// block, weight)), with what did not fit a row left on the list.  Bit for bit the host builder's
+// structures.  h_tile_info[tile] = group | mode << 30 (1: all records, 2: pre-signed ones only),
+// 0xFFFFFFFF: none.  The device buffers of the result belong to the caller (hipFree / rt::dfree).
+struct Incidence {
+  uint64_t n_entries = 0;
+  std::vector<uint32_t> inc_begin, inc_end;      // per group: its part of the list columns (multiples of PULL_RUN)
+  uint32_t *d_inc_wid = nullptr, *d_inc_slot = nullptr;
+  float *d_inc_d = nullptr;
+  struct BlockTable {
+    U32x4 *d_ell = nullptr;
+    std::vector<uint32_t> tile0;
+    uint32_t blocks = 0, depth = 0;
+    uint64_t total = 0, on_list = 0;             // the group's entries; those left on the list
+  };
+  std::vector<BlockTable> bp;                    // [groups], or empty: no block pull
+  std::vector<uint32_t> dvals;                   // ascending f32 bit patterns of the distinct deltas
+  uint64_t max_blocks = 0, wp = 0;
+};
+void build_incidence(const TileDesc *d_tiles, const TileDesc *h_tiles, uint32_t n_tiles, const uint32_t *h_tile_info,
+                     const uint32_t *d_v_meta, const uint32_t *d_v_row, const uint32_t *d_row_ptr, const EdgeRec *d_edges,
+                     bool learn_non_evidence, bool noise_aware, uint32_t W, uint32_t n_groups, uint64_t block_pull_min_w,
+                     uint32_t bp_tiles, Incidence &out, void *stream);
+
+// max(power-iteration estimate, largest diagonal entry) of the curvature bound of the mini-batch of
+// variables [p0, p1) (row_sum_bound's dense branch in dwx_api.cc, WITHOUT its 1.1 safety factor): the
+// host's arithmetic term for term, 64-bit fixed-point sums.  `sc`: scratch vectors kept between calls.
+struct CurvatureScratch {
+  void *x = nullptr, *y = nullptr, *yfix = nullptr, *dfix = nullptr, *part = nullptr, *small = nullptr;
+  ~CurvatureScratch();
+};
+double batch_curvature(uint32_t p0, uint32_t p1, const uint32_t *d_v_meta, const uint32_t *d_v_row, const uint32_t *d_row_ptr,
+                       const EdgeRec *d_edges, const double *d_fval64, bool learn_non_evidence, bool noise_aware, uint32_t W,
+                       CurvatureScratch &sc, void *stream);
 
 }  // namespace devb
 }  // namespace dwx

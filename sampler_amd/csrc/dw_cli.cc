@@ -799,6 +799,8 @@ dwx_compile_opts compile_opts_for(const CmdLine &args) {
   bool order = args.n_learning_epoch + args.n_inference_epoch >= 20000;
   if (const char *e = getenv("DWX_DW_WEIGHT_ORDER")) order = atoi(e) != 0;
   co.no_weight_order = order ? 0u : 1u;
+  // (what the gradient all-reduce may assume about the sums: only runs over several GPUs ask)
+  co.no_narrow_info = (args.gpus >= 2 || args.n_datacopy > 1) ? 0u : 1u;
   return co;
 }
 

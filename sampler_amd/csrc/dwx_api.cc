@@ -788,6 +788,54 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
     rt::stream_sync(s->stream);      // (ts dies with this scope)
     }
     // (b) incidence list
+    if (tables_on_device) {
+      // on the device (device_build.hip): ordered emit per tile, one stable radix sort by (chunk, weight),
+      // the block tables filled by a lane per weight -- the structures below, bit for bit
+      uint64_t min_w = 131072, bp_tiles = BP_TILES;
+      if (const char *e = getenv("DWX_BLOCK_PULL_MIN_W")) min_w = (uint64_t)std::max(0L, atol(e));          // test hooks
+      if (const char *e = getenv("DWX_BLOCK_PULL_TILES")) bp_tiles = (uint64_t)std::min<long>(BP_TILES, std::max(1L, atol(e)));
+      std::vector<uint32_t> tile_info(c.tiles.size(), 0xFFFFFFFFu);
+      for (size_t ti = 0; ti < c.tiles.size(); ++ti) {
+        const TileDesc &td = c.tiles[ti];
+        const bool unary_only = !(td.flags & TILE_PULL) && (td.flags & TILE_PULL_UNARY) && c.ecap <= 6 * BLOCK_THREADS;
+        if ((!(td.flags & TILE_PULL) && !unary_only) || (td.flags & TILE_OUTSIDE)) continue;
+        tile_info[ti] = chunk_of[ti] | ((unary_only ? 2u : 1u) << 30);
+      }
+      devb::Incidence inc;
+      devb::build_incidence(s->d_tiles, c.tiles.data(), (uint32_t)c.tiles.size(), tile_info.data(), s->d_v_meta, s->d_v_row,
+                            s->d_row_ptr, s->d_edges, o.learn_non_evidence != 0, o.noise_aware != 0, (uint32_t)c.W, nc, min_w,
+                            (uint32_t)bp_tiles, inc, (void *)s->stream);
+      L->d_inc_wid = inc.d_inc_wid; L->d_inc_slot = inc.d_inc_slot; L->d_inc_d = inc.d_inc_d;
+      L->inc_begin = inc.inc_begin; L->inc_end = inc.inc_end;
+      if (!inc.bp.empty()) {
+        const bool bp_timing = getenv("DWX_TIMING") != nullptr;
+        L->bp.resize(nc);
+        for (uint32_t k = 0; k < nc; ++k) {
+          if (!inc.bp[k].blocks) continue;
+          dwx_sampler::Level::BlockTable &bt = L->bp[k];
+          bt.d_ell = inc.bp[k].d_ell;
+          bt.d_tile0 = upload(inc.bp[k].tile0, s->stream);
+          bt.blocks = inc.bp[k].blocks; bt.depth = inc.bp[k].depth;
+          bt.parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(rt::cu_count() / bt.blocks, inc.wp / BP_THREADS));
+          if (bp_timing)
+            fprintf(stderr, "[dwx block pull] group %u: %u blocks x depth %u, %zu deltas, %llu of %llu entries on the list (device build)\n",
+                    k, bt.blocks, bt.depth, inc.dvals.size(), (unsigned long long)inc.bp[k].on_list, (unsigned long long)inc.bp[k].total);
+        }
+        std::vector<long long> qtab(inc.dvals.size());
+        for (size_t i = 0; i < inc.dvals.size(); ++i) {
+          float d; std::memcpy(&d, &inc.dvals[i], 4);
+          qtab[i] = std::llrint(FIX_SCALE * (double)d);
+        }
+        L->d_bp_qtab = upload(qtab, s->stream);
+        L->d_bp_partial = (long long *)rt::dmalloc(inc.max_blocks * inc.wp * 8);
+        L->bp_deltas = (uint32_t)inc.dvals.size(); L->bp_wp = (uint32_t)inc.wp;
+        rt::allow_dynamic_lds(pull_ell_kernel<1, false>, BP_LDS_BYTES);
+        rt::allow_dynamic_lds(pull_ell_kernel<2, false>, BP_LDS_BYTES);
+        rt::allow_dynamic_lds(pull_ell_kernel<1, true>, BP_LDS_BYTES);
+        rt::allow_dynamic_lds(pull_ell_kernel<2, true>, BP_LDS_BYTES);
+      }
+      rt::stream_sync(s->stream);
+    } else {
     struct Inc { uint32_t wid, slot; float d; uint32_t chunk; };
     RawArray<Inc> by_w, by_c;
     std::vector<uint64_t> w_start, c_start;
@@ -1019,6 +1067,7 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
       L->d_inc_d = upload_raw(id.data(), padded, s->stream);
       rt::stream_sync(s->stream);   // the columns die with this scope
     }
+    }
     rt::stream_sync(s->stream);
   }
   dwx_sampler::Level *out = L.get();
@@ -1042,6 +1091,7 @@ double row_sum_bound(dwx_sampler *s, uint32_t batches) {
   if (it != s->row_sum_cache.end()) return it->second;
   const CompiledGraph &c = *s->cg;
   std::vector<double> x(c.W, 0.0), y(c.W, 0.0), diag(c.W, 0.0);
+  devb::CurvatureScratch dev_sc;      // (device vectors of the batches estimated on the device, kept over the chunks)
   std::vector<uint8_t> seen(c.W, 0);
   std::vector<uint32_t> touched;
   double lam_max = 0.0;
@@ -1058,7 +1108,14 @@ double row_sum_bound(dwx_sampler *s, uint32_t batches) {
       const uint32_t p0 = c.tile_v[ta], p1 = c.tile_v[tb];
       // y = H x, three times: x0 = 1 (y = row sums), then two normalised power steps
       double lam = 0.0, dmax = 0.0;
-      if ((uint64_t)(p1 - p0) * 8 >= c.W && p1 - p0 >= 65536) {
+      if ((uint64_t)(p1 - p0) * 8 >= c.W && p1 - p0 >= 65536 && devb::available() && !getenv("DWX_HOST_BUILD")) {
+        // ... on the device: the arithmetic of the branch below, term for term (device_build.hip)
+        rt::set_device(s->device);
+        const double v = devb::batch_curvature(p0, p1, s->d_v_meta, s->d_v_row, s->d_row_ptr, s->d_edges, s->d_edge_fval64,
+                                               s->opts.learn_non_evidence != 0, s->opts.noise_aware != 0, (uint32_t)c.W, dev_sc,
+                                               (void *)s->stream);
+        lam = v; dmax = 0.0;
+      } else if ((uint64_t)(p1 - p0) * 8 >= c.W && p1 - p0 >= 65536) {
         // a batch that touches a good part of the weight table: variable ranges in parallel on ALL host
         // threads, ONE shared y (and diagonal) in 64-bit FIXED POINT -- integer atomic adds: the sums
         // do not depend on the order, lambda is reproducible -- and dense passes over the table.

@@ -829,7 +829,7 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     }
     // What a multi-GPU driver may assume about the gradient sums (graph_compile.h: grad_shift)
     g.grad_shift = 0; g.grad_unit_max = 0; g.max_records_per_weight = 0;
-    if (g.edges8.size() && !g.has_categorical && W > 0) {
+    if (g.edges8.size() && !g.has_categorical && W > 0 && !o.no_narrow_info) {
       // (records per weight: a private histogram per thread where that fits -- 10^8 relaxed atomic
       // increments on one shared table were 0.2 s of config 3's compile -- else the shared table)
       uint32_t T = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nth, g.NIdx / 65536 + 1));

@@ -48,7 +48,8 @@ class CompileOpts(C.Structure):
                 ("no_compact_records", C.c_uint32), ("no_weight_order", C.c_uint32),
                 ("wide_min_records", C.c_uint32), ("no_record_vifs", C.c_uint32),
                 ("no_pull_unary", C.c_uint32), ("no_sorted_records", C.c_uint32),
-                ("super_tiles", C.c_uint32), ("sorted_slots", C.c_uint32), ("defer_sorted_records", C.c_uint32)]
+                ("super_tiles", C.c_uint32), ("sorted_slots", C.c_uint32), ("defer_sorted_records", C.c_uint32),
+                ("no_narrow_info", C.c_uint32)]
 
 
 class GraphInfo(C.Structure):

@@ -16,5 +16,14 @@ void build_static_tables(const TileDesc *, uint32_t, const uint32_t *, const uin
                          long long *, long long *, void *) {
   throw std::runtime_error("device build is not available in the host harness");
 }
+void build_incidence(const TileDesc *, const TileDesc *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *,
+                     const uint32_t *, const EdgeRec *, bool, bool, uint32_t, uint32_t, uint64_t, uint32_t, Incidence &, void *) {
+  throw std::runtime_error("device build is not available in the host harness");
+}
+CurvatureScratch::~CurvatureScratch() {}
+double batch_curvature(uint32_t, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, const EdgeRec *, const double *,
+                       bool, bool, uint32_t, CurvatureScratch &, void *) {
+  throw std::runtime_error("device build is not available in the host harness");
+}
 }  // namespace devb
 }  // namespace dwx

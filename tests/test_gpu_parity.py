@@ -106,16 +106,16 @@ def test_device_built_static_tables_equal_the_host_builder(lib, monkeypatch):
     un-split and split levels."""
     rng = np.random.default_rng(9)
     graphs = []
-    raw = synthetic.cfg3(120_000, n_weights=9000, seed=21)
+    raw = synthetic.cfg3(300_000, n_weights=9000, seed=21)
     raw.fac_feature_value[:] = rng.choice([1.0, 0.5, 2.0, -1.0, 0.3], size=raw.num_factors)   # (0.3: not f32-exact -> f64 side array)
     raw.w_is_fixed[:] = rng.random(raw.num_weights) < 0.1
     graphs.append(raw)
     graphs.append(synthetic.cfg3b(60_000, n_weights=5000, seed=5))
     graphs.append(synthetic.cfg3c(30_000, n_weights=3000, seed=6))
-    graphs.append(synthetic.cfg4(40_000, card=8, seed=7, learn=True))
+    graphs.append(synthetic.cfg4(150_000, card=8, seed=7, learn=True))
     graphs.append(synthetic.cfg4b(20_000, card=8, n_weights=2000, seed=8))
     for gi, raw in enumerate(graphs):
-        got = {}
+        got, lam = {}, {}
         for mode in ("device", "host"):
             if mode == "host":
                 monkeypatch.setenv("DWX_HOST_BUILD", "1")
@@ -126,12 +126,59 @@ def test_device_built_static_tables_equal_the_host_builder(lib, monkeypatch):
             b, n_chunks, min_step = s.sgd_plan(0.01, 4)
             t4 = s.read_buffer(dwx.BUF_TSTATIC_PLAN, np.int64)
             got[mode] = (t1, t4, np.array([min_step1, min_step, n_chunks], np.float64))
+            # the curvature estimates (three power steps per mini-batch, 64-bit fixed-point sums on both sides:
+            # the same integers; the closing dot products are added up in another order)
+            lam[mode] = [s.sgd_curvature(bb) for bb in (1, 2, 4)]
             s.close()
             if mode == "host":
                 monkeypatch.delenv("DWX_HOST_BUILD")
         assert len(got["device"][0]) == 2 * raw.num_weights and np.abs(got["device"][0]).max() > 0
         for k, what in enumerate(("un-split tables", "split tables", "smallest steps")):
             assert np.array_equal(got["device"][k], got["host"][k]), (gi, what)
+        np.testing.assert_allclose(lam["device"], lam["host"], rtol=1e-9, err_msg="curvature estimates, graph %d" % gi)
+        assert min(lam["device"]) > 0
+
+
+@pytest.mark.parametrize("block_pull", [False, True])
+def test_device_built_incidence_lists_and_block_tables_equal_the_host_builder(lib, monkeypatch, block_pull):
+    """The pull gradient's structures of a plan level -- the incidence list sorted by (chunk, weight), the
+    block-pull tables with their overflow lists -- built on the device (device_build.hip: ordered emit,
+    one radix sort, a lane per weight filling the rows) against the host builder (DWX_HOST_BUILD=1):
+    integer gradient sums, so the learned weights and both chains must be bit for bit the same after
+    un-split and split learning sweeps, and both must equal the oracle.  Several feature values and sign
+    classes, fixed weights, unary records of mixed tiles (config 3b), block tables forced at this size."""
+    if block_pull:
+        monkeypatch.setenv("DWX_BLOCK_PULL_MIN_W", "0")
+        monkeypatch.setenv("DWX_BLOCK_PULL_TILES", "64")      # (several variable blocks at this size)
+    rng = np.random.default_rng(11)
+    raw = synthetic.cfg3(200_000, n_weights=6000, seed=21)
+    raw.fac_feature_value[:] = rng.choice([1.0, 0.5, 2.0, -1.0, 0.25], size=raw.num_factors)
+    raw.edge_equal_to[:] = rng.integers(0, 2, size=raw.num_edges)
+    raw.w_is_fixed[:] = rng.random(raw.num_weights) < 0.1
+    for gi, (g_raw, forced) in enumerate(((raw, 1), (raw, 4), (synthetic.cfg3b(80_000, n_weights=5000, seed=5), 2))):
+        got = {}
+        for mode in ("device", "host"):
+            if mode == "host":
+                monkeypatch.setenv("DWX_HOST_BUILD", "1")
+            g = dwx.Graph(g_raw, lib=lib)
+            s = dwx.GibbsSampler(g, seed=3)
+            for k in range(3):
+                batches, n_chunks, _ = s.sgd_plan(0.01, forced)
+                for c in range(n_chunks):
+                    s.sgd_accumulate(c)
+                    if batches > 1 or c + 1 == n_chunks:
+                        s.sgd_apply()
+                s.sgd_finish()
+            s.sample(); s.wait()
+            got[mode] = (s.weights.copy(), s.assignments("free").copy(), s.assignments("evid").copy())
+            s.close()
+            if mode == "host":
+                monkeypatch.delenv("DWX_HOST_BUILD")
+        assert np.abs(got["device"][0]).max() > 0
+        for k, what in enumerate(("weights", "free chain", "evidence chain")):
+            assert np.array_equal(got["device"][k], got["host"][k]), (gi, forced, what)
+    # ... and against the oracle (the device build is the default: every other parity test runs on it too)
+    run_parity(lib, raw, n_learn=3, n_infer=1, stepsize=0.01, check_index=False)
 
 
 def test_split_learning_sweep_as_one_persistent_launch(lib, monkeypatch):
