@@ -389,7 +389,10 @@ int dwx_stream(dwx_sampler *s, void **stream);
  * launches = sweeps = the split learning sweeps that ran as ONE persistent launch (DWX_PERSIST=1 in the
  * environment at dwx_sampler_create; all-unary graphs with at most 128 weights, >= 8 mini-batches:
  * chunk loop, grid barrier and update inside the kernel; off by default -- measured, it is slower
- * than the launches it replaces: sampler_amd/csrc/persist_kernels.h). */
+ * than the launches it replaces: sampler_amd/csrc/persist_kernels.h); 5 = no time: launches = sweeps =
+ * the split learning sweeps that ran with ONE launch per mini-batch -- the update of a mini-batch as the
+ * prologue of the next one's sweep kernel (all-unary graphs with at most 1024 weights and no
+ * degree-binned variable; the default for them, DWX_NO_MERGED_APPLY=1 at dwx_sampler_create disables it). */
 int dwx_kernel_time(dwx_sampler *s, int kind, double *ms, uint64_t *launches, uint64_t *sweeps);
 int dwx_kernel_time_reset(dwx_sampler *s, int enable);
 

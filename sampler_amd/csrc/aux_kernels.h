@@ -304,15 +304,25 @@ DWX_DEV void apply_one(double *weights, float *w32, const uint8_t *w_fixed, cons
   weights[i] = x;
   w32[i] = (float)x;
 }
+// w_in (the last update of a sweep whose mini-batches ran as merged launches, persist_kernels.h): the
+// weights before this update live in another buffer -- every weight is written, touched or not;
+// also_zero: a second gradient buffer to clear (the one the last merged launch read).
 __global__ void __launch_bounds__(BLOCK_THREADS)
 apply_kernel(double *weights, float *w32, const uint8_t *w_fixed, long long *grad,
              const long long *t_static, const long long *t_hess, uint32_t W, double stepsize,
-             double reg_param, int l2) {
+             double reg_param, int l2, const double *w_in = nullptr, long long *also_zero = nullptr) {
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W; i += stride) {
     const long long G = grad[i], Td = grad[W + i];
     if (G != 0 || Td != 0) { grad[i] = 0; grad[W + i] = 0; }
-    apply_one(weights, w32, w_fixed, t_static, t_hess, i, G, Td, stepsize, reg_param, l2);
+    if (also_zero) { also_zero[i] = 0; also_zero[W + i] = 0; }
+    if (w_in) {
+      const double x = apply_value(w_in[i], w_fixed[i] != 0, t_static, t_hess, i, G, Td, stepsize, reg_param, l2);
+      weights[i] = x;
+      w32[i] = (float)x;
+    } else {
+      apply_one(weights, w32, w_fixed, t_static, t_hess, i, G, Td, stepsize, reg_param, l2);
+    }
   }
 }
 

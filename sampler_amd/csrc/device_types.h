@@ -73,9 +73,9 @@ constexpr uint32_t REC8_FIXED = 1u << 27, REC8_HIT_SHIFT = 28, REC8_MISS_SHIFT =
 // -- neighbouring lanes of the record stream then gather neighbouring weights: a fraction of an
 // L2 request per record instead of one.  A record adds w * d to its owner's potential
 // difference pp - pn, d = (sign(hit) - sign(miss)) * f, summed in fixed point in LDS (pot_fix).
-//   wid: the weight id;  od: bits 0-12 the owner's slot in the super-tile (variable position -
-//   SuperTile::v0), bits 13-31 the index of d in the table of distinct values (entry 0 is 0.0:
-//   the zero-filled lanes past a super-tile's end add nothing).
+//   wid: the weight id;  od: bits 0-13 (SORT_OWNER_BITS) the owner's slot in the super-tile (variable
+//   position - SuperTile::v0), bits 14-31 the index of d in the table of distinct values (entry 0 is
+//   0.0: the zero-filled lanes past a super-tile's end add nothing).
 struct alignas(8) SortRec8 {
   uint32_t wid, od;
 };
@@ -84,9 +84,9 @@ static_assert(sizeof(SortRec8) == 8, "SortRec8 must be 8 bytes");
 #define DWX_SORT_OWNER_BITS 14
 #endif
 constexpr uint32_t SORT_OWNER_BITS = DWX_SORT_OWNER_BITS, SORT_OWNER_MASK = (1u << SORT_OWNER_BITS) - 1;
-constexpr uint32_t SUPER_NV_MAX = 1u << SORT_OWNER_BITS;      // 8192 variables: 64 KiB of sums
-constexpr uint32_t SUPER_TILES_DEFAULT = SUPER_NV_MAX / 256;  // 32 full tiles
-constexpr uint32_t SORT_WG_PER_CU = SORT_OWNER_BITS <= 13 ? 2 : 1;   // (16 384 variables: 128 KiB, the CU's LDS)
+constexpr uint32_t SUPER_NV_MAX = 1u << SORT_OWNER_BITS;      // 16 384 variables: 128 KiB of fixed-point sums
+constexpr uint32_t SUPER_TILES_DEFAULT = SUPER_NV_MAX / 256;  // 64 full tiles
+constexpr uint32_t SORT_WG_PER_CU = SORT_OWNER_BITS <= 13 ? 2 : 1;   // (14 bits: the CU's whole LDS, one 1024-thread workgroup per CU)
 constexpr uint32_t SORT_TV_SLOTS = 2 * SUPER_TILES_DEFAULT;   // tile starts of a super-tile in LDS (+ end), padded
 #ifndef DWX_SORT_THREADS
 #define DWX_SORT_THREADS 1024
@@ -286,6 +286,22 @@ struct PersistArgs {
   uint32_t lds_red_off;          // ... reduction scratch of the in-launch update (BLOCK_THREADS x 8 bytes) + flag
 };
 constexpr uint32_t PERSIST_MIN_CHUNKS = 8;     // fewer mini-batches: plain launches (nothing to win)
+
+// A mini-batch of a split learning sweep of a few-weights graph as ONE launch (sweep8_merged_kernel,
+// persist_kernels.h): the previous mini-batch's update runs as the kernel's prologue, by every
+// workgroup for itself, into an LDS copy of the f32 weights.
+struct MergeArgs {
+  const long long *prev_grad;    // [2W] gradient sums / counts of the previous mini-batch, or null (the sweep's first)
+  long long *zero;               // [2W] the buffer the NEXT mini-batch accumulates into: zeroed by workgroup 0, or null
+  const double *w_src;           // [W] weights before the previous mini-batch's update
+  double *w_dst;                 // [W] ... and after it (written by workgroup 0; null with prev_grad == null)
+  float *w32_dst;
+  const uint8_t *w_fixed;
+  const long long *t_static;     // [T[W] | h[W]] of the previous mini-batch, or null
+  double stepsize, reg_param;
+  int32_t l2;
+  uint32_t lds_lw32_off;         // dynamic LDS: the f32 weights [W]
+};
 
 }  // namespace dwx
 #endif

@@ -150,6 +150,7 @@ struct dwx_sampler {
   size_t lds_sorted = 0;
   bool sorted_learn = false;            // ... also in learning sweeps (the super-tiles' tiles pull their gradient)
   bool no_sort_uni = false;             // DWX_NO_SORT_UNI: never the single-d build of sorted_sweep_kernel (A/B)
+  bool sorted_fallback_said = false;    // the "more than 8 runs: tile sweep instead" note was printed
   double *d_row_truth = nullptr, *d_edge_fval64 = nullptr;
   EdgeRec *d_edges = nullptr;
   VifRec *d_vifs = nullptr;
@@ -225,6 +226,15 @@ struct dwx_sampler {
   uint32_t persist_w64_off = 0, persist_red_off = 0;
   bool persist_check_pending = false;
   uint64_t persist_launches = 0;
+  // ... and with one launch per mini-batch (sweep8_merged_kernel: the update as the next sweep kernel's
+  // prologue): three gradient buffers ([0] = d_grad) and two weight buffers in turn
+  bool merge_ok = false;
+  long long *d_gbuf[3] = {nullptr, nullptr, nullptr};
+  double *d_wbuf64[2] = {nullptr, nullptr};
+  float *d_wbuf32[2] = {nullptr, nullptr};
+  size_t lds_merge = 0;
+  uint32_t merge_lw32_off = 0;
+  uint64_t merged_sweeps = 0;
   int *d_grad32 = nullptr;              // dwx_grad_pack32_async: the gradient sums as 32-bit counts
   uint32_t *d_pack_bad = nullptr;       // ... and its "not a multiple / does not fit" counter
   bool pack_check_pending = false;
@@ -249,6 +259,7 @@ struct dwx_sampler {
     rt::dfree(d_edges); rt::dfree(d_edges8); rt::dfree(d_vifs); rt::dfree(d_assign_free); rt::dfree(d_assign_evid);
     rt::dfree(d_tally); rt::dfree(d_weights); rt::dfree(d_w32); rt::dfree(d_w_init); rt::dfree(d_terms); rt::dfree(d_delta);
     rt::dfree(d_w_fixed); rt::dfree(d_grad); rt::dfree(d_persist_rows); rt::dfree(d_persist_bar);
+    rt::dfree(d_gbuf[1]); rt::dfree(d_gbuf[2]); rt::dfree(d_wbuf64[0]); rt::dfree(d_wbuf64[1]); rt::dfree(d_wbuf32[0]); rt::dfree(d_wbuf32[1]);
     for (int i = 0; i < 2; ++i) { if (side[i]) rt::stream_destroy(side[i]); if (ev_join[i]) rt::event_destroy(ev_join[i]); }
     if (ev_fork) rt::event_destroy(ev_fork);
     if (stream) rt::stream_destroy(stream);
@@ -382,6 +393,13 @@ uint32_t launch_tiles(dwx_sampler *s, KernelParams &P, size_t l, uint32_t t0, ui
       while (j < b && sv[j].tile0 == sv[j - 1].tile0 + sv[j - 1].ntiles) ++j;
       runs.push_back({i, j});
       i = j;
+    }
+    if (runs.size() > 8 && !s->sorted_fallback_said) {
+      // (this used to be silent) ineligible tiles -- wave / workgroup bins, categorical rows --
+      // interleave with the eligible ones: the launch falls back to the tile sweep, said once per sampler
+      s->sorted_fallback_said = true;
+      fprintf(stderr, "dwx: a launch's weight-sorted super-tiles form %zu gap-free runs (more than 8): its tiles take "
+                      "the plain tile sweep (slower weight gathers)\n", runs.size());
     }
     if (!runs.empty() && runs.size() <= 8) {
       used_sorted = true;
@@ -1412,7 +1430,92 @@ void enqueue_apply(dwx_sampler *s) {
   }
   rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32,
              (const uint8_t *)s->d_w_fixed, s->d_grad, ts, hs, W, s->plan_eta, s->opts.reg_param,
-             (int)(s->opts.regularization == 1));
+             (int)(s->opts.regularization == 1), (const double *)nullptr, (long long *)nullptr);
+}
+
+// A split learning sweep of an all-unary graph with few weights (LDS gradient accumulators), one launch
+// per mini-batch: the update of mini-batch c - 1 is the prologue of mini-batch c's sweep kernel
+// (sweep8_merged_kernel, persist_kernels.h); three gradient buffers and two weight buffers in turn, the
+// last update by apply_kernel into the sampler's own arrays.  false: the sweep does not qualify.
+bool enqueue_merged_sweep(dwx_sampler *s) {
+  dwx_sampler::Level *L = s->plan_level;
+  const uint32_t n = (uint32_t)s->plan_chunks.size();
+  const CompiledGraph &c = *s->cg;
+  const uint32_t W = (uint32_t)c.W;
+  if (!s->merge_ok || !L || s->plan_batches < 2 || n < 2 || !L->fast || !L->d_t_static || L->rows < n || s->plan_force_dynamic)
+    return false;
+  rt::set_device(s->device);
+  if (!s->d_gbuf[1]) {
+    for (int k = 1; k < 3; ++k) {
+      s->d_gbuf[k] = (long long *)rt::dmalloc((size_t)W * 16);
+      rt::dmemset(s->d_gbuf[k], 0, (size_t)W * 16, s->stream);
+    }
+    for (int k = 0; k < 2; ++k) { s->d_wbuf64[k] = (double *)rt::dmalloc((size_t)W * 8); s->d_wbuf32[k] = (float *)rt::dmalloc((size_t)W * 4 + 4); }
+  }
+  s->d_gbuf[0] = s->d_grad;
+  if (s->plan_level) ++s->plan_level->sweeps;
+  const unsigned cap = s->persistent_blocks8[1];
+  for (uint32_t ci = 0; ci < n; ++ci) {
+    const dwx_sampler::Chunk &ch = s->plan_chunks[ci];
+    s->cur_chunk = ci;
+    KernelParams P = s->base;
+    P.sweep = s->sweep;
+    P.grad = s->d_gbuf[ci % 3];
+    P.tile_begin = ch.t0; P.tile_end = ch.t1;
+    MergeArgs M{};
+    M.prev_grad = ci ? s->d_gbuf[(ci - 1) % 3] : nullptr;
+    M.zero = s->d_gbuf[(ci + 1) % 3];
+    M.w_src = ci <= 1 ? s->d_weights : s->d_wbuf64[(ci - 2) % 2];
+    M.w_dst = ci ? s->d_wbuf64[(ci - 1) % 2] : nullptr;
+    M.w32_dst = ci ? s->d_wbuf32[(ci - 1) % 2] : nullptr;
+    M.w_fixed = s->d_w_fixed;
+    M.t_static = ci ? L->d_t_static + (size_t)(ci - 1) * 2 * W : nullptr;
+    M.stepsize = s->plan_eta; M.reg_param = s->opts.reg_param;
+    M.l2 = s->opts.regularization == 1 ? 1 : 0;
+    M.lds_lw32_off = s->merge_lw32_off;
+    TimedSpan sp{};
+    if (s->timing) {
+      sp.a = rt::event_create(); sp.b = rt::event_create(); sp.c = rt::event_create(); sp.kind = 1;
+      rt::event_record(sp.a, s->stream);
+    }
+    if (ch.t1 > ch.t0) {
+      const unsigned grid = std::min<unsigned>(ch.t1 - ch.t0, cap);
+      if (s->rp_cat) rt::launch(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL_CAT>, grid, BLOCK_THREADS, s->lds_merge, s->stream, P, M);
+      else switch (s->stage_k) {
+        case 3: rt::launch(sweep8_merged_kernel<3, (int)ROWPTR_UNROLL>, grid, BLOCK_THREADS, s->lds_merge, s->stream, P, M); break;
+        case 6: rt::launch(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL>, grid, BLOCK_THREADS, s->lds_merge, s->stream, P, M); break;
+        default: rt::launch(sweep8_merged_kernel<12, (int)ROWPTR_UNROLL>, grid, BLOCK_THREADS, s->lds_merge, s->stream, P, M); break;
+      }
+    } else {
+      // (an empty chunk: the update alone, through a one-workgroup launch over no tile)
+      P.tile_begin = P.tile_end = 0;
+      if (s->rp_cat) rt::launch(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL_CAT>, 1u, BLOCK_THREADS, s->lds_merge, s->stream, P, M);
+      else switch (s->stage_k) {
+        case 3: rt::launch(sweep8_merged_kernel<3, (int)ROWPTR_UNROLL>, 1u, BLOCK_THREADS, s->lds_merge, s->stream, P, M); break;
+        case 6: rt::launch(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL>, 1u, BLOCK_THREADS, s->lds_merge, s->stream, P, M); break;
+        default: rt::launch(sweep8_merged_kernel<12, (int)ROWPTR_UNROLL>, 1u, BLOCK_THREADS, s->lds_merge, s->stream, P, M); break;
+      }
+    }
+    if (s->timing) {
+      rt::event_record(sp.b, s->stream);
+      rt::event_record(sp.c, s->stream);
+      sp.launches = 1; sp.has_pull = false; sp.new_sweep = ci == 0;
+      s->spans.push_back(sp);
+    }
+  }
+  // the last mini-batch's update: from the weights the last merged launch wrote, into the sampler's own arrays
+  {
+    const uint32_t last = n - 1;
+    const unsigned grid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 2048u);
+    const long long *ts = L->d_t_static + (size_t)last * 2 * W;
+    const double *w_in = last == 0 ? (const double *)nullptr : (const double *)s->d_wbuf64[(last - 1) % 2];
+    rt::launch(apply_kernel, grid, BLOCK_THREADS, 0, s->stream, s->d_weights, s->d_w32, (const uint8_t *)s->d_w_fixed,
+               s->d_gbuf[last % 3], ts, ts + W, W, s->plan_eta, s->opts.reg_param, (int)(s->opts.regularization == 1), w_in,
+               last ? s->d_gbuf[(last - 1) % 3] : (long long *)nullptr);
+  }
+  s->terms_state = 0;
+  ++s->merged_sweeps;
+  return true;
 }
 
 // A split learning sweep of a few-weights, all-unary graph as ONE persistent launch
@@ -1812,6 +1915,21 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
         default: prepare8(sweep8_kernel<false, 12>, sweep8_kernel<true, 12>); prepare_tab(sweep8_kernel<false, 12, true>); break;
       }
     }
+    if (P.lds_agg_off && s->rec8 && s->cgiant_tiles.empty() && s->bgiant_tiles.empty() && c.wide_tiles.empty() &&
+        !getenv("DWX_NO_MERGED_APPLY")) {
+      // split learning sweeps, one launch per mini-batch: the update as the next sweep kernel's prologue
+      s->merge_lw32_off = (uint32_t)((s->lds_bytes[1] + 15) & ~(size_t)15);
+      s->lds_merge = s->merge_lw32_off + (size_t)c.W * 4 + 16;
+      s->merge_ok = s->lds_merge <= 160 * 1024;
+      if (s->merge_ok) {
+        if (s->rp_cat) rt::allow_dynamic_lds(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL_CAT>, s->lds_merge);
+        else switch (s->stage_k) {
+          case 3: rt::allow_dynamic_lds(sweep8_merged_kernel<3, (int)ROWPTR_UNROLL>, s->lds_merge); break;
+          case 6: rt::allow_dynamic_lds(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL>, s->lds_merge); break;
+          default: rt::allow_dynamic_lds(sweep8_merged_kernel<12, (int)ROWPTR_UNROLL>, s->lds_merge); break;
+        }
+      }
+    }
     if (P.lds_agg_off && c.W <= PERSIST_MAX_W && s->rec8 && s->cgiant_tiles.empty() && s->bgiant_tiles.empty() &&
         c.wide_tiles.empty() && getenv("DWX_PERSIST") && !getenv("DWX_NO_PERSIST")) {
       // a split learning sweep as one persistent launch (opt-in): at most one workgroup per CU, all resident
@@ -2025,7 +2143,9 @@ int dwx_sample_sgd_async(dwx_sampler *s, double stepsize) {
                         !s->timing && L->use_graph >= 0 && L->sweeps >= 1 &&
                         !(s->opts.plan_layouts == 0 && L->sweeps + 1 == layout_after_sweeps());
     if (enqueue_persistent_sweep(s)) {
-      // (few weights, many mini-batches: the whole split sweep is one persistent launch)
+      // (few weights, many mini-batches: the whole split sweep is one persistent launch; opt-in)
+    } else if (!replay && enqueue_merged_sweep(s)) {
+      // (few weights, split sweep: one launch per mini-batch, the update as the next one's prologue)
     } else if (!replay) {
       enqueue_sweep();
     } else {
@@ -2378,7 +2498,13 @@ int dwx_kernel_time_reset(dwx_sampler *s, int enable) {
 }
 
 int dwx_kernel_time(dwx_sampler *s, int kind, double *ms, uint64_t *launches, uint64_t *sweeps) {
-  if (!s || kind < 0 || kind > 4) return fail(DWX_E_INVALID, "bad argument");
+  if (!s || kind < 0 || kind > 5) return fail(DWX_E_INVALID, "bad argument");
+  if (kind == 5) {   // split learning sweeps run with one (merged) launch per mini-batch since the sampler was created
+    if (ms) *ms = 0.0;
+    if (launches) *launches = s->merged_sweeps;
+    if (sweeps) *sweeps = s->merged_sweeps;
+    return DWX_OK;
+  }
   if (kind == 4) {   // split learning sweeps run as ONE persistent launch since the sampler was created (no device time)
     if (ms) *ms = 0.0;
     if (launches) *launches = s->persist_launches;

@@ -157,5 +157,35 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 1) persist_learn8_kernel(const 
     for (uint32_t i = t; i < W; i += BLOCK_THREADS) { A.weights[i] = s_w64[i]; A.w32[i] = s_lw32[i]; }
 }
 
+// ---------------------------------------------------------------- one launch per mini-batch
+// What the persistent launch above could not buy, the other way round (round 4): a mini-batch of a split
+// sweep stays a launch of its own -- a kernel boundary is cheaper than a grid barrier -- but there is ONE
+// launch per mini-batch instead of two: the update of mini-batch c - 1 (apply_kernel's arithmetic,
+// apply_value) runs as the PROLOGUE of mini-batch c's sweep kernel, by every workgroup for itself, from the
+// previous launch's gradient sums (complete: the launch has ended) into an LDS copy of the f32 weights that
+// the tile loop gathers from.  Workgroup 0 also writes the new weights out (to the OTHER of two buffers:
+// its neighbours may still be reading the old ones) and zeroes the buffer the next mini-batch will add
+// into (three gradient buffers in turn).  A dependent launch costs ~4 us here whatever it does
+// (profiles/r04/v5): 64 of them less per sweep of config 4.  Bit for bit the two-launch path.
+template <int K, int RP>
+__global__ void __launch_bounds__(BLOCK_THREADS, DWX_S8_LEARN_WG) sweep8_merged_kernel(const KernelParams P, const MergeArgs M) {
+  DWX_DYN_LDS(dyn_lds);
+  float *s_lw32 = (float *)(dyn_lds + M.lds_lw32_off);
+  const uint32_t W = P.num_weights;
+  for (uint32_t i = threadIdx.x; i < W; i += BLOCK_THREADS) {
+    double x = M.w_src[i];
+    if (M.prev_grad) {
+      x = apply_value(x, M.w_fixed[i] != 0, M.t_static, M.t_static ? M.t_static + W : nullptr, i, M.prev_grad[i],
+                      M.prev_grad[W + i], M.stepsize, M.reg_param, M.l2);
+      if (blockIdx.x == 0) { M.w_dst[i] = x; M.w32_dst[i] = (float)x; }
+    }
+    s_lw32[i] = (float)x;
+  }
+  if (blockIdx.x == 0 && M.zero)
+    for (uint32_t i = threadIdx.x; i < 2u * W; i += BLOCK_THREADS) M.zero[i] = 0;
+  __syncthreads();
+  sweep8_body<true, K, false, RP, false, true>(P, s_lw32);
+}
+
 }  // namespace dwx
 #endif  // DWX_PERSIST_KERNELS_H_

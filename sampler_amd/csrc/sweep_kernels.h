@@ -543,10 +543,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
 #endif
 // MULTI (inference, gathering build only): P.n_sweeps sweeps per launch -- the tile is staged once
 // and every variable is drawn n_sweeps times (infer_variable_multi, tile_walk.h).
-template <bool LEARN, int K, bool TAB = false, int RP = (int)ROWPTR_UNROLL, bool MULTI = false>
-__global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN_WG : DWX_S8_INFER_WG)) sweep8_kernel(const KernelParams P) {
+// LW (sweep8_merged_kernel, persist_kernels.h): the weight gathers read lw32, the workgroup's own LDS copy
+// of the f32 weights, instead of P.w32.
+template <bool LEARN, int K, bool TAB = false, int RP = (int)ROWPTR_UNROLL, bool MULTI = false, bool LW = false>
+DWX_DEV void sweep8_body(const KernelParams &P, const float *lw32) {
   static_assert(!(LEARN && TAB), "the terms table serves inference sweeps only");
   static_assert(!MULTI || (!LEARN && !TAB), "several sweeps per launch: the gathering inference build");
+  static_assert(!LW || (LEARN && !TAB && !MULTI), "LDS weights: the learning build");
   DWX_DYN_LDS(dyn_lds);
   uint32_t *s_rowptr = (uint32_t *)dyn_lds;
   double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
@@ -578,7 +581,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
       float w[K];
       if (!TAB) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) w[k] = P.w32[f.rec[k].key & REC8_WID_MASK];
+        for (int k = 0; k < K; ++k) w[k] = (LW ? lw32 : P.w32)[f.rec[k].key & REC8_WID_MASK];
       }
       // ... and this lane's uniforms while the gathers are in flight
       if (!MULTI) philox_uniforms(P.seed, P.vid_offset + pre.orig, P.sweep, A, B);
@@ -684,6 +687,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN
     tile = next; next = nn; has_next = has_nn;
   }
   flush_accumulators(P, s_agg, t);
+}
+template <bool LEARN, int K, bool TAB = false, int RP = (int)ROWPTR_UNROLL, bool MULTI = false>
+__global__ void __launch_bounds__(BLOCK_THREADS, TAB ? 4 : (LEARN ? DWX_S8_LEARN_WG : DWX_S8_INFER_WG)) sweep8_kernel(const KernelParams P) {
+  sweep8_body<LEARN, K, TAB, RP, MULTI, false>(P, nullptr);
 }
 
 // ---------------------------------------------------------------- weight-sorted super-tiles

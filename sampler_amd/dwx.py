@@ -382,7 +382,7 @@ class GibbsSampler:
 
     def kernel_time(self, kind):
         ms, nl, ns = C.c_double(), C.c_uint64(), C.c_uint64()
-        k = {0: 0, "infer": 0, 1: 1, "learn": 1, 2: 2, "pull": 2, 3: 3, "graph": 3, 4: 4, "persist": 4}[kind]
+        k = {0: 0, "infer": 0, 1: 1, "learn": 1, 2: 2, "pull": 2, 3: 3, "graph": 3, 4: 4, "persist": 4, 5: 5, "merged": 5}[kind]
         self.lib.check(self.lib.L.dwx_kernel_time(self.h, k, C.byref(ms), C.byref(nl), C.byref(ns)))
         return ms.value, nl.value, ns.value
 

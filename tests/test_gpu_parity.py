@@ -181,6 +181,27 @@ def test_device_built_incidence_lists_and_block_tables_equal_the_host_builder(li
     run_parity(lib, raw, n_learn=3, n_infer=1, stepsize=0.01, check_index=False)
 
 
+def test_split_learning_sweep_with_one_launch_per_mini_batch(lib, monkeypatch):
+    """Config 4 with learning (8 weights tied to 10^5 evidence factors each: 64 mini-batches per sweep) and a
+    boolean graph with 20 weights: every mini-batch is ONE launch (sweep8_merged_kernel: the previous
+    mini-batch's update as the kernel's prologue, every workgroup for itself) -- the default.  Exact
+    against the oracle stepped chunk by chunk, bit for bit the two-launch path (DWX_NO_MERGED_APPLY)."""
+    for raw, kw in ((synthetic.cfg4(200_000, card=8, seed=7, learn=True), dict(stepsize=0.001, decay=0.9)),
+                    (synthetic.cfg3(300_000, n_weights=20, seed=4), dict(stepsize=0.002, decay=0.8, regularization="l1",
+                                                                        reg_param=0.002))):
+        s, _ = run_parity(lib, raw, n_learn=4, n_infer=2, **kw)
+        batches, n_chunks, _ = s.sgd_plan(kw["stepsize"])
+        assert batches >= 8 and n_chunks >= 8, (batches, n_chunks)
+        assert s.kernel_time("merged")[1] == 4, s.kernel_time("merged")
+        monkeypatch.setenv("DWX_NO_MERGED_APPLY", "1")
+        s2, _ = run_parity(lib, raw, n_learn=4, n_infer=2, **kw)
+        monkeypatch.delenv("DWX_NO_MERGED_APPLY")
+        assert s2.kernel_time("merged")[1] == 0
+        assert np.array_equal(s.weights, s2.weights)
+        assert np.array_equal(s.assignments("free"), s2.assignments("free"))
+        assert np.array_equal(s.assignments("evid"), s2.assignments("evid"))
+
+
 def test_split_learning_sweep_as_one_persistent_launch(lib, monkeypatch):
     """DWX_PERSIST=1 (opt-in: built, exact, measured slower than the plain launches -- persist_kernels.h).
     Config 4 with learning (8 weights tied to 10^5 evidence factors each: 64 mini-batches per sweep)

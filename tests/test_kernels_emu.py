@@ -88,6 +88,29 @@ def test_categorical_draws_through_the_second_tier():
         run_parity(lib2, binary_format.read_graph_dir(os.path.join(GOLDEN, fx)), n_learn=20, n_infer=40, stepsize=0.01)
 
 
+def test_split_sweep_with_one_launch_per_mini_batch(lib, monkeypatch):
+    """A split learning sweep of an all-unary graph with few weights (LDS gradient accumulators) runs ONE
+    launch per mini-batch (sweep8_merged_kernel): the update of mini-batch c - 1 is the prologue of
+    mini-batch c's sweep kernel -- every workgroup for itself, into its LDS copy of the f32 weights --
+    with three gradient buffers and two weight buffers in turn.  Exact against the oracle stepped chunk by
+    chunk (categorical, boolean, L2 and L1, 8 to 900 weights) and bit for bit the two-launch path
+    (DWX_NO_MERGED_APPLY)."""
+    cases = [(synthetic.cfg4(700, card=5, seed=7, learn=True), dict(stepsize=0.01, decay=1.0, compile_opts=dict(tile_vars=16))),
+             (synthetic.cfg3(3000, n_weights=20, seed=4), dict(stepsize=0.01, decay=0.9, compile_opts=dict(tile_vars=32),
+                                                              regularization="l1", reg_param=0.002)),
+             (synthetic.cfg3(3000, n_weights=900, seed=4), dict(stepsize=0.3, decay=0.9, compile_opts=dict(tile_vars=32),
+                                                               step_cap=0.05))]
+    for raw, kw in cases:
+        s, _ = run_parity(lib, raw, n_learn=4, n_infer=2, **kw)
+        assert s.sgd_plan(kw["stepsize"])[0] >= 2
+        assert s.kernel_time("merged")[1] == 4, s.kernel_time("merged")
+        monkeypatch.setenv("DWX_NO_MERGED_APPLY", "1")
+        s2, _ = run_parity(lib, raw, n_learn=4, n_infer=2, **kw)
+        monkeypatch.delenv("DWX_NO_MERGED_APPLY")
+        assert s2.kernel_time("merged")[1] == 0
+        assert np.array_equal(s.weights, s2.weights) and np.array_equal(s.assignments("evid"), s2.assignments("evid"))
+
+
 def test_split_sweep_as_one_persistent_launch(lib, monkeypatch):
     """DWX_PERSIST=1 (opt-in: measured slower than the plain launches, persist_kernels.h): a split
     learning sweep of an all-unary graph with few weights (>= 8 mini-batches) runs as ONE
