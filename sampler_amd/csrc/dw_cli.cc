@@ -813,7 +813,12 @@ void quick_exit_if_done(int exit_code) {
   std::cout.flush();
   std::cerr.flush();
   fflush(nullptr);
-  if (getenv("DWX_TIMING")) fprintf(stderr, "[dw timing] teardown (device + graph): skipped (process exit)\n");
+  if (getenv("DWX_TIMING")) {
+    fprintf(stderr, "[dw timing] teardown (device + graph): skipped (process exit)\n");
+    // (tools/e2e_walltime.py: what the process exit itself costs = the caller's clock - this)
+    fprintf(stderr, "[dw timing] epoch at exit: %.3f\n",
+            std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
+  }
   std::_Exit(exit_code);
 }
 
@@ -833,6 +838,9 @@ int gibbs(const CmdLine &args) {
     }
     // DWX_TIMING=1: wall time of every host phase on stderr
     const bool timing = getenv("DWX_TIMING") != nullptr;
+    if (timing)
+      fprintf(stderr, "[dw timing] epoch at start: %.3f\n",
+              std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
     double t_phase = now();
     auto phase = [&](const char *what) {
       const double t = now();

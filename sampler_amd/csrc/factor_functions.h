@@ -111,18 +111,43 @@ DWX_DEV void decode_inline2(const EdgeRec &r, uint32_t me, VifRec &a, VifRec &b)
 }
 
 // binary factor from its two satisfied bits (a = first predicate, b = second / head)
-DWX_DEV double binary_sign(uint32_t func, bool a, bool b) {
-  switch (func) {
-    case FUNC_AND: case FUNC_ISTRUE: return (a && b) ? 1.0 : -1.0;
-    case FUNC_AND_CATEGORICAL: return (a && b) ? 1.0 : 0.0;
-    case FUNC_OR: return (a || b) ? 1.0 : -1.0;
-    case FUNC_EQUAL: return (a == b) ? 1.0 : -1.0;
-    case FUNC_IMPLY_NATURAL: return !a ? 0.0 : (b ? 1.0 : -1.0);
-    case FUNC_IMPLY_MLN: return !a ? 1.0 : (b ? 1.0 : 0.0);
-    case FUNC_LINEAR: case FUNC_LOGICAL: return (!a || b) ? 1.0 : 0.0;
-    default: return (!a || b) ? 1.0 : 0.0;   // FUNC_RATIO: log2(1 + [!a || b])
-  }
+// Straight-line (round 4): a per-lane `switch (func)` compiles to a cascade of exec-mask branches -- in the
+// edge-parallel staging of sweep_kernel<LEARN> (6 records x 4 evaluations per lane) that cascade was 4 253 of
+// the kernel's 6 915 instructions, all scalar.  A function of two bits IS its four-entry truth table: one byte
+// per function id, two bits per (a, b) holding sign + 1:
+//   AND, ISTRUE          (a && b) ? +1 : -1                     OR       (a || b) ? +1 : -1
+//   AND_CATEGORICAL      (a && b) ? +1 :  0                     EQUAL    (a == b) ? +1 : -1
+//   IMPLY_NATURAL        !a ? 0 : (b ? +1 : -1)                 IMPLY_MLN !a ? +1 : (b ? +1 : 0)
+//   LINEAR, LOGICAL      (!a || b) ? +1 : 0                     RATIO    log2(1 + [!a || b]) = the same
+// (src/factor.h:112-299 at arity 2; ids that are no function read as the last line, as the switch's default did)
+constexpr uint32_t binary_truth_byte(int sign_ff, int sign_ft, int sign_tf, int sign_tt) {
+  return (uint32_t)(sign_ff + 1) | (uint32_t)(sign_ft + 1) << 2 | (uint32_t)(sign_tf + 1) << 4 | (uint32_t)(sign_tt + 1) << 6;
 }
+constexpr uint64_t binary_truth_word(int first_func) {
+  uint64_t word = 0;
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t f = (uint32_t)(first_func + i);
+    uint32_t byte = binary_truth_byte(1, 1, 0, 1);                       // LINEAR / LOGICAL / RATIO / IMPLY_MLN
+    if (f == FUNC_AND || f == FUNC_ISTRUE) byte = binary_truth_byte(-1, -1, -1, 1);
+    else if (f == FUNC_AND_CATEGORICAL) byte = binary_truth_byte(0, 0, 0, 1);
+    else if (f == FUNC_OR) byte = binary_truth_byte(-1, 1, 1, 1);
+    else if (f == FUNC_EQUAL) byte = binary_truth_byte(1, -1, -1, 1);
+    else if (f == FUNC_IMPLY_NATURAL) byte = binary_truth_byte(0, 0, -1, 1);
+    word |= (uint64_t)byte << (8 * i);
+  }
+  return word;
+}
+// the function's table (func < 16: EDGE_FUNC_MASK)
+DWX_DEV uint32_t binary_truth(uint32_t func) {
+  constexpr uint64_t LO = binary_truth_word(0), HI = binary_truth_word(8);
+  const uint64_t word = (func & 8u) ? HI : LO;
+  return (uint32_t)(word >> ((func & 7u) * 8u)) & 0xFFu;
+}
+// ... and its entry: -1, 0 or +1
+DWX_DEV int binary_code(uint32_t truth, bool a, bool b) {
+  return (int)((truth >> (((a ? 2u : 0u) | (b ? 1u : 0u)) * 2u)) & 3u) - 1;
+}
+DWX_DEV double binary_sign(uint32_t func, bool a, bool b) { return (double)binary_code(binary_truth(func), a, b); }
 
 // sign functions of src/factor.h:112-299 (returned as double, before * feature_value)
 DWX_DEV double factor_sign(uint32_t func, uint32_t arity, uint32_t aux, const VifRec *vifs,

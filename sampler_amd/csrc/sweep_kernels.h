@@ -299,26 +299,28 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
+          // straight-line (no per-lane branch: the function is its truth table, factor_functions.h; a
+          // pre-signed record decodes to harmless operands and takes its own two fields at the end)
           const EdgeRec r = rec[k];
           LearnRec lr;
           lr.wid = r.wid; lr.packed = r.packed; lr.w = w[k]; lr.pad = 0;
-          if (r.packed & EDGE_PRESIGNED) {
-            lr.sf1 = lr.se1 = r.fval;
-            lr.sf0 = lr.se0 = bits_to_float(r.aux);
-          } else {
-            const uint32_t me = d.v0 + edge_owner_lane(r);
-            const bool a_me = va[k].vid == me, b_me = vb[k].vid == me;
-            const bool a1 = va[k].equal_to == 1u, a0 = va[k].equal_to == 0u;
-            const bool b1 = vb[k].equal_to == 1u, b0 = vb[k].equal_to == 0u;
-            const bool af = of[k] == va[k].equal_to, bf = of[k] == vb[k].equal_to;
-            const bool ae = oe[k] == va[k].equal_to, be = oe[k] == vb[k].equal_to;
-            const uint32_t fn = edge_func(r);
-            const double fv = (double)r.fval;
-            lr.sf1 = (float)(binary_sign(fn, a_me ? a1 : af, b_me ? b1 : bf) * fv);
-            lr.sf0 = (float)(binary_sign(fn, a_me ? a0 : af, b_me ? b0 : bf) * fv);
-            lr.se1 = (float)(binary_sign(fn, a_me ? a1 : ae, b_me ? b1 : be) * fv);
-            lr.se0 = (float)(binary_sign(fn, a_me ? a0 : ae, b_me ? b0 : be) * fv);
-          }
+          const bool presigned = r.packed & EDGE_PRESIGNED;
+          const uint32_t me = d.v0 + edge_owner_lane(r);
+          const bool a_me = va[k].vid == me, b_me = vb[k].vid == me;
+          const bool a1 = va[k].equal_to == 1u, a0 = va[k].equal_to == 0u;
+          const bool b1 = vb[k].equal_to == 1u, b0 = vb[k].equal_to == 0u;
+          const bool af = of[k] == va[k].equal_to, bf = of[k] == vb[k].equal_to;
+          const bool ae = oe[k] == va[k].equal_to, be = oe[k] == vb[k].equal_to;
+          const uint32_t truth = binary_truth(edge_func(r));
+          // sign in {-1, 0, +1} times an f32: that f32, its negation or a zero -- in f32 what
+          // (float)(sign * (double)f) is, bit for bit
+          const float u1 = (float)binary_code(truth, a_me ? a1 : af, b_me ? b1 : bf) * r.fval;
+          const float u0 = (float)binary_code(truth, a_me ? a0 : af, b_me ? b0 : bf) * r.fval;
+          const float e1 = (float)binary_code(truth, a_me ? a1 : ae, b_me ? b1 : be) * r.fval;
+          const float e0 = (float)binary_code(truth, a_me ? a0 : ae, b_me ? b0 : be) * r.fval;
+          const float miss = bits_to_float(r.aux);
+          lr.sf1 = presigned ? r.fval : u1; lr.sf0 = presigned ? miss : u0;
+          lr.se1 = presigned ? r.fval : e1; lr.se0 = presigned ? miss : e0;
           s_lrec[t + k * BLOCK_THREADS] = lr;
         }
       } else if ((TV & TV_TERMS3) && K <= 6 && !LEARN && (d.flags & TILE_TERMS3)) {
@@ -354,21 +356,19 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
             const double wf = u32x2_to_double(r.wid, r.aux);
             const uint32_t bits = float_to_bits(r.fval);
             EdgeTerms tt;
-            if (bits & TAB2_UNARY) {
-              tt.t1 = (bits & TAB2_C1) ? wf : 0.0;
-              const uint32_t c0 = (bits >> TAB2_C0_SHIFT) & 3u;   // 0: -1, 1: 0, 2: +1
-              tt.t0 = c0 == 1u ? 0.0 : (c0 == 2u ? wf : -wf);
-            } else {
-              const uint32_t pa = (bits >> INLINE2_PRED_A_SHIFT) & INLINE2_PRED_MASK;
-              const uint32_t pb = (bits >> INLINE2_PRED_B_SHIFT) & INLINE2_PRED_MASK;
-              const bool a_me = bits & INLINE2_A_IS_OWNER, b_me = bits & INLINE2_B_IS_OWNER;
-              const bool a_o = other[k] == pa, b_o = other[k] == pb;
-              const bool a1 = a_me ? (pa == 1u) : a_o, b1 = b_me ? (pb == 1u) : b_o;
-              const bool a0 = a_me ? (pa == 0u) : a_o, b0 = b_me ? (pb == 0u) : b_o;
-              const uint32_t fn = bits & EDGE_FUNC_MASK;
-              tt.t1 = binary_sign(fn, a1, b1) * wf;
-              tt.t0 = binary_sign(fn, a0, b0) * wf;
-            }
+            // (straight-line; a unary entry's garbage operands are never selected)
+            const bool unary = bits & TAB2_UNARY;
+            const uint32_t c0 = (bits >> TAB2_C0_SHIFT) & 3u;   // 0: -1, 1: 0, 2: +1
+            const uint32_t pa = (bits >> INLINE2_PRED_A_SHIFT) & INLINE2_PRED_MASK;
+            const uint32_t pb = (bits >> INLINE2_PRED_B_SHIFT) & INLINE2_PRED_MASK;
+            const bool a_me = bits & INLINE2_A_IS_OWNER, b_me = bits & INLINE2_B_IS_OWNER;
+            const bool a_o = other[k] == pa, b_o = other[k] == pb;
+            const bool a1 = a_me ? (pa == 1u) : a_o, b1 = b_me ? (pb == 1u) : b_o;
+            const bool a0 = a_me ? (pa == 0u) : a_o, b0 = b_me ? (pb == 0u) : b_o;
+            const uint32_t truth = binary_truth(bits & EDGE_FUNC_MASK);
+            const double s1 = (double)binary_code(truth, a1, b1) * wf, s0 = (double)binary_code(truth, a0, b0) * wf;
+            tt.t1 = unary ? ((bits & TAB2_C1) ? wf : 0.0) : s1;
+            tt.t0 = unary ? (c0 == 1u ? 0.0 : (c0 == 2u ? wf : -wf)) : s0;
             s_terms[t + k * BLOCK_THREADS] = tt;
           }
         } else {
@@ -397,21 +397,18 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
           const EdgeRec r = rec[k];
           const double wv = (double)w[k];
           EdgeTerms tt;
-          if (r.packed & EDGE_PRESIGNED) {
-            tt.t1 = wv * (double)r.fval;
-            tt.t0 = wv * (double)bits_to_float(r.aux);
-          } else {
-            const uint32_t me = d.v0 + edge_owner_lane(r);
-            const bool a_me = va[k].vid == me, b_me = vb[k].vid == me;
-            const bool a_o = other[k] == va[k].equal_to, b_o = other[k] == vb[k].equal_to;
-            // satisfied bits under proposal x: own positions compare x with their predicate
-            const bool a1 = a_me ? (va[k].equal_to == 1u) : a_o, b1 = b_me ? (vb[k].equal_to == 1u) : b_o;
-            const bool a0 = a_me ? (va[k].equal_to == 0u) : a_o, b0 = b_me ? (vb[k].equal_to == 0u) : b_o;
-            const uint32_t fn = edge_func(r);
-            const double fv = (double)r.fval;
-            tt.t1 = wv * (binary_sign(fn, a1, b1) * fv);
-            tt.t0 = wv * (binary_sign(fn, a0, b0) * fv);
-          }
+          // (straight-line, as in the learning staging above: sign * f in f32 is exact)
+          const bool presigned = r.packed & EDGE_PRESIGNED;
+          const uint32_t me = d.v0 + edge_owner_lane(r);
+          const bool a_me = va[k].vid == me, b_me = vb[k].vid == me;
+          const bool a_o = other[k] == va[k].equal_to, b_o = other[k] == vb[k].equal_to;
+          // satisfied bits under proposal x: own positions compare x with their predicate
+          const bool a1 = a_me ? (va[k].equal_to == 1u) : a_o, b1 = b_me ? (vb[k].equal_to == 1u) : b_o;
+          const bool a0 = a_me ? (va[k].equal_to == 0u) : a_o, b0 = b_me ? (vb[k].equal_to == 0u) : b_o;
+          const uint32_t truth = binary_truth(edge_func(r));
+          const float u1 = (float)binary_code(truth, a1, b1) * r.fval, u0 = (float)binary_code(truth, a0, b0) * r.fval;
+          tt.t1 = wv * (double)(presigned ? r.fval : u1);
+          tt.t0 = wv * (double)(presigned ? bits_to_float(r.aux) : u0);
           s_terms[t + k * BLOCK_THREADS] = tt;
         }
         }

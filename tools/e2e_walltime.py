@@ -41,8 +41,14 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
         os.makedirs(out)
         t0 = time.time()
         r = subprocess.run([exe, "gibbs"] + files + ["-o", out] + flags, capture_output=True, text=True)
-        res[name + "_wall_s"] = round(time.time() - t0, 2)
+        t1 = time.time()
+        res[name + "_wall_s"] = round(t1 - t0, 2)
         res[name + "_rc"] = r.returncode
+        for l in r.stderr.splitlines():   # DWX_TIMING=1: what lies before the first and after the last phase
+            if l.startswith("[dw timing] epoch at start:"):
+                res[name + "_startup_s"] = round(float(l.split(":")[1]) - t0, 2)
+            if l.startswith("[dw timing] epoch at exit:"):
+                res[name + "_process_exit_s"] = round(t1 - float(l.split(":")[1]), 2)
         phases = [l for l in r.stderr.splitlines() if l.startswith("[dw")]   # DWX_TIMING=1
         if phases:
             res[name + "_phases"] = phases
