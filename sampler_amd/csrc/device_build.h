@@ -16,6 +16,13 @@ namespace devb {
 
 bool available();
 
+// The builds below take their large temporaries from a cache of device blocks that are handed back instead of
+// freed (device_build.hip: a hipFree of gigabytes is paid by a later hipMalloc, a second per 16 GB).
+// release_scratch really frees the idle blocks of `device` (-1: all) -- with only_if_tight, only when they are a
+// quarter or more of the device memory that is still free; scratch_bytes is what the cache holds.
+void release_scratch(int device, bool only_if_tight);
+uint64_t scratch_bytes(int device);
+
 // The weight-sorted records of `n_supers` super-tiles (SuperTile::lo/hi/nrec already planned: the
 // records of super-tile i go to d_out[lo | hi << 32 .. + nrec)), n_total records in all, sorted by
 // (weight id, owner) inside every super-tile -- byte for byte what build_sorted_layout (graph_compile.cc)

@@ -22,7 +22,11 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -37,6 +41,47 @@ inline void check(hipError_t e, const char *what) {
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
 }
 #define DEVB_HIP(x) check((x), #x)
+
+// The builds' large temporaries (sort keys / values / rocPRIM storage: 16 GB for config 5's incidence list) come
+// from a cache of device blocks that are handed back, not freed: on this stack hipFree of a large block returns
+// at once and the release is paid by a LATER hipMalloc -- about a second per 16 GB (tools: 4 x 4 GB allocated in
+// 1 ms, or in 1.08 s after two rounds of free), which made `dw gibbs` on config 5's size vary by seconds from
+// run to run.  A block serves any later request it is large enough for (smallest fit); release_scratch()
+// really frees the idle ones.  Small requests (< 1 MiB) go to hipMalloc / hipFree as before.
+constexpr size_t SCRATCH_MIN = (size_t)1 << 20;
+struct ScratchBlock { void *p; size_t bytes; int device; bool busy; };
+std::mutex g_scratch_mu;
+std::vector<ScratchBlock> g_scratch;
+
+void *scratch_take(size_t bytes) {
+  bytes = std::max<size_t>(16, bytes);
+  int dev = 0;
+  DEVB_HIP(hipGetDevice(&dev));
+  if (bytes >= SCRATCH_MIN) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    ScratchBlock *best = nullptr;
+    for (ScratchBlock &b : g_scratch)
+      if (!b.busy && b.device == dev && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+    if (best) { best->busy = true; return best->p; }
+  }
+  void *p = nullptr;
+  DEVB_HIP(hipMalloc(&p, bytes));
+  if (bytes >= SCRATCH_MIN) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    g_scratch.push_back({p, bytes, dev, true});
+  }
+  return p;
+}
+
+void scratch_give(void *p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (ScratchBlock &b : g_scratch)
+      if (b.p == p) { b.busy = false; return; }
+  }
+  (void)hipFree(p);
+}
 
 constexpr uint32_t EMIT_THREADS = 1024;
 
@@ -508,9 +553,19 @@ void build_incidence(const TileDesc *d_tiles, const TileDesc *h_tiles, uint32_t 
   out = Incidence();
   out.inc_begin.assign(n_groups, 0); out.inc_end.assign(n_groups, 0);
   std::vector<void *> scratch;
-  auto dalloc = [&](size_t bytes) { void *p = nullptr; DEVB_HIP(hipMalloc(&p, std::max<size_t>(16, bytes))); scratch.push_back(p); return p; };
-  auto release = [&]() { for (void *p : scratch) (void)hipFree(p); scratch.clear(); };
+  auto dalloc = [&](size_t bytes) { void *p = scratch_take(bytes); scratch.push_back(p); return p; };
+  auto release = [&]() { for (void *p : scratch) scratch_give(p); scratch.clear(); };
   U32x4 *ell_now = nullptr;
+  // DWX_TIMING=1: wall time of the steps on stderr (each ends on a stream sync)
+  const bool timing = getenv("DWX_TIMING") != nullptr;
+  auto t_step = std::chrono::steady_clock::now();
+  auto step = [&](const char *what) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(st);
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[devb incidence] %-26s %.3f s\n", what, std::chrono::duration<double>(t - t_step).count());
+    t_step = t;
+  };
   try {
     // ---- entries: count per tile, scan on the host (a few hundred thousand tiles), emit, sort ----
     uint32_t *d_info = (uint32_t *)dalloc((size_t)n_tiles * 4);
@@ -530,12 +585,15 @@ void build_incidence(const TileDesc *d_tiles, const TileDesc *h_tiles, uint32_t 
     if (n + (uint64_t)n_groups * PULL_RUN >= 0xFFFFFFFFull) throw std::invalid_argument("incidence list exceeds 2^32-1 entries");
     if (!n) { release(); return; }
     DEVB_HIP(hipMemcpyAsync(d_cnt, base.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, st));
+    step("count");
     unsigned long long *k0 = (unsigned long long *)dalloc(n * 8), *k1 = (unsigned long long *)dalloc(n * 8);
     unsigned long long *v0 = (unsigned long long *)dalloc(n * 8), *v1 = (unsigned long long *)dalloc(n * 8);
+    step("allocate 4 x n x 8 bytes");
     hipLaunchKernelGGL(incidence_emit_kernel<false>, dim3(n_tiles), dim3(BLOCK_THREADS), 0, st, d_tiles, n_tiles,
                        (const uint32_t *)d_info, d_v_meta, d_v_row, d_row_ptr, d_edges, (uint32_t)learn_non_evidence,
                        (uint32_t)noise_aware, (unsigned long long *)nullptr, (const unsigned long long *)d_cnt, k0, v0);
     DEVB_HIP(hipGetLastError());
+    step("emit");
     uint32_t gbits = 0;
     while ((1ull << gbits) < (uint64_t)n_groups) ++gbits;
     {
@@ -544,6 +602,7 @@ void build_incidence(const TileDesc *d_tiles, const TileDesc *h_tiles, uint32_t 
       void *tmp = dalloc(tmp_bytes);
       DEVB_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, (size_t)n, 0u, 32u + (gbits ? gbits : 1u), st));
     }
+    step("radix sort");
     const unsigned long long *keys = k1, *vals = v1;      // (k0 / v0 are free again: the kept lists go there)
     // ---- where the groups start; which tiles own entries; the distinct deltas ----
     std::vector<unsigned long long> q(n_groups + 1), c_start(n_groups + 1);
@@ -567,6 +626,7 @@ void build_incidence(const TileDesc *d_tiles, const TileDesc *h_tiles, uint32_t 
     DEVB_HIP(hipMemcpyAsync(dset.data(), d_dset, DSET_SLOTS * 4, hipMemcpyDeviceToHost, st));
     DEVB_HIP(hipMemcpyAsync(&dcount, d_dcount, 4, hipMemcpyDeviceToHost, st));
     DEVB_HIP(hipStreamSynchronize(st));
+    step("group starts, owners, deltas");
     // ---- block pull: per group, runs of <= bp_tiles consecutive tiles started at tiles that own entries ----
     std::vector<uint32_t> dvals;
     bool enabled = W >= block_pull_min_w && dcount <= BP_MAX_DELTAS;
@@ -642,6 +702,7 @@ void build_incidence(const TileDesc *d_tiles, const TileDesc *h_tiles, uint32_t 
       }
       if (!max_blocks) out.bp.clear();
     }
+    step("block tables");
     // groups without a table keep all their entries: the kept arrays hold them at the same positions
     for (uint32_t k = 0; k < n_groups; ++k) {
       const uint64_t g0 = c_start[k], gn = c_start[k + 1] - c_start[k];
@@ -670,6 +731,7 @@ void build_incidence(const TileDesc *d_tiles, const TileDesc *h_tiles, uint32_t 
     out.max_blocks = max_blocks;
     out.wp = Wp;
     DEVB_HIP(hipStreamSynchronize(st));
+    step("list columns");
   } catch (...) {
     release();
     (void)hipFree(ell_now);
@@ -679,6 +741,7 @@ void build_incidence(const TileDesc *d_tiles, const TileDesc *h_tiles, uint32_t 
     throw;
   }
   release();
+  step("release scratch");
 }
 
 void build_static_tables(const TileDesc *d_tiles, uint32_t n_tiles, const uint32_t *h_group_of, const uint32_t *d_v_meta,
@@ -725,12 +788,12 @@ void build_sorted_records(const TileDesc *d_tiles, const EdgeRec *d_edges, const
   uint32_t *v0 = nullptr, *v1 = nullptr, *d_dbits = nullptr;
   void *tmp = nullptr;
   auto cleanup = [&]() {
-    (void)hipFree(k0); (void)hipFree(k1); (void)hipFree(v0); (void)hipFree(v1); (void)hipFree(d_dbits); (void)hipFree(tmp);
+    scratch_give(k0); scratch_give(k1); scratch_give(v0); scratch_give(v1); scratch_give(d_dbits); scratch_give(tmp);
   };
   try {
-    DEVB_HIP(hipMalloc(&k0, n_total * 8)); DEVB_HIP(hipMalloc(&k1, n_total * 8));
-    DEVB_HIP(hipMalloc(&v0, n_total * 4)); DEVB_HIP(hipMalloc(&v1, n_total * 4));
-    DEVB_HIP(hipMalloc(&d_dbits, std::max<size_t>(4, (size_t)n_dbits * 4)));
+    k0 = (unsigned long long *)scratch_take(n_total * 8); k1 = (unsigned long long *)scratch_take(n_total * 8);
+    v0 = (uint32_t *)scratch_take(n_total * 4); v1 = (uint32_t *)scratch_take(n_total * 4);
+    d_dbits = (uint32_t *)scratch_take(std::max<size_t>(4, (size_t)n_dbits * 4));
     if (n_dbits) DEVB_HIP(hipMemcpyAsync(d_dbits, h_dbits, (size_t)n_dbits * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(emit_sorted_kernel, dim3(n_supers), dim3(EMIT_THREADS), 0, st, d_tiles, d_edges, d_edges8, d_supers,
                        n_supers, (const uint32_t *)d_dbits, n_dbits, k0, v0);
@@ -741,7 +804,7 @@ void build_sorted_records(const TileDesc *d_tiles, const EdgeRec *d_edges, const
     const unsigned end_bit = 32u + (sbits ? sbits : 1u);
     size_t tmp_bytes = 0;
     DEVB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, (size_t)n_total, 0u, end_bit, st));
-    DEVB_HIP(hipMalloc(&tmp, std::max<size_t>(16, tmp_bytes)));
+    tmp = scratch_take(tmp_bytes);
     DEVB_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, (size_t)n_total, 0u, end_bit, st));
     const unsigned grid = (unsigned)std::min<uint64_t>((n_total + 255) / 256, 256u * 32u);
     hipLaunchKernelGGL(compose_sorted_kernel, dim3(grid), dim3(256), 0, st, (const unsigned long long *)k1,
@@ -753,6 +816,37 @@ void build_sorted_records(const TileDesc *d_tiles, const EdgeRec *d_edges, const
     throw;
   }
   cleanup();
+}
+
+uint64_t scratch_bytes(int device);
+void release_scratch(int device, bool only_if_tight) {
+  if (only_if_tight) {
+    // (kept for the plan levels built later unless it is a quarter or more of what is still free)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && scratch_bytes(device) < free_b / 4) return;
+  }
+  std::vector<void *> dead;
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (size_t i = 0; i < g_scratch.size();) {
+      if (!g_scratch[i].busy && (device < 0 || g_scratch[i].device == device)) {
+        dead.push_back(g_scratch[i].p);
+        g_scratch[i] = g_scratch.back();
+        g_scratch.pop_back();
+      } else {
+        ++i;
+      }
+    }
+  }
+  for (void *p : dead) (void)hipFree(p);
+}
+
+uint64_t scratch_bytes(int device) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  uint64_t n = 0;
+  for (const ScratchBlock &b : g_scratch)
+    if (device < 0 || b.device == device) n += b.bytes;
+  return n;
 }
 
 }  // namespace devb

@@ -280,7 +280,7 @@ struct Mapped {
     close(fd);
   }
   ~Mapped() {
-    if (mapped_) munmap((void *)p, n);
+    if (mapped_) dwx::unmap_parallel((void *)p, n);   // (42 GB of page-table entries at config 5's size)
     delete owned_;
   }
   Mapped(const Mapped &) = delete;
@@ -868,6 +868,18 @@ int gibbs(const CmdLine &args) {
     dwx_compile_opts co = compile_opts_for(args);
     ok(dwx_graph_create(&desc, &co, &graph));
     phase("dwx_graph_create (index, colouring, device layout)");
+    // the decoded factor / edge columns (42 GB at config 5's size) are dead once the graph is compiled (it keeps
+    // no pointer into them): a helper thread gives them back while the sampler is created -- in 64 MiB steps
+    // that take the address-space lock shared (host_parallel.h, unmap_parallel), so the creating thread's own
+    // mappings never wait longer than one step
+    {
+      struct Dead {
+        dwx::RawArray<uint16_t> a; dwx::RawArray<uint64_t> b, c; dwx::RawArray<double> d; dwx::RawArray<uint64_t> e, f;
+      };
+      Dead *dead = new Dead{std::move(lg.fac_func), std::move(lg.fac_edge_offset), std::move(lg.fac_weight_id),
+                            std::move(lg.fac_feature_value), std::move(lg.edge_vid), std::move(lg.edge_equal_to)};
+      std::thread([dead]() { delete dead; }).detach();
+    }
     dwx_graph_info info;
     ok(dwx_graph_get_info(graph, &info));
     auto print_size = [&](const char *what) {
@@ -1031,6 +1043,8 @@ int gibbs(const CmdLine &args) {
         }
       }
     }
+    // (before this scope's destructors: they would unmap gigabytes one array after the other)
+    quick_exit_if_done(0);
   } catch (const std::exception &e) {
     std::cerr << "dw: " << e.what() << std::endl;
     exit_code = 1;

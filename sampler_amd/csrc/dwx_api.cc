@@ -718,8 +718,20 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
   }
   // (plan_layouts 0, the default: with the level wherever the records are sorted on the device -- it
   // costs milliseconds there; a host build pays 0.3 s per level and waits for 2048 sweeps)
+  // DWX_TIMING=1: wall time of the level's build steps on stderr (each ends on a stream sync)
+  const bool lv_timing = getenv("DWX_TIMING") != nullptr;
+  auto lv_t0 = std::chrono::steady_clock::now();
+  auto lv_step = [&](const char *what) {
+    if (!lv_timing) return;
+    rt::stream_sync(s->stream);
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[dwx level B=%u] %-28s %.3f s\n", batches, what, std::chrono::duration<double>(t - lv_t0).count());
+    lv_t0 = t;
+  };
+  lv_step("chunks");
   if (s->opts.plan_layouts == 1 || (s->opts.plan_layouts == 0 && devb::available() && !getenv("DWX_HOST_BUILD")))
     ensure_level_layout(s, L.get(), batches);
+  lv_step("weight-sorted layout");
   const uint32_t nc = (uint32_t)L->chunks.size();
   // beyond this the per-chunk tables cost more than they save: such plans keep the
   // per-record atomics and dynamic counts
@@ -754,6 +766,7 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
                                 s->d_edges, s->d_edge_fval64, (const uint8_t *)s->d_w_fixed, (uint32_t)c.W, nc,
                                 o.learn_non_evidence != 0, o.noise_aware != 0, L->d_t_static, &tm, &hm, (void *)s->stream);
       L->c_max = (double)hm / H_SCALE; L->t_max = (double)tm / FIX_SCALE;
+      lv_step("static tables (device)");
     } else {
     RawArray<long long> ts((size_t)nc * 2 * c.W);
     parallel_ranges((uint64_t)nc * 2 * c.W, nth, [&](uint64_t b, uint64_t e) { std::fill(ts.data() + b, ts.data() + e, 0LL); });
@@ -825,6 +838,7 @@ dwx_sampler::Level *build_level(dwx_sampler *s, uint32_t batches) {
                             (uint32_t)bp_tiles, inc, (void *)s->stream);
       L->d_inc_wid = inc.d_inc_wid; L->d_inc_slot = inc.d_inc_slot; L->d_inc_d = inc.d_inc_d;
       L->inc_begin = inc.inc_begin; L->inc_end = inc.inc_end;
+      lv_step("incidence list (device)");
       if (!inc.bp.empty()) {
         const bool bp_timing = getenv("DWX_TIMING") != nullptr;
         L->bp.resize(nc);
@@ -1982,6 +1996,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     phase("static counts + gradient incidence list");
     if (opts->step_cap > 0) (void)row_sum_bound(s.get(), 1);
     phase("curvature estimate");
+    devb::release_scratch(s->device, true);   // (the builds' cached temporaries: kept unless memory is tight)
   });
   if (rc != DWX_OK) return rc;
   *out = s.release();
@@ -2017,7 +2032,9 @@ void dwx_sampler_destroy(dwx_sampler *s) {
     rt::stream_sync(s->stream);
   } catch (...) {
   }
+  const int device = s->device;
   delete s;
+  devb::release_scratch(device, false);
 }
 
 

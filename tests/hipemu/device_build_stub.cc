@@ -7,6 +7,8 @@
 namespace dwx {
 namespace devb {
 bool available() { return false; }
+void release_scratch(int, bool) {}
+uint64_t scratch_bytes(int) { return 0; }
 void build_sorted_records(const TileDesc *, const EdgeRec *, const EdgeRec8 *, const SuperTile *, uint32_t,
                           const uint32_t *, uint32_t, uint64_t, SortRec8 *, void *) {
   throw std::runtime_error("device build is not available in the host harness");

@@ -49,7 +49,7 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
                 res[name + "_startup_s"] = round(float(l.split(":")[1]) - t0, 2)
             if l.startswith("[dw timing] epoch at exit:"):
                 res[name + "_process_exit_s"] = round(t1 - float(l.split(":")[1]), 2)
-        phases = [l for l in r.stderr.splitlines() if l.startswith("[dw")]   # DWX_TIMING=1
+        phases = [l for l in r.stderr.splitlines() if l.startswith(("[dw", "[devb"))]   # DWX_TIMING=1
         if phases:
             res[name + "_phases"] = phases
         for line in r.stdout.splitlines():
