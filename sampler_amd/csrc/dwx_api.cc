@@ -1857,9 +1857,24 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     off += slots * sizeof(EdgeRec);
     P.lds_w_off = (uint32_t)off;     // f32 weights right behind the 16-byte records
     s->lds_bytes[0] = off;
-    // learning: 16-byte records + f32 weights (20 B per slot); with TILE_TERMS2 tiles the
-    // same region alternatively holds 32-byte LearnRecs (which carry their weight)
-    s->lds_bytes[1] = P.lds_edge_off + slots * (s->wide_learn ? 32 : 20);
+    {
+      // the tile classes this graph holds: sweep_kernel's smallest build that contains them
+      uint32_t tv = 0;
+      for (const TileDesc &td : c.tiles) {
+        if (td.flags & TILE_OUTSIDE) continue;
+        if (td.flags & TILE_CATEGORICAL) tv |= TV_CATEGORICAL;
+        if (td.flags & TILE_TERMS3) tv |= TV_TERMS3;
+        else if (td.flags & TILE_TERMS2) tv |= (td.flags & TILE_INLINE2) ? TV_TERMS2_INLINE : TV_TERMS2_VIFS;
+        else if (td.flags & TILE_SIMPLE) tv |= TV_SIMPLE;
+        else tv |= TV_GENERIC;
+      }
+      // (TV_PAIR stages 16-byte learning records: the weight id shares its word with two flags)
+      s->tv_pair = s->wide_learn && s->stage_k == 6 && (tv & TV_TERMS2_INLINE) && !(tv & ~TV_PAIR) &&
+                   c.W <= LR16_WID_MASK && !getenv("DWX_NO_TILE_VARIANTS");
+    }
+    // learning: 16-byte records + f32 weights (20 B per slot); with TILE_TERMS2 tiles the same region
+    // alternatively holds 32-byte LearnRecs (which carry their weight) -- 16-byte ones in the TV_PAIR build
+    s->lds_bytes[1] = P.lds_edge_off + slots * (s->wide_learn && !s->tv_pair ? 32 : 20);
     P.lds_agg_off = 0;
     P.n_sweeps = 1;
     if (c.W > 0 && c.W <= LDS_AGG_MAX_W) {
@@ -1873,19 +1888,6 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       s->persistent_blocks[0] = rt::resident_blocks(infer, BLOCK_THREADS, s->lds_bytes[0]);
       s->persistent_blocks[1] = rt::resident_blocks(learn, BLOCK_THREADS, s->lds_bytes[1]);
     };
-    {
-      // the tile classes this graph holds: sweep_kernel's smallest build that contains them
-      uint32_t tv = 0;
-      for (const TileDesc &td : c.tiles) {
-        if (td.flags & TILE_OUTSIDE) continue;
-        if (td.flags & TILE_CATEGORICAL) tv |= TV_CATEGORICAL;
-        if (td.flags & TILE_TERMS3) tv |= TV_TERMS3;
-        else if (td.flags & TILE_TERMS2) tv |= (td.flags & TILE_INLINE2) ? TV_TERMS2_INLINE : TV_TERMS2_VIFS;
-        else if (td.flags & TILE_SIMPLE) tv |= TV_SIMPLE;
-        else tv |= TV_GENERIC;
-      }
-      s->tv_pair = s->wide_learn && s->stage_k == 6 && (tv & TV_TERMS2_INLINE) && !(tv & ~TV_PAIR) && !getenv("DWX_NO_TILE_VARIANTS");
-    }
     if (s->tv_pair) {
       prepare(sweep_kernel<false, 6, false, TV_PAIR>, sweep_kernel<true, 6, true, TV_PAIR>);
     } else if (s->wide_learn) {

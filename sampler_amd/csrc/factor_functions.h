@@ -143,10 +143,11 @@ DWX_DEV uint32_t binary_truth(uint32_t func) {
   const uint64_t word = (func & 8u) ? HI : LO;
   return (uint32_t)(word >> ((func & 7u) * 8u)) & 0xFFu;
 }
-// ... and its entry: -1, 0 or +1
-DWX_DEV int binary_code(uint32_t truth, bool a, bool b) {
-  return (int)((truth >> (((a ? 2u : 0u) | (b ? 1u : 0u)) * 2u)) & 3u) - 1;
+// ... and its entry: sign + 1 in two bits / the sign -1, 0 or +1
+DWX_DEV uint32_t binary_code2(uint32_t truth, bool a, bool b) {
+  return (truth >> (((a ? 2u : 0u) | (b ? 1u : 0u)) * 2u)) & 3u;
 }
+DWX_DEV int binary_code(uint32_t truth, bool a, bool b) { return (int)binary_code2(truth, a, b) - 1; }
 DWX_DEV double binary_sign(uint32_t func, bool a, bool b) { return (double)binary_code(binary_truth(func), a, b); }
 
 // sign functions of src/factor.h:112-299 (returned as double, before * feature_value)

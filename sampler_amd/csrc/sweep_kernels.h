@@ -33,6 +33,8 @@
 #ifndef DWX_SWEEP_KERNELS_H_
 #define DWX_SWEEP_KERNELS_H_
 
+#include <type_traits>
+
 #include "tile_walk.h"
 
 namespace dwx {
@@ -206,10 +208,33 @@ DWX_DEV void flush_accumulators(const KernelParams &P, const long long *s_agg, u
 constexpr uint32_t TV_SIMPLE = 1u, TV_TERMS2_INLINE = 2u, TV_TERMS2_VIFS = 4u, TV_TERMS3 = 8u, TV_GENERIC = 16u;
 constexpr uint32_t TV_CATEGORICAL = 32u;      // some lane tile holds categorical variables
 constexpr uint32_t TV_ALL = 63u, TV_PAIR = TV_SIMPLE | TV_TERMS2_INLINE;
+#ifndef DWX_PAIR_WG
+#define DWX_PAIR_WG 4
+#endif
+// the staged learning record of a TILE_TERMS2 tile, in either form (tile_walk.h); codes: sign + 1
+DWX_DEV void store_learn_rec(LearnRec *dst, const EdgeRec &r, float w, bool presigned, float miss,
+                             uint32_t cu1, uint32_t cu0, uint32_t ce1, uint32_t ce0) {
+  // sign in {-1, 0, +1} times an f32: that f32, its negation or a zero -- in f32 what
+  // (float)(sign * (double)f) is, bit for bit
+  LearnRec lr;
+  lr.wid = r.wid; lr.packed = r.packed; lr.w = w; lr.pad = 0;
+  lr.sf1 = presigned ? r.fval : (float)((int)cu1 - 1) * r.fval; lr.sf0 = presigned ? miss : (float)((int)cu0 - 1) * r.fval;
+  lr.se1 = presigned ? r.fval : (float)((int)ce1 - 1) * r.fval; lr.se0 = presigned ? miss : (float)((int)ce0 - 1) * r.fval;
+  *dst = lr;
+}
+DWX_DEV void store_learn_rec(LearnRec16 *dst, const EdgeRec &r, float w, bool presigned, float miss,
+                             uint32_t cu1, uint32_t cu0, uint32_t ce1, uint32_t ce0) {
+  LearnRec16 lr;
+  lr.wf = r.wid | (presigned ? LR16_PRESIGNED : 0u) | ((r.packed & EDGE_FIXED_FLAG) ? LR16_FIXED : 0u);
+  lr.w = w; lr.a = r.fval;
+  lr.b = presigned ? miss : bits_to_float(cu1 | cu0 << 2 | ce1 << 4 | ce0 << 6);
+  *dst = lr;
+}
 template <bool LEARN, int K, bool WIDE = false, uint32_t TV = TV_ALL>
 // (the learning kernel's LDS footprint admits 2 workgroups per CU at K = 12: give the
 // register allocator the matching budget instead of spilling at the 3-per-CU limit)
-__global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEARN ? (K <= 6 ? 3 : 2) : 3)) sweep_kernel(const KernelParams P) {
+// (the TV_PAIR learning build stages 16-byte records: its LDS footprint admits DWX_PAIR_WG workgroups per CU)
+__global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? ((TV & TV_TERMS3) ? 3 : DWX_PAIR_WG) : 1) : (LEARN ? (K <= 6 ? 3 : 2) : 3)) sweep_kernel(const KernelParams P) {
   DWX_DYN_LDS(dyn_lds);
   uint32_t *s_rowptr = (uint32_t *)dyn_lds;
   double *s_pot = (double *)(dyn_lds + P.lds_pot_off);
@@ -218,6 +243,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
   long long *s_agg = (LEARN && P.lds_agg_off) ? (long long *)(dyn_lds + P.lds_agg_off) : nullptr;
   const uint32_t t = threadIdx.x;
   constexpr int WMODE = LEARN ? W_ARRAY : W_INRECORD;
+  // staged learning records of TILE_TERMS2 tiles: 16 bytes in a build without arity-3 staging (tile_walk.h)
+  using LRec = typename std::conditional<(TV & TV_TERMS3) != 0, LearnRec, LearnRec16>::type;
   uint32_t tile = P.tile_begin + blockIdx.x;
   if (tile >= P.tile_end) return;
   const uint32_t stride = gridDim.x;
@@ -276,7 +303,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
         };
         stage_generic_records<K, 4, 2, 0>(P, d, rec, chains, chain, prop, hit, put);
       } else if ((TV & (TV_TERMS2_INLINE | TV_TERMS2_VIFS)) && K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS2)) {
-        LearnRec *s_lrec = (LearnRec *)s_edges;
+        LRec *s_lrec = (LRec *)s_edges;
         VifRec va[K], vb[K];
         if (!(TV & TV_TERMS2_VIFS) || (d.flags & TILE_INLINE2)) {   // workgroup-uniform
 #pragma unroll
@@ -302,8 +329,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
           // straight-line (no per-lane branch: the function is its truth table, factor_functions.h; a
           // pre-signed record decodes to harmless operands and takes its own two fields at the end)
           const EdgeRec r = rec[k];
-          LearnRec lr;
-          lr.wid = r.wid; lr.packed = r.packed; lr.w = w[k]; lr.pad = 0;
           const bool presigned = r.packed & EDGE_PRESIGNED;
           const uint32_t me = d.v0 + edge_owner_lane(r);
           const bool a_me = va[k].vid == me, b_me = vb[k].vid == me;
@@ -312,16 +337,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
           const bool af = of[k] == va[k].equal_to, bf = of[k] == vb[k].equal_to;
           const bool ae = oe[k] == va[k].equal_to, be = oe[k] == vb[k].equal_to;
           const uint32_t truth = binary_truth(edge_func(r));
-          // sign in {-1, 0, +1} times an f32: that f32, its negation or a zero -- in f32 what
-          // (float)(sign * (double)f) is, bit for bit
-          const float u1 = (float)binary_code(truth, a_me ? a1 : af, b_me ? b1 : bf) * r.fval;
-          const float u0 = (float)binary_code(truth, a_me ? a0 : af, b_me ? b0 : bf) * r.fval;
-          const float e1 = (float)binary_code(truth, a_me ? a1 : ae, b_me ? b1 : be) * r.fval;
-          const float e0 = (float)binary_code(truth, a_me ? a0 : ae, b_me ? b0 : be) * r.fval;
+          // sign + 1 of the four evaluations: free / evidence chain x proposal 1 / 0
+          const uint32_t cu1 = binary_code2(truth, a_me ? a1 : af, b_me ? b1 : bf);
+          const uint32_t cu0 = binary_code2(truth, a_me ? a0 : af, b_me ? b0 : bf);
+          const uint32_t ce1 = binary_code2(truth, a_me ? a1 : ae, b_me ? b1 : be);
+          const uint32_t ce0 = binary_code2(truth, a_me ? a0 : ae, b_me ? b0 : be);
           const float miss = bits_to_float(r.aux);
-          lr.sf1 = presigned ? r.fval : u1; lr.sf0 = presigned ? miss : u0;
-          lr.se1 = presigned ? r.fval : e1; lr.se0 = presigned ? miss : e0;
-          s_lrec[t + k * BLOCK_THREADS] = lr;
+          store_learn_rec(&s_lrec[t + k * BLOCK_THREADS], r, w[k], presigned, miss, cu1, cu0, ce1, ce0);
         }
       } else if ((TV & TV_TERMS3) && K <= 6 && !LEARN && (d.flags & TILE_TERMS3)) {
         // inference, arity <= 3: both proposals' terms of every record, edge-parallel
@@ -464,7 +486,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
     int delta = 0;
     if ((TV & (TV_TERMS2_INLINE | TV_TERMS2_VIFS | TV_TERMS3)) && fits && chain_pair_tile<LEARN, K, WIDE>(d)) {
       if (t < 2u * d.nv)
-        delta = learn_variable_terms2_pair(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + (t >> 1), pre, A, B,
+        delta = learn_variable_terms2_pair(P, s_rowptr, d.r0, (const LRec *)s_edges, d.e0, s_agg, d.v0 + (t >> 1), pre, A, B,
                                            t & 1u, pull_unary);
     } else if (fits && t < d.nv) {
       TileView T{s_rowptr, d.r0, s_edges, d.e0, s_w, s_agg, P.lds_pot_off ? s_pot : nullptr};
@@ -473,7 +495,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? 3 : 1) : (LEAR
       if ((TV & TV_TERMS3) && K <= 6 && LEARN && WIDE && (d.flags & TILE_TERMS3) && (d.flags & TILE_CATEGORICAL))
         process_variable<LEARN, W_LREC, false>(P, T, d.v0 + t, pre, A, B);
       else if ((TV & TV_T23) && K <= 6 && LEARN && WIDE && (d.flags & (TILE_TERMS2 | TILE_TERMS3)))
-        delta = learn_variable_terms2(P, s_rowptr, d.r0, (const LearnRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B, pull_unary);
+        delta = learn_variable_terms2(P, s_rowptr, d.r0, (const LRec *)s_edges, d.e0, s_agg, d.v0 + t, pre, A, B, pull_unary);
       else if ((TV & TV_SIMPLE) && LEARN && pull)   // the staged records ARE terms: sgd_row is never reached (want_delta)
         delta = process_variable<LEARN, W_TERMS, true, false, NOCAT>(P, T, d.v0 + t, pre, A, B, true);
       else if (((TV & TV_SIMPLE) && (d.flags & TILE_SIMPLE)) || ((TV & TV_T23) && K <= 6 && !LEARN && (d.flags & (TILE_TERMS2 | TILE_TERMS3))))

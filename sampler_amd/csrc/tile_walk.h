@@ -82,6 +82,34 @@ struct alignas(16) LearnRec {
   uint32_t pad;
 };
 static_assert(sizeof(LearnRec) == 32, "LearnRec must be 32 bytes");
+// The same in 16 bytes, for builds whose staged tiles hold only pre-signed and arity-2 records (TV_PAIR,
+// config 3b / 5b): a binary sign is -1, 0 or +1, so the four products of an arity-2 record are its feature
+// value `a` times four 2-bit codes (sign + 1: free chain proposal 1 / 0 in bits 0-1 / 2-3, evidence chain in
+// 4-5 / 6-7 of the word in `b`); a pre-signed record keeps its two terms in a (hit) and b (miss).  Half the
+// LDS of LearnRec: four workgroups per CU instead of three (round 4).  wf: weight id | flags (W < 2^30).
+struct alignas(16) LearnRec16 {
+  uint32_t wf;
+  float w, a, b;
+};
+static_assert(sizeof(LearnRec16) == 16, "LearnRec16 must be 16 bytes");
+constexpr uint32_t LR16_PRESIGNED = 1u << 31, LR16_FIXED = 1u << 30, LR16_WID_MASK = (1u << 30) - 1u;
+// one accessor set over both forms (chain: 0 free / 1 evidence; value: the owner's proposal)
+DWX_DEV float lrec_term(const LearnRec &r, uint32_t chain, uint32_t value) {
+  return chain ? (value ? r.se1 : r.se0) : (value ? r.sf1 : r.sf0);
+}
+DWX_DEV uint32_t lrec_wid(const LearnRec &r) { return r.wid; }
+DWX_DEV bool lrec_fixed(const LearnRec &r) { return r.packed & EDGE_FIXED_FLAG; }
+DWX_DEV bool lrec_presigned(const LearnRec &r) { return r.packed & EDGE_PRESIGNED; }
+DWX_DEV float lrec_term(const LearnRec16 &r, uint32_t chain, uint32_t value) {
+  uint32_t codes;
+  __builtin_memcpy(&codes, &r.b, 4);
+  const int sign = (int)((codes >> (chain * 4u + (value ? 0u : 2u))) & 3u) - 1;
+  const float binary = (float)sign * r.a;      // (a pre-signed record's `b` is a float: this value is then unused)
+  return (r.wf & LR16_PRESIGNED) ? (value ? r.a : r.b) : binary;
+}
+DWX_DEV uint32_t lrec_wid(const LearnRec16 &r) { return r.wf & LR16_WID_MASK; }
+DWX_DEV bool lrec_fixed(const LearnRec16 &r) { return r.wf & LR16_FIXED; }
+DWX_DEV bool lrec_presigned(const LearnRec16 &r) { return r.wf & LR16_PRESIGNED; }
 // Table entry of a record of a TILE_INLINE2 tile (build_terms_kernel), overlaying an EdgeRec:
 // wf = w * |f|-signed product (f64 of two f32: exact), `other` = device position of the other
 // endpoint (the owner's for a unary record), bits: func id in 0-3; unary: TAB2_UNARY, TAB2_C1
@@ -1053,8 +1081,9 @@ DWX_DEV uint32_t compress_even_bits(unsigned long long x) {
 // pull_unary (TILE_PULL_UNARY): the pre-signed records' gradient is pulled (aux_kernels.h) from the
 // returned hit(free) - hit(evid) in {-1, 0, +1} (0 for a variable that triggers no SGD); only the
 // other records scatter.
+template <class Rec>
 DWX_DEV int learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr, uint32_t row_bias,
-                                  const LearnRec *recs, uint32_t edge_bias, long long *agg,
+                                  const Rec *recs, uint32_t edge_bias, long long *agg,
                                   uint32_t p, const VarPre pre, double A, double B, const bool pull_unary) {
   const bool is_evid = pre.meta & VM_EVIDENCE;
   const bool noise_aware = P.flags & OPT_NOISE_AWARE;
@@ -1063,15 +1092,15 @@ DWX_DEV int learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr,
   // LEARN_BATCH staged records per step (all LDS reads in flight); sums stay sequential and in
   // row order, a slot past the end adds +0.0 (cannot change a running sum)
   for (uint32_t e = es; e < ee; e += LEARN_BATCH) {
-    LearnRec r[LEARN_BATCH];
+    Rec r[LEARN_BATCH];
 #pragma unroll
     for (uint32_t u = 0; u < LEARN_BATCH; ++u) r[u] = recs[umin(e + u, ee - 1) - edge_bias];
 #pragma unroll
     for (uint32_t u = 0; u < LEARN_BATCH; ++u) {
       const bool in = e + u < ee;
       const double w = (double)r[u].w;
-      ppf += in ? w * (double)r[u].sf1 : 0.0; pnf += in ? w * (double)r[u].sf0 : 0.0;
-      ppe += in ? w * (double)r[u].se1 : 0.0; pne += in ? w * (double)r[u].se0 : 0.0;
+      ppf += in ? w * (double)lrec_term(r[u], 0u, 1u) : 0.0; pnf += in ? w * (double)lrec_term(r[u], 0u, 0u) : 0.0;
+      ppe += in ? w * (double)lrec_term(r[u], 1u, 1u) : 0.0; pne += in ? w * (double)lrec_term(r[u], 1u, 0u) : 0.0;
     }
   }
   const uint32_t p_free = bool_draw(A, ppf, pnf);
@@ -1082,16 +1111,17 @@ DWX_DEV int learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr,
   P.assign_evid[p] = p_evid;
   if (!(P.flags & OPT_LEARN_NON_EVIDENCE) && (noise_aware || !is_evid)) return 0;
   for (uint32_t e = es; e < ee; ++e) {
-    const LearnRec r = recs[e - edge_bias];
-    if (r.packed & EDGE_FIXED_FLAG) continue;
-    if (pull_unary && (r.packed & EDGE_PRESIGNED)) continue;
-    const double pot_free = (double)(p_free ? r.sf1 : r.sf0);
-    const double pot_evid = (double)(evid_value ? r.se1 : r.se0);
+    const Rec r = recs[e - edge_bias];
+    if (lrec_fixed(r)) continue;
+    if (pull_unary && lrec_presigned(r)) continue;
+    const double pot_free = (double)lrec_term(r, 0u, p_free);
+    const double pot_evid = (double)lrec_term(r, 1u, evid_value);
     const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
     long long *dst = agg ? agg : P.grad;
-    if (gi) atomicAdd((unsigned long long *)&dst[r.wid], (unsigned long long)gi);
+    const uint32_t wid = lrec_wid(r);
+    if (gi) atomicAdd((unsigned long long *)&dst[wid], (unsigned long long)gi);
     if (P.flags & OPT_DYNAMIC_T)
-      atomicAdd((unsigned long long *)&dst[P.num_weights + r.wid], (unsigned long long)(long long)FIX_SCALE);
+      atomicAdd((unsigned long long *)&dst[P.num_weights + wid], (unsigned long long)(long long)FIX_SCALE);
   }
   return (int)p_free - (int)evid_value;
 }
@@ -1100,8 +1130,9 @@ DWX_DEV int learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr,
 // each -- would leave half of the workgroup idle in this phase): lane 2j sums and draws the free
 // chain of variable j, lane 2j + 1 its evidence chain -- each sum in row order as before -- they
 // swap the free sample, and each takes every other record of the gradient walk.
+template <class Rec>
 DWX_DEV int learn_variable_terms2_pair(const KernelParams &P, const uint32_t *rowptr, uint32_t row_bias,
-                                       const LearnRec *recs, uint32_t edge_bias, long long *agg,
+                                       const Rec *recs, uint32_t edge_bias, long long *agg,
                                        uint32_t p, const VarPre pre, double A, double B, const uint32_t chain,
                                        const bool pull_unary) {
   const bool is_evid = pre.meta & VM_EVIDENCE;
@@ -1109,15 +1140,15 @@ DWX_DEV int learn_variable_terms2_pair(const KernelParams &P, const uint32_t *ro
   const uint32_t es = rowptr[pre.row0 - row_bias], ee = rowptr[pre.row0 + 1 - row_bias];
   double pp = 0.0, pn = 0.0;
   for (uint32_t e = es; e < ee; e += LEARN_BATCH) {
-    LearnRec r[LEARN_BATCH];
+    Rec r[LEARN_BATCH];
 #pragma unroll
     for (uint32_t u = 0; u < LEARN_BATCH; ++u) r[u] = recs[umin(e + u, ee - 1) - edge_bias];
 #pragma unroll
     for (uint32_t u = 0; u < LEARN_BATCH; ++u) {
       const bool in = e + u < ee;
       const double w = (double)r[u].w;
-      pp += in ? w * (double)(chain ? r[u].se1 : r[u].sf1) : 0.0;
-      pn += in ? w * (double)(chain ? r[u].se0 : r[u].sf0) : 0.0;
+      pp += in ? w * (double)lrec_term(r[u], chain, 1u) : 0.0;
+      pn += in ? w * (double)lrec_term(r[u], chain, 0u) : 0.0;
     }
   }
   const uint32_t evid_value = pre.init;
@@ -1133,16 +1164,17 @@ DWX_DEV int learn_variable_terms2_pair(const KernelParams &P, const uint32_t *ro
   const uint32_t p_free = chain == 0u ? mine : theirs;
   if (!(P.flags & OPT_LEARN_NON_EVIDENCE) && (noise_aware || !is_evid)) return 0;
   for (uint32_t e = es + chain; e < ee; e += 2u) {
-    const LearnRec r = recs[e - edge_bias];
-    if (r.packed & EDGE_FIXED_FLAG) continue;
-    if (pull_unary && (r.packed & EDGE_PRESIGNED)) continue;
-    const double pot_free = (double)(p_free ? r.sf1 : r.sf0);
-    const double pot_evid = (double)(evid_value ? r.se1 : r.se0);
+    const Rec r = recs[e - edge_bias];
+    if (lrec_fixed(r)) continue;
+    if (pull_unary && lrec_presigned(r)) continue;
+    const double pot_free = (double)lrec_term(r, 0u, p_free);
+    const double pot_evid = (double)lrec_term(r, 1u, evid_value);
     const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
     long long *dst = agg ? agg : P.grad;
-    if (gi) atomicAdd((unsigned long long *)&dst[r.wid], (unsigned long long)gi);
+    const uint32_t wid = lrec_wid(r);
+    if (gi) atomicAdd((unsigned long long *)&dst[wid], (unsigned long long)gi);
     if (P.flags & OPT_DYNAMIC_T)
-      atomicAdd((unsigned long long *)&dst[P.num_weights + r.wid], (unsigned long long)(long long)FIX_SCALE);
+      atomicAdd((unsigned long long *)&dst[P.num_weights + wid], (unsigned long long)(long long)FIX_SCALE);
   }
   return (int)p_free - (int)evid_value;   // (both lanes of the pair hold it)
 }
