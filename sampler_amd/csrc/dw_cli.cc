@@ -317,6 +317,32 @@ void load_variables(const std::vector<std::string> &files, LoadedGraph &g) {
   for (const auto &path : files) {
     Mapped m(path);
     if (m.n % 27) throw std::runtime_error(path + ": truncated variable record");
+    const uint64_t n_rec = m.n / 27;
+    // One file with exactly V records (the usual case): all host threads decode (10^8 records on one thread
+    // were 0.8 s of config 5's load).  A variable id met twice then means another one is missing -- the
+    // count check below fails as it does on the serial path, whatever the order the records were written in.
+    if (files.size() == 1 && n_rec == V && V >= (1u << 16)) {
+      const uint32_t T = dwx::host_threads();
+      std::vector<uint64_t> n_new(T, 0), n_ev(T, 0);
+      dwx::parallel_parts(n_rec, T, [&](uint32_t t, uint64_t b, uint64_t e) {
+        uint64_t fresh = 0, ev = 0;
+        for (uint64_t i = b; i < e; ++i) {
+          const uint8_t *r = m.p + i * 27;
+          const uint64_t vid = be64(r);
+          if (vid >= V) throw std::runtime_error(path + ": variable id " + std::to_string(vid) + " out of range");
+          const uint16_t dt = be16(r + 17);
+          if (dt > 1) throw std::runtime_error("[ERROR] Only Boolean and Categorical variables are supported now!");
+          g.var_role[vid] = r[8];
+          g.var_init_value[vid] = be64(r + 9);
+          g.var_dtype[vid] = dt;
+          g.var_cardinality[vid] = be64(r + 19);
+          if (!__atomic_exchange_n(&seen[vid], (uint8_t)1, __ATOMIC_RELAXED)) { ++fresh; ev += r[8] >= 1; }
+        }
+        n_new[t] = fresh; n_ev[t] = ev;
+      }, 0);
+      for (uint32_t t = 0; t < T; ++t) { count += n_new[t]; g.n_evidence += n_ev[t]; g.n_query += n_new[t] - n_ev[t]; }
+      continue;
+    }
     for (size_t off = 0; off < m.n; off += 27) {
       const uint8_t *r = m.p + off;
       uint64_t vid = be64(r);
@@ -758,10 +784,8 @@ void dump_weights_in_text(std::ostream &o, const std::vector<double> &w) {
 
 // src/inference_result.cc:211-243
 void dump_marginals_in_text(std::ostream &o, const LoadedGraph &g, bool sample_evidence,
-                            const std::vector<uint64_t> &var_val_base,
-                            const std::vector<uint64_t> &value_sparse,
-                            const std::vector<uint64_t> &tallies,
-                            const std::vector<uint64_t> &nsamples, uint64_t id_offset, uint64_t n_vars) {
+                            const uint64_t *var_val_base, const uint64_t *value_sparse,
+                            const uint64_t *tallies, const uint64_t *nsamples, uint64_t id_offset, uint64_t n_vars) {
   dump_parallel(o, std::min<uint64_t>(g.n_variables, n_vars), [&](uint64_t v, std::string &s) {
     if (g.var_role[v] >= 1 && !sample_evidence) return;
     const uint64_t b = var_val_base[v];
@@ -993,7 +1017,9 @@ int gibbs(const CmdLine &args) {
     phase("inference sweeps");
     // ---- aggregate_results_and_dump (src/dimmwitted.cc:260-277), only if -i > 0
     if (args.n_inference_epoch > 0) {
-      std::vector<uint64_t> tallies(info.num_values), nsamples(V), base(V), sparse(info.num_values);
+      // (uninitialised, first touched by the library's parallel fills: zero-filling 3.2 GB of vectors on one
+      // thread was 0.3 s at config 5's size; every entry is written -- one GPU owns every variable)
+      dwx::RawArray<uint64_t> tallies(info.num_values), nsamples(V), base(V), sparse(info.num_values);
       ok(dwx_get_tallies(sampler, tallies.data(), nsamples.data()));
       ok(dwx_graph_get_values(graph, base.data(), sparse.data()));
       auto sampled = [&](uint64_t v) { return lg.var_role[v] < 1 || args.should_sample_evidence; };
@@ -1019,7 +1045,7 @@ int gibbs(const CmdLine &args) {
       std::ofstream f(fn);
       if (!f) throw std::runtime_error("cannot write " + fn);
       phase("dwx_get_tallies");
-      dump_marginals_in_text(f, lg, args.should_sample_evidence, base, sparse, tallies, nsamples);
+      dump_marginals_in_text(f, lg, args.should_sample_evidence, base.data(), sparse.data(), tallies.data(), nsamples.data());
       f.close();
       phase("dump marginals");
       if (progress) {

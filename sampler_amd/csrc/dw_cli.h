@@ -81,10 +81,8 @@ void load_factors(const std::vector<std::string> &files, LoadedGraph &g);
 // ---- result dumps
 void dump_weights_in_text(std::ostream &o, const std::vector<double> &w);
 void dump_marginals_in_text(std::ostream &o, const LoadedGraph &g, bool sample_evidence,
-                            const std::vector<uint64_t> &var_val_base,
-                            const std::vector<uint64_t> &value_sparse,
-                            const std::vector<uint64_t> &tallies,
-                            const std::vector<uint64_t> &nsamples,
+                            const uint64_t *var_val_base, const uint64_t *value_sparse,
+                            const uint64_t *tallies, const uint64_t *nsamples,
                             uint64_t id_offset = 0, uint64_t n_vars = ~0ull);   // (a shard: local ids + offset, owned only)
 
 // graph-compile options of a run (dw_cli.cc: the weight order of the variables only for long runs)

@@ -908,8 +908,8 @@ int gibbs_multi(const CmdLine &args) {
       if (!f) throw std::runtime_error("cannot write " + fn);
       for (int r = 0; r < (replicas ? 1 : n); ++r) {
         const Shared::Result &res = sh.results[r];
-        dump_marginals_in_text(f, *res.g, args.should_sample_evidence, res.base, res.sparse, res.tallies,
-                               res.nsamples, res.id_offset, res.n_owned);
+        dump_marginals_in_text(f, *res.g, args.should_sample_evidence, res.base.data(), res.sparse.data(), res.tallies.data(),
+                               res.nsamples.data(), res.id_offset, res.n_owned);
       }
     }
     quick_exit_if_done(0);     // (the result files are written: see dw_cli.cc)

@@ -202,3 +202,46 @@ def test_factor_loader_rejects_malformed_files():
         bad[42 * 50 + 2:42 * 50 + 10] = (1 << 40).to_bytes(8, "big")
         rc, err, _ = _load_through_bin2text(t, recs, raw=bytes(bad))
         assert rc != 0 and "truncated" in err
+
+
+def test_variable_loader_parallel_path():
+    """One variable file with exactly #V >= 65 536 records is decoded by all host threads (dw_cli.cc,
+    load_variables): shuffled ids, roles, initial values and cardinalities come back exactly (through
+    `dw bin2text`'s variables.tsv); an id met twice -- another one is then missing -- is rejected as on the
+    serial path."""
+    import struct
+    import numpy as np
+    rng = np.random.default_rng(5)
+    n = 70_000
+    ids = rng.permutation(n)
+    role = rng.integers(0, 2, n)
+    dtype = rng.integers(0, 2, n)
+    card = np.where(dtype == 1, rng.integers(2, 7, n), 2)
+    init = np.where(role == 1, rng.integers(0, 1 << 30, n) % card, 0)
+
+    def write(tmp, id_list):
+        open(os.path.join(tmp, "graph.meta"), "w").write("1,%d,1,1" % n)
+        open(os.path.join(tmp, "graph.variables"), "wb").write(
+            b"".join(struct.pack(">QBQHQ", int(v), int(role[v]), int(init[v]), int(dtype[v]), int(card[v])) for v in id_list))
+        open(os.path.join(tmp, "graph.weights"), "wb").write(struct.pack(">QBd", 0, 0, 0.0))
+        open(os.path.join(tmp, "graph.factors"), "wb").write(_factor_bytes([(4, [(0, 1)], 0, 1.0)]))
+        out = os.path.join(tmp, "txt")
+        os.makedirs(out, exist_ok=True)
+        return subprocess.run([DW, "bin2text", "-m", os.path.join(tmp, "graph.meta"), "-v", os.path.join(tmp, "graph.variables"),
+                               "-w", os.path.join(tmp, "graph.weights"), "-f", os.path.join(tmp, "graph.factors"), "-o", out],
+                              capture_output=True, text=True), out
+
+    with tempfile.TemporaryDirectory() as t:
+        r, out = write(t, ids)
+        assert r.returncode == 0, r.stderr
+        lines = open(os.path.join(out, "variables.tsv")).read().splitlines()
+        assert len(lines) == n
+        for v in list(range(0, n, 997)) + [n - 1]:
+            cols = lines[v].split("\t")
+            assert int(cols[0]) == v and int(cols[1]) == role[v] and int(cols[3]) == dtype[v] and int(cols[4]) == card[v]
+            assert int(cols[2]) == (init[v] if role[v] else 0)
+    with tempfile.TemporaryDirectory() as t:
+        twice = ids.copy()
+        twice[123] = twice[456]          # (one id twice, one missing: still #V records)
+        r, _ = write(t, twice)
+        assert r.returncode != 0 and "variable count" in r.stderr
