@@ -48,10 +48,25 @@ inline void check(hipError_t e, const char *what) {
 // 1 ms, or in 1.08 s after two rounds of free), which made `dw gibbs` on config 5's size vary by seconds from
 // run to run.  A block serves any later request it is large enough for (smallest fit); release_scratch()
 // really frees the idle ones.  Small requests (< 1 MiB) go to hipMalloc / hipFree as before.
+}  // namespace
+void release_scratch(int device, bool only_if_tight);
+namespace {
 constexpr size_t SCRATCH_MIN = (size_t)1 << 20;
 struct ScratchBlock { void *p; size_t bytes; int device; bool busy; };
 std::mutex g_scratch_mu;
 std::vector<ScratchBlock> g_scratch;
+
+// a persistent output of a build: plain hipMalloc, the idle cache blocks given back once if that fails
+hipError_t output_malloc(void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) release_scratch(dev, false);
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
 
 void *scratch_take(size_t bytes) {
   bytes = std::max<size_t>(16, bytes);
@@ -65,7 +80,12 @@ void *scratch_take(size_t bytes) {
     if (best) { best->busy = true; return best->p; }
   }
   void *p = nullptr;
-  DEVB_HIP(hipMalloc(&p, bytes));
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    // out of device memory with idle blocks in the cache that are all too small: give them back, once
+    (void)hipGetLastError();
+    release_scratch(dev, false);
+    DEVB_HIP(hipMalloc(&p, bytes));
+  }
   if (bytes >= SCRATCH_MIN) {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     g_scratch.push_back({p, bytes, dev, true});
@@ -674,7 +694,7 @@ void build_incidence(const TileDesc *d_tiles, const TileDesc *h_tiles, uint32_t 
         if (!depth[k] || !nvb) continue;
         const uint64_t g0 = c_start[k], g1 = c_start[k + 1];
         hipLaunchKernelGGL(weight_start_kernel, dim3(wgrid), dim3(256), 0, st, keys, g0, g1, k, W, d_wat);
-        DEVB_HIP(hipMalloc(&ell_now, nvb * depth[k] * Wp * sizeof(U32x4)));
+        DEVB_HIP(output_malloc((void **)&ell_now, nvb * depth[k] * Wp * sizeof(U32x4)));
         DEVB_HIP(hipMemsetAsync(ell_now, 0xFF, nvb * depth[k] * Wp * sizeof(U32x4), st));
         hipLaunchKernelGGL(ell_walk_kernel<true>, dim3(wgrid), dim3(256), 0, st, vals, g0, (const uint32_t *)d_wat, W,
                            (const uint32_t *)d_block_of, (const uint32_t *)(d_tile0 + tile0_off[k]), depth[k], Wp,
@@ -716,7 +736,8 @@ void build_incidence(const TileDesc *d_tiles, const TileDesc *h_tiles, uint32_t 
     for (uint32_t k = 0; k < n_groups; ++k) off[k + 1] = off[k] + (kept_n[k] + PULL_RUN - 1) / PULL_RUN * PULL_RUN;
     const uint64_t padded = off[n_groups];
     if (padded) {
-      DEVB_HIP(hipMalloc(&out.d_inc_wid, padded * 4)); DEVB_HIP(hipMalloc(&out.d_inc_slot, padded * 4)); DEVB_HIP(hipMalloc(&out.d_inc_d, padded * 4));
+      DEVB_HIP(output_malloc((void **)&out.d_inc_wid, padded * 4)); DEVB_HIP(output_malloc((void **)&out.d_inc_slot, padded * 4));
+      DEVB_HIP(output_malloc((void **)&out.d_inc_d, padded * 4));
       for (uint32_t k = 0; k < n_groups; ++k) {
         out.inc_begin[k] = (uint32_t)off[k]; out.inc_end[k] = (uint32_t)off[k + 1];
         const uint64_t pn = off[k + 1] - off[k];

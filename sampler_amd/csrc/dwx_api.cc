@@ -1725,6 +1725,7 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
   std::unique_ptr<dwx_sampler> s(new dwx_sampler());
   int rc = guarded([&]() {
     rt::init_device(opts->device);
+    rt::oom_hook() = [](int dev) { devb::release_scratch(dev, false); };
     s->cg = g->cg;
     s->opts = *opts;
     s->device = opts->device;
@@ -2027,6 +2028,7 @@ int dwx_buffer_copy(dwx_sampler *s, void *dst, const void *src, uint64_t nbytes,
 int dwx_device_init(int32_t device) {
   return guarded([&]() {
     rt::init_device(device);
+    rt::oom_hook() = [](int dev) { devb::release_scratch(dev, false); };
     rt::dfree(rt::dmalloc(16));   // forces the context
   });
 }

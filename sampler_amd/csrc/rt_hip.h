@@ -38,9 +38,22 @@ inline int device_count() {
   return n;
 }
 
+// (what to try once when the device is out of memory: dwx_api.cc points it at the device builds' block cache,
+// whose idle blocks are the library's own to give back)
+inline void (*&oom_hook())(int) {
+  static void (*hook)(int) = nullptr;
+  return hook;
+}
 inline void *dmalloc(size_t n) {
   void *p = nullptr;
-  DWX_HIP(hipMalloc(&p, n ? n : 16));
+  hipError_t e = hipMalloc(&p, n ? n : 16);
+  if (e != hipSuccess && oom_hook()) {
+    (void)hipGetLastError();
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) oom_hook()(dev);
+    e = hipMalloc(&p, n ? n : 16);
+  }
+  DWX_HIP(e);
   return p;
 }
 inline void dfree(void *p) { if (p) (void)hipFree(p); }

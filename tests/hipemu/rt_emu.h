@@ -22,6 +22,10 @@ inline void init_device(int dev) {
 }
 inline void set_device(int) {}
 inline int device_count() { return 1; }
+inline void (*&oom_hook())(int) {
+  static void (*hook)(int) = nullptr;
+  return hook;
+}
 inline void *dmalloc(size_t n) { return malloc(n ? n : 16); }
 inline void dfree(void *p) { free(p); }
 inline void h2d(void *d, const void *h, size_t n, stream_t) { if (n) memcpy(d, h, n); }

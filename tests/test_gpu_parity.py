@@ -64,6 +64,35 @@ def test_synth_exact(lib):
                stepsize=0.001)
 
 
+def test_device_build_scratch_is_given_back(lib):
+    """The device builds take their large temporaries from a block cache instead of hipMalloc / hipFree
+    (device_build.hip: a hipFree of gigabytes is paid by a later hipMalloc).  The cache must not grow
+    with the number of samplers built, and destroying the samplers must return the device to where it was:
+    five create / sweep / destroy rounds on a 1.2 M-variable graph (120 MB of sort buffers each)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")      # (the runtime the library itself is linked against)
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    raw = synthetic.cfg3(1_200_000, n_weights=150_000, seed=22)
+    g = dwx.Graph(raw, lib=lib)
+    s = dwx.GibbsSampler(g, seed=3)          # (context, kernels, the runtime's own pools: before the baseline)
+    s.close()
+    free0 = free_bytes()
+    held = []
+    for _ in range(5):
+        s = dwx.GibbsSampler(g, seed=3)
+        s.sample_sgd(0.01); s.sample(); s.wait()
+        held.append(free0 - free_bytes())
+        s.close()
+    free1 = free_bytes()
+    assert max(held) - min(held) < (64 << 20), held          # every round holds the same: blocks are reused
+    assert abs(free0 - free1) < (64 << 20), (free0, free1)   # ... and all of it comes back
+
+
 def test_device_built_sorted_records_equal_the_host_builder(lib, monkeypatch):
     """The weight-sorted copy of the records is built on the device (device_build.hip: ordered emit +
     radix sort by (super-tile, weight id)) from the uploaded columns; the host builder
