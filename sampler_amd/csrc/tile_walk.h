@@ -1119,7 +1119,9 @@ DWX_DEV int learn_variable_terms2(const KernelParams &P, const uint32_t *rowptr,
     const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
     long long *dst = agg ? agg : P.grad;
     const uint32_t wid = lrec_wid(r);
+#ifndef DWX_EXP_NOSCATTER   // (experiment: what the pairwise records' gradient atomics cost -- profiles/r04/v3/)
     if (gi) atomicAdd((unsigned long long *)&dst[wid], (unsigned long long)gi);
+#endif
     if (P.flags & OPT_DYNAMIC_T)
       atomicAdd((unsigned long long *)&dst[P.num_weights + wid], (unsigned long long)(long long)FIX_SCALE);
   }
@@ -1172,7 +1174,9 @@ DWX_DEV int learn_variable_terms2_pair(const KernelParams &P, const uint32_t *ro
     const long long gi = llrint(FIX_SCALE * (pot_free - pot_evid));
     long long *dst = agg ? agg : P.grad;
     const uint32_t wid = lrec_wid(r);
+#ifndef DWX_EXP_NOSCATTER   // (experiment: what the pairwise records' gradient atomics cost -- profiles/r04/v3/)
     if (gi) atomicAdd((unsigned long long *)&dst[wid], (unsigned long long)gi);
+#endif
     if (P.flags & OPT_DYNAMIC_T)
       atomicAdd((unsigned long long *)&dst[P.num_weights + wid], (unsigned long long)(long long)FIX_SCALE);
   }
