@@ -199,6 +199,16 @@ def _port_epochs(raw, stepsize, decay, reg, n_learn, n_infer):
     return tl, ti
 
 
+def cpu_quota_cores():
+    """CPUs' worth of CPU time the cgroup grants this process (cpu.max), or None: the box reports its 256
+    hardware threads whatever the quota, and the reference spawns a thread for each."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else round(int(quota) / int(period), 2)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(raw, stepsize, decay, reg, what, smaller, timeout=420):
     """Time the CPU side on `raw` -- 3 learning + 10 inference epochs on all host cores, the
     epoch loops the step of this bench stands for (src/dimmwitted.cc:143-154, 191-236) -- with the
@@ -209,6 +219,8 @@ def cpu_baseline(raw, stepsize, decay, reg, what, smaller, timeout=420):
     cores = os.cpu_count() or 1
     sample = what + "; 3 learning + 10 inference epochs, all host cores; value = 2V / (median learn epoch + median inference epoch)"
     extra = {"sample_is_smaller": bool(smaller)}
+    if cpu_quota_cores() is not None:
+        extra["cpu_quota_cores"] = cpu_quota_cores()   # (`cores` threads share this much CPU time)
     if smaller:
         extra["note"] = ("a smaller graph than the GPU's (its tables sit higher in the CPU's caches: "
                          "conservative for the CPU); the GPU/CPU ratio is not like-for-like")

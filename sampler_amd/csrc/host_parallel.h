@@ -7,6 +7,7 @@
 
 #include <stdint.h>
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <sys/mman.h>
 
@@ -19,15 +20,41 @@
 
 namespace dwx {
 
-// threads for the host-side setup work: the caller's request, else DWX_HOST_THREADS, else
-// the hardware concurrency capped at 64
+// CPUs' worth of CPU time this process may use (cgroup v2 cpu.max, v1 cfs quota), rounded up; 0 = no limit
+// found.  A container on a 256-thread host with a quota of 16 reports 256 hardware threads: 64 setup threads
+// there are throttled as a group -- `dw gibbs` on config 5's files took 13.8-14.6 s with 64 threads, 12.3-13.0
+// with 24-32 (profiles/r04/e2e_threads.json).
+inline uint32_t cgroup_cpu_quota() {
+  static const uint32_t quota = []() -> uint32_t {
+    long long q = 0, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char first[64] = {0};
+      const int n = fscanf(f, "%63s %lld", first, &period);
+      fclose(f);
+      if (n == 2 && first[0] != 'm') q = atoll(first);
+    } else {
+      if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &q) != 1) q = 0; fclose(fq); }
+      if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+    }
+    if (q <= 0 || period <= 0) return 0u;
+    return (uint32_t)std::min<long long>((q + period - 1) / period, 4096);
+  }();
+  return quota;
+}
+
+// threads for the host-side setup work: the caller's request, else DWX_HOST_THREADS, else the hardware
+// concurrency capped at 64 -- and at twice the cgroup's CPU quota where there is one (the phases stall on page
+// faults and on each other: two threads per granted CPU measured best over both sizes -- config 3: 1.34-1.52 s
+// with 32 threads, 1.45-1.53 with 64, 1.56-1.79 with 24 at a quota of 16)
 inline uint32_t host_threads(uint32_t requested = 0) {
   if (requested) return std::min(requested, 256u);
   if (const char *e = getenv("DWX_HOST_THREADS")) {
     const long v = atol(e);
     if (v > 0) return (uint32_t)std::min(v, 256L);
   }
-  return std::min(std::max(1u, std::thread::hardware_concurrency()), 64u);
+  uint32_t n = std::min(std::max(1u, std::thread::hardware_concurrency()), 64u);
+  if (const uint32_t q = cgroup_cpu_quota()) n = std::min(n, std::max(1u, 2 * q));
+  return n;
 }
 
 // Give the pages of a large private mapping back from several threads, then unmap it.  Freeing is not
