@@ -77,7 +77,8 @@ typedef struct dwx_compile_opts {
   uint32_t conflict_arity_cap; /* factors wider than this do not constrain the
                                   colouring (Hogwild reads, as in the reference);
                                   default 256                                          */
-  uint32_t n_threads;          /* host threads for the build (0 = all cores)           */
+  uint32_t n_threads;          /* host threads for the build (0 = DWX_HOST_THREADS, else the hardware
+                                  concurrency capped at 64 and at twice the cgroup's CPU quota)  */
   uint32_t no_compact_records; /* 1: keep 16-byte records even for all-unary graphs
                                   (default 0: such graphs stream 8-byte records)       */
   uint32_t no_weight_order;    /* 1: keep variables in id order inside a class (default 0: an
@@ -210,6 +211,8 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
 int dwx_device_init(int32_t device);
 /* Number of usable HIP devices (0 without a GPU: not an error). */
 int dwx_device_count(int32_t *count);
+/* Frees the sampler's device buffers and hands the device builds' idle scratch blocks (sort buffers
+ * kept in a cache inside the library: INTEGRATION.md, "Device memory a caller may notice") back to the runtime. */
 void dwx_sampler_destroy(dwx_sampler *s);
 
 /* GibbsSampler::sample(i_epoch) (src/gibbs_sampler.cc:20-25): one inference sweep. */
