@@ -40,12 +40,14 @@ struct CompiledGraph {
   RawArray<uint32_t> ref_fidx;             // [NIdx] factor ids, reference order
 
   // ---- device order ----
-  std::vector<uint32_t> perm;      // [V] position -> original variable id
-  std::vector<uint32_t> pos;       // [V] original id -> position
-  std::vector<uint32_t> v_meta;    // [V]
-  std::vector<uint32_t> v_init;    // [V]
-  std::vector<uint32_t> v_row;     // [V+1]
-  std::vector<uint32_t> row_ptr;   // [R+1]
+  // (uninitialised storage, first touched by the parallel fills: six serial zero-fills of 400 MB each at
+  // config 5's size otherwise)
+  RawArray<uint32_t> perm;         // [V] position -> original variable id
+  RawArray<uint32_t> pos;          // [V] original id -> position
+  RawArray<uint32_t> v_meta;       // [V]
+  RawArray<uint32_t> v_init;       // [V]
+  RawArray<uint32_t> v_row;        // [V+1]
+  RawArray<uint32_t> row_ptr;      // [R+1]
   std::vector<double> row_truth;   // [R] or empty
   RawArray<EdgeRec> edges;         // [NIdx] (uninitialised storage: first touch inside the parallel fill)
   RawArray<EdgeRec8> edges8;       // [NIdx] when every tile is TILE_SIMPLE (and W < 2^27), else empty
