@@ -1492,7 +1492,16 @@ bool enqueue_merged_sweep(dwx_sampler *s) {
       sp.a = rt::event_create(); sp.b = rt::event_create(); sp.c = rt::event_create(); sp.kind = 1;
       rt::event_record(sp.a, s->stream);
     }
-    if (ch.t1 > ch.t0) {
+    if (ch.t1 > ch.t0 && ch.t1 - ch.t0 <= cap && !getenv("DWX_NO_ONE_TILE")) {
+      // a workgroup per tile (the usual shape of a mini-batch): the build without the next-tile machinery
+      const unsigned grid = ch.t1 - ch.t0;
+      if (s->rp_cat) rt::launch(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL_CAT, true>, grid, BLOCK_THREADS, s->lds_merge, s->stream, P, M);
+      else switch (s->stage_k) {
+        case 3: rt::launch(sweep8_merged_kernel<3, (int)ROWPTR_UNROLL, true>, grid, BLOCK_THREADS, s->lds_merge, s->stream, P, M); break;
+        case 6: rt::launch(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL, true>, grid, BLOCK_THREADS, s->lds_merge, s->stream, P, M); break;
+        default: rt::launch(sweep8_merged_kernel<12, (int)ROWPTR_UNROLL, true>, grid, BLOCK_THREADS, s->lds_merge, s->stream, P, M); break;
+      }
+    } else if (ch.t1 > ch.t0) {
       const unsigned grid = std::min<unsigned>(ch.t1 - ch.t0, cap);
       if (s->rp_cat) rt::launch(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL_CAT>, grid, BLOCK_THREADS, s->lds_merge, s->stream, P, M);
       else switch (s->stage_k) {
@@ -1943,11 +1952,16 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
       s->lds_merge = s->merge_lw32_off + (size_t)c.W * 4 + 16;
       s->merge_ok = s->lds_merge <= 160 * 1024;
       if (s->merge_ok) {
-        if (s->rp_cat) rt::allow_dynamic_lds(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL_CAT>, s->lds_merge);
-        else switch (s->stage_k) {
-          case 3: rt::allow_dynamic_lds(sweep8_merged_kernel<3, (int)ROWPTR_UNROLL>, s->lds_merge); break;
-          case 6: rt::allow_dynamic_lds(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL>, s->lds_merge); break;
-          default: rt::allow_dynamic_lds(sweep8_merged_kernel<12, (int)ROWPTR_UNROLL>, s->lds_merge); break;
+        if (s->rp_cat) {
+          rt::allow_dynamic_lds(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL_CAT>, s->lds_merge);
+          rt::allow_dynamic_lds(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL_CAT, true>, s->lds_merge);
+        } else switch (s->stage_k) {
+          case 3: rt::allow_dynamic_lds(sweep8_merged_kernel<3, (int)ROWPTR_UNROLL>, s->lds_merge);
+                  rt::allow_dynamic_lds(sweep8_merged_kernel<3, (int)ROWPTR_UNROLL, true>, s->lds_merge); break;
+          case 6: rt::allow_dynamic_lds(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL>, s->lds_merge);
+                  rt::allow_dynamic_lds(sweep8_merged_kernel<6, (int)ROWPTR_UNROLL, true>, s->lds_merge); break;
+          default: rt::allow_dynamic_lds(sweep8_merged_kernel<12, (int)ROWPTR_UNROLL>, s->lds_merge);
+                   rt::allow_dynamic_lds(sweep8_merged_kernel<12, (int)ROWPTR_UNROLL, true>, s->lds_merge); break;
         }
       }
     }

@@ -167,24 +167,28 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 1) persist_learn8_kernel(const 
 // its neighbours may still be reading the old ones) and zeroes the buffer the next mini-batch will add
 // into (three gradient buffers in turn).  A dependent launch costs ~4 us here whatever it does
 // (profiles/r04/v5): 64 of them less per sweep of config 4.  Bit for bit the two-launch path.
-template <int K, int RP>
+// The update runs once the tile's own loads are in flight (they need no weight): its few loads return under the
+// record stream's instead of ahead of it.  ONE: the launch has a workgroup per tile (sweep8_body).
+template <int K, int RP, bool ONE = false>
 __global__ void __launch_bounds__(BLOCK_THREADS, DWX_S8_LEARN_WG) sweep8_merged_kernel(const KernelParams P, const MergeArgs M) {
   DWX_DYN_LDS(dyn_lds);
   float *s_lw32 = (float *)(dyn_lds + M.lds_lw32_off);
-  const uint32_t W = P.num_weights;
-  for (uint32_t i = threadIdx.x; i < W; i += BLOCK_THREADS) {
-    double x = M.w_src[i];
-    if (M.prev_grad) {
-      x = apply_value(x, M.w_fixed[i] != 0, M.t_static, M.t_static ? M.t_static + W : nullptr, i, M.prev_grad[i],
-                      M.prev_grad[W + i], M.stepsize, M.reg_param, M.l2);
-      if (blockIdx.x == 0) { M.w_dst[i] = x; M.w32_dst[i] = (float)x; }
+  auto update = [&]() {
+    const uint32_t W = P.num_weights;
+    for (uint32_t i = threadIdx.x; i < W; i += BLOCK_THREADS) {
+      double x = M.w_src[i];
+      if (M.prev_grad) {
+        x = apply_value(x, M.w_fixed[i] != 0, M.t_static, M.t_static ? M.t_static + W : nullptr, i, M.prev_grad[i],
+                        M.prev_grad[W + i], M.stepsize, M.reg_param, M.l2);
+        if (blockIdx.x == 0) { M.w_dst[i] = x; M.w32_dst[i] = (float)x; }
+      }
+      s_lw32[i] = (float)x;
     }
-    s_lw32[i] = (float)x;
-  }
-  if (blockIdx.x == 0 && M.zero)
-    for (uint32_t i = threadIdx.x; i < 2u * W; i += BLOCK_THREADS) M.zero[i] = 0;
-  __syncthreads();
-  sweep8_body<true, K, false, RP, false, true>(P, s_lw32);
+    if (blockIdx.x == 0 && M.zero)
+      for (uint32_t i = threadIdx.x; i < 2u * W; i += BLOCK_THREADS) M.zero[i] = 0;
+    __syncthreads();
+  };
+  sweep8_body<true, K, false, RP, false, true, ONE, decltype(update)>(P, s_lw32, update);
 }
 
 }  // namespace dwx

@@ -564,8 +564,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS, WIDE ? (K <= 6 ? ((TV & TV_TERM
 // and every variable is drawn n_sweeps times (infer_variable_multi, tile_walk.h).
 // LW (sweep8_merged_kernel, persist_kernels.h): the weight gathers read lw32, the workgroup's own LDS copy
 // of the f32 weights, instead of P.w32.
-template <bool LEARN, int K, bool TAB = false, int RP = (int)ROWPTR_UNROLL, bool MULTI = false, bool LW = false>
-DWX_DEV void sweep8_body(const KernelParams &P, const float *lw32) {
+// ONE (sweep8_merged_kernel when the launch has a workgroup per tile -- a mini-batch of a split sweep): no next
+// tile, so no descriptor ahead, no prefetch of a tile that does not exist, no loop.
+// Pre: work of the caller's that needs no tile data, run once the first tile's loads are in flight (the merged
+// kernel's weight update: its own loads then return under the record stream's instead of before it).
+struct NoPrologue { DWX_DEV void operator()() const {} };
+template <bool LEARN, int K, bool TAB = false, int RP = (int)ROWPTR_UNROLL, bool MULTI = false, bool LW = false,
+          bool ONE = false, class Pre = NoPrologue>
+DWX_DEV void sweep8_body(const KernelParams &P, const float *lw32, Pre pre_fn = Pre()) {
   static_assert(!(LEARN && TAB), "the terms table serves inference sweeps only");
   static_assert(!MULTI || (!LEARN && !TAB), "several sweeps per launch: the gathering inference build");
   static_assert(!LW || (LEARN && !TAB && !MULTI), "LDS weights: the learning build");
@@ -577,14 +583,15 @@ DWX_DEV void sweep8_body(const KernelParams &P, const float *lw32) {
   long long *s_agg = (LEARN && P.lds_agg_off) ? (long long *)(dyn_lds + P.lds_agg_off) : nullptr;
   const uint32_t t = threadIdx.x;
   uint32_t tile = P.tile_begin + blockIdx.x;
-  if (tile >= P.tile_end) return;
+  if (tile >= P.tile_end) { pre_fn(); return; }   // (workgroup-uniform)
   const uint32_t stride = gridDim.x;
   TileDesc d = scalarise(P.tiles[tile]);
   uint32_t next = tile + stride;
-  bool has_next = next < P.tile_end;
-  TileDesc dn = scalarise(P.tiles[has_next ? next : tile]);   // one descriptor ahead
+  bool has_next = !ONE && next < P.tile_end;
+  TileDesc dn = ONE ? d : scalarise(P.tiles[has_next ? next : tile]);   // one descriptor ahead
   TilePrefetch<K, EdgeRec8, RP> f;
   issue_tile_loads<LEARN, K, !TAB>(P, d, t, f);
+  pre_fn();
   if (s_agg) {   // the first __syncthreads of the loop orders this before any use
     for (uint32_t i = t; i < 2 * P.num_weights; i += BLOCK_THREADS) s_agg[i] = 0;
   }
@@ -660,10 +667,13 @@ DWX_DEV void sweep8_body(const KernelParams &P, const float *lw32) {
     // ahead, then the next tile's records / row pointers / variable inputs
     const uint32_t nn = next + stride;
     const bool has_nn = has_next && nn < P.tile_end;
-    const TileDesc raw_nn = P.tiles[has_nn ? nn : tile];
-    TileDesc dl = dn;
-    if (!has_next) { dl.nedges = 0; dl.nrows = 0; dl.nv = 1; }
-    issue_tile_loads<LEARN, K, !TAB>(P, dl, t, f);
+    TileDesc raw_nn = d;
+    if (!ONE) {
+      raw_nn = P.tiles[has_nn ? nn : tile];
+      TileDesc dl = dn;
+      if (!has_next) { dl.nedges = 0; dl.nrows = 0; dl.nv = 1; }
+      issue_tile_loads<LEARN, K, !TAB>(P, dl, t, f);
+    }
     // the current tile out of LDS
     int delta = 0;
     if (MULTI) {
@@ -699,7 +709,7 @@ DWX_DEV void sweep8_body(const KernelParams &P, const float *lw32) {
         DWX_NT_STORE(nz, &wd[0]); DWX_NT_STORE(ng, &wd[1]);
       }
     }
-    if (!has_next) break;
+    if (ONE || !has_next) break;
     __syncthreads();   // LDS is rewritten by the next iteration
     d = dn;
     dn = scalarise(raw_nn);
