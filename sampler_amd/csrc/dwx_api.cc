@@ -1469,8 +1469,40 @@ bool enqueue_merged_sweep(dwx_sampler *s) {
   s->d_gbuf[0] = s->d_grad;
   if (s->plan_level) ++s->plan_level->sweeps;
   const unsigned cap = s->persistent_blocks8[1];
+  // The leading tiles of the first mini-batch in which NOTHING learns -- the query part of the colour launch:
+  // half of config 4's tiles, 190 us of bandwidth work at the head of 63 latency-bound launches of 16 us -- run
+  // beside the mini-batches instead of ahead of them: on a side stream, one workgroup per CU (the mini-batches'
+  // workgroups keep the other two slots of every CU).  They read the sweep's starting weights -- the sampler's
+  // own arrays, which no merged launch writes; the closing update waits for them -- add nothing to any gradient
+  // (flush_accumulators skips zeros) and, on an all-unary graph, nobody reads their samples: the same results.
+  uint32_t quiet_end = s->plan_chunks[0].t0;
+  if (s->side[0] && s->ev_fork && s->ev_join[0] && !getenv("DWX_NO_QUIET_ASIDE")) {
+    const dwx_sampler::Chunk &c0 = s->plan_chunks[0];
+    while (quiet_end < c0.t1 && quiet_end + 1 < s->sgd_work.size() && s->sgd_work[quiet_end + 1] == s->sgd_work[quiet_end]) ++quiet_end;
+    if (quiet_end - c0.t0 < 4 * rt::grid_barrier_blocks()) quiet_end = c0.t0;   // (too few to be worth a launch)
+  }
+  const bool aside = quiet_end > s->plan_chunks[0].t0;
+  if (aside) {
+    KernelParams Q = s->base;
+    Q.sweep = s->sweep;
+    Q.tile_begin = s->plan_chunks[0].t0; Q.tile_end = quiet_end;
+    rt::event_record(s->ev_fork, s->stream);
+    rt::stream_wait_event(s->side[0], s->ev_fork);
+    unsigned side_wgs = std::max(1u, rt::grid_barrier_blocks());
+    if (const char *e = getenv("DWX_QUIET_GRID")) side_wgs = (unsigned)std::max(1L, atol(e));   // (tuning knob)
+    const unsigned grid = std::min<unsigned>(quiet_end - Q.tile_begin, side_wgs);
+    const size_t lds = s->lds_bytes[1];
+    if (s->rp_cat) rt::launch(sweep8_kernel<true, 6, false, (int)ROWPTR_UNROLL_CAT>, grid, BLOCK_THREADS, lds, s->side[0], Q);
+    else switch (s->stage_k) {
+      case 3: rt::launch(sweep8_kernel<true, 3>, grid, BLOCK_THREADS, lds, s->side[0], Q); break;
+      case 6: rt::launch(sweep8_kernel<true, 6>, grid, BLOCK_THREADS, lds, s->side[0], Q); break;
+      default: rt::launch(sweep8_kernel<true, 12>, grid, BLOCK_THREADS, lds, s->side[0], Q); break;
+    }
+    rt::event_record(s->ev_join[0], s->side[0]);
+  }
   for (uint32_t ci = 0; ci < n; ++ci) {
-    const dwx_sampler::Chunk &ch = s->plan_chunks[ci];
+    dwx_sampler::Chunk ch = s->plan_chunks[ci];
+    if (ci == 0) ch.t0 = quiet_end;
     s->cur_chunk = ci;
     KernelParams P = s->base;
     P.sweep = s->sweep;
@@ -1527,6 +1559,7 @@ bool enqueue_merged_sweep(dwx_sampler *s) {
     }
   }
   // the last mini-batch's update: from the weights the last merged launch wrote, into the sampler's own arrays
+  if (aside) rt::stream_wait_event(s->stream, s->ev_join[0]);   // (the quiet tiles still read those arrays)
   {
     const uint32_t last = n - 1;
     const unsigned grid = std::min<unsigned>((W + BLOCK_THREADS - 1) / BLOCK_THREADS, 2048u);
