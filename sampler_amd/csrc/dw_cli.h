@@ -85,7 +85,7 @@ void dump_marginals_in_text(std::ostream &o, const LoadedGraph &g, bool sample_e
                             const uint64_t *tallies, const uint64_t *nsamples,
                             uint64_t id_offset = 0, uint64_t n_vars = ~0ull);   // (a shard: local ids + offset, owned only)
 
-// the same two dumps straight into a file, copied in by all host threads (the single-GPU `dw gibbs`)
+// the same two dumps straight into a file (the single-GPU `dw gibbs`)
 void dump_weights_to_file(const std::string &path, const std::vector<double> &w);
 void dump_marginals_to_file(const std::string &path, const LoadedGraph &g, bool sample_evidence,
                             const uint64_t *var_val_base, const uint64_t *value_sparse,
