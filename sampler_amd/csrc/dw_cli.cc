@@ -921,8 +921,9 @@ void quick_exit_if_done(int exit_code) {
   std::cout.flush();
   std::cerr.flush();
   fflush(nullptr);
-  // (measured and dropped: handing the remaining host arrays' pages back from all threads first cost 1.1 s at
-  // config 5's size and took 0.4 s off the exit)
+  // the pages of every large host array, handed back by all threads (the exit would clear them on one core;
+  // this only pays since the uploads are staged -- rt_hip.h -- and the arrays' pages therefore ordinary ones)
+  if (!getenv("DWX_NO_EXIT_DROP")) dwx::mapping_registry_drop_all();   // (A/B knob)
   if (getenv("DWX_TIMING")) {
     fprintf(stderr, "[dw timing] teardown (device + graph): skipped (process exit)\n");
     // (tools/e2e_walltime.py: what the process exit itself costs = the caller's clock - this)

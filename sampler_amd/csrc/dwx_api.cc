@@ -2051,6 +2051,8 @@ int dwx_sampler_create(const dwx_graph *g, const dwx_options *opts, dwx_sampler 
     if (opts->step_cap > 0) (void)row_sum_bound(s.get(), 1);
     phase("curvature estimate");
     devb::release_scratch(s->device, true);   // (the builds' cached temporaries: kept unless memory is tight)
+    rt::stream_sync(st);
+    rt::stage_trim();                          // (the uploads' pinned staging chunks)
   });
   if (rc != DWX_OK) return rc;
   *out = s.release();

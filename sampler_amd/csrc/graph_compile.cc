@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
 #include <thread>
@@ -1011,6 +1012,46 @@ void compile_graph(const dwx_graph_desc &d, const dwx_compile_opts &o, CompiledG
     *limit = true;
     throw;
   }
+}
+
+// ---------------------------------------------------------------- registry of large host mappings
+// (host_parallel.h: RawArray registers its direct mappings here)
+namespace {
+std::mutex g_map_mu;
+std::vector<std::pair<void *, size_t>> g_maps;
+}  // namespace
+
+void mapping_registry_add(void *p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_map_mu);
+  g_maps.emplace_back(p, bytes);
+}
+
+void mapping_registry_remove(void *p) {
+  std::lock_guard<std::mutex> lk(g_map_mu);
+  for (size_t i = 0; i < g_maps.size(); ++i)
+    if (g_maps[i].first == p) { g_maps[i] = g_maps.back(); g_maps.pop_back(); return; }
+}
+
+void mapping_registry_drop_all() {
+  std::vector<std::pair<void *, size_t>> maps;
+  {
+    std::lock_guard<std::mutex> lk(g_map_mu);
+    maps = g_maps;
+  }
+  constexpr size_t kStep = (size_t)64 << 20;
+  struct Step { char *p; size_t n; };
+  std::vector<Step> steps;
+  for (const auto &m : maps)
+    for (size_t off = 0; off < m.second; off += kStep) steps.push_back({(char *)m.first + off, std::min(kStep, m.second - off)});
+  const uint32_t T = (uint32_t)std::min<size_t>(std::min(host_threads(), 32u), steps.size() / 4);
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    for (size_t i; (i = next.fetch_add(1)) < steps.size();) madvise(steps[i].p, steps[i].n, MADV_DONTNEED);
+  };
+  std::vector<std::thread> th;
+  for (uint32_t t = 1; t < T; ++t) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
 }
 
 }  // namespace dwx

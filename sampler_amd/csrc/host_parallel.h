@@ -80,6 +80,15 @@ inline void unmap_parallel(void *p, size_t bytes) {
   munmap(p, bytes);
 }
 
+// The live large mappings of every RawArray in the process (graph_compile.cc holds the list: one copy, in the
+// library, for its own arrays and its callers').  A run that is DONE and leaves through _Exit (dw_cli.cc:
+// quick_exit_if_done) hands all of their pages back from all threads first -- the exit itself clears them on
+// one core (20 GB/s: 1.8 s for config 5's graph).  Worth it only since the uploads are staged (rt_hip.h): pages
+// the runtime has copied from directly come back ten times slower, whoever frees them.
+void mapping_registry_add(void *p, size_t bytes);
+void mapping_registry_remove(void *p);
+void mapping_registry_drop_all();
+
 // Uninitialised array of trivially copyable T: unlike std::vector it does not zero-fill
 // serially, so the first touch (and its page faults) happens inside the parallel loops.
 // Large arrays are mapped directly and advised to use transparent huge pages: first touch
@@ -112,6 +121,7 @@ class RawArray {
       if (m == MAP_FAILED) { mapped_ = 0; n_ = 0; throw std::bad_alloc(); }
       madvise(m, mapped_, MADV_HUGEPAGE);
       p_ = (T *)m;
+      mapping_registry_add(m, mapped_);
     } else {
       p_ = (T *)malloc(bytes);
       if (!p_) { n_ = 0; throw std::bad_alloc(); }
@@ -129,7 +139,7 @@ class RawArray {
  private:
   static constexpr size_t kHuge = (size_t)2 << 20;
   void release() {
-    if (mapped_) unmap_parallel(p_, mapped_); else free(p_);
+    if (mapped_) { mapping_registry_remove(p_); unmap_parallel(p_, mapped_); } else free(p_);
     p_ = nullptr; n_ = 0; mapped_ = 0;
   }
   T *p_ = nullptr;

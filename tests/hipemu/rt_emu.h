@@ -29,6 +29,7 @@ inline void (*&oom_hook())(int) {
 inline void *dmalloc(size_t n) { return malloc(n ? n : 16); }
 inline void dfree(void *p) { free(p); }
 inline void h2d(void *d, const void *h, size_t n, stream_t) { if (n) memcpy(d, h, n); }
+inline void stage_trim() {}
 inline void d2h(void *h, const void *d, size_t n, stream_t) { if (n) memcpy(h, d, n); }
 inline void d2d(void *dst, const void *src, size_t n, stream_t) { if (n) memcpy(dst, src, n); }
 inline void dmemset(void *d, int v, size_t n, stream_t) { if (n) memset(d, v, n); }
