@@ -1049,7 +1049,9 @@ void mapping_registry_drop_all() {
     for (size_t i; (i = next.fetch_add(1)) < steps.size();) madvise(steps[i].p, steps[i].n, MADV_DONTNEED);
   };
   std::vector<std::thread> th;
-  for (uint32_t t = 1; t < T; ++t) th.emplace_back(work);
+  for (uint32_t t = 1; t < T; ++t) {
+    try { th.emplace_back(work); } catch (...) { break; }
+  }
   work();
   for (auto &t : th) t.join();
 }

@@ -73,7 +73,10 @@ inline void unmap_parallel(void *p, size_t bytes) {
         madvise((char *)p + i * kStep, std::min(kStep, bytes - i * kStep), MADV_DONTNEED);
     };
     std::vector<std::thread> th;
-    for (uint32_t t = 1; t < T; ++t) th.emplace_back(work);
+    for (uint32_t t = 1; t < T; ++t) {
+      // (called from destructors: a thread that cannot be started is done without)
+      try { th.emplace_back(work); } catch (...) { break; }
+    }
     work();
     for (auto &t : th) t.join();
   }
