@@ -923,7 +923,11 @@ void quick_exit_if_done(int exit_code) {
   fflush(nullptr);
   // the pages of every large host array, handed back by all threads (the exit would clear them on one core;
   // this only pays since the uploads are staged -- rt_hip.h -- and the arrays' pages therefore ordinary ones)
+  const auto t_drop = std::chrono::steady_clock::now();
   if (!getenv("DWX_NO_EXIT_DROP")) dwx::mapping_registry_drop_all();   // (A/B knob)
+  if (getenv("DWX_TIMING"))
+    fprintf(stderr, "[dw timing] host arrays handed back: %g s\n",
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t_drop).count());
   if (getenv("DWX_TIMING")) {
     fprintf(stderr, "[dw timing] teardown (device + graph): skipped (process exit)\n");
     // (tools/e2e_walltime.py: what the process exit itself costs = the caller's clock - this)
